@@ -1,0 +1,38 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- see lago_oracle_impl.h.
+ *
+ * CPU oracle for the lagomorph deform/interp/metric/adjrep hot path: a scalar,
+ * single-threaded C restatement of the reference's CUDA kernels
+ * (/root/reference/lagomorph/extension/cuda/{interp,diff,metric,affine}.cu and
+ * include/{interp,extrap,diff}.h), instantiated for float and double.
+ *
+ * Pinning (see oracle/README.md): the known-answer table of SURVEY.md 8(c)
+ * (tests/golden/kat_survey.json), the reference's own property tests
+ * (testing/test_*.py restated in tests/test_oracle_properties.py), and
+ * bit-exact agreement of oracle_affine_interp_forward_cpuref_* with
+ * oracle/_ref (the reference's cpu/affine.cpp compiled where it lies).
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off; strict IEEE evaluation)
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define REAL float
+#define SUF _f32
+#define LG_SQRT sqrtf
+#include "lago_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef LG_SQRT
+
+#define REAL double
+#define SUF _f64
+#define LG_SQRT sqrt
+#include "lago_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef LG_SQRT
+
+const char *oracle_version(void) { return "lago-oracle 1 (scalar C, strict IEEE, 1 thread)"; }
