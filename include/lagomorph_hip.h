@@ -1,0 +1,126 @@
+/*
+ * lagomorph_hip.h -- C ABI of liblagomorph_hip.so, the MI355X (gfx950) HIP
+ * implementation of lagomorph's deform / interp / metric / adjrep hot path.
+ *
+ * This is the drop-in boundary: each entry point replaces one function of the
+ * reference's `lagomorph_ext` pybind11 module
+ * (/root/reference/lagomorph/extension/extension.cpp:175-189).  Signatures are
+ * plain C: raw device pointers, 64-bit extents, scalar parameters, flags, and
+ * the hipStream_t to launch on (as void*; NULL = the null stream).  No torch
+ * types, no allocation, no host synchronisation (except in debug mode).
+ *
+ * Conventions
+ *  - Every tensor is dense, contiguous, batch-major N C (D) H W with the LAST
+ *    spatial axis fastest, exactly as the reference indexes it
+ *    (include/extrap.h:15-21: index = (x*sizeY + y)*sizeZ + z).
+ *  - `dim` is 2 or 3.  For dim == 2 pass nz = 1 (ignored).
+ *  - Each function exists for float (`_f32`) and double (`_f64`); the
+ *    reference dispatches both via AT_DISPATCH_FLOATING_TYPES.
+ *  - Outputs are written in full by the call (splat targets are zeroed on the
+ *    stream before the kernel), so callers may pass uninitialised buffers.
+ *  - Return value: LAGO_OK (0), LAGO_ERR_INVALID (-1: bad argument; nothing
+ *    was launched) or LAGO_ERR_HIP (-2: a HIP runtime call failed).
+ *    lago_last_error() returns a thread-local description.
+ *  - Extent limits: nx*ny*nz < 2^31 per batch item; total elements per tensor
+ *    are addressed with 64-bit offsets.
+ */
+#ifndef LAGOMORPH_HIP_H
+#define LAGOMORPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAGO_OK 0
+#define LAGO_ERR_INVALID (-1)
+#define LAGO_ERR_HIP (-2)
+
+#define LAGO_ABI_VERSION 1
+
+/* ---- housekeeping --------------------------------------------------------- */
+
+/* replaces set_debug_mode (extension.cpp:105-107): when non-zero every entry
+ * point synchronises its stream after the launch and reports kernel faults
+ * through its return value (the reference only printed them, defs.h:17-23). */
+void lago_set_debug(int on);
+int lago_get_debug(void);
+int lago_abi_version(void);
+const char *lago_version(void);
+const char *lago_last_error(void);
+
+/* Tuning knob for interp_backward: 0 = global float atomics only,
+ * 1 = LDS-privatised splat with atomic flush (default for 3D f32). */
+void lago_set_splat_mode(int mode);
+int lago_get_splat_mode(void);
+/* Tuning hook for the LDS-privatised splat: source tile TX x TY x TZ (TZ = 0:
+ * whole rows when nz <= 192), window margins MX MY MZ, threads per workgroup
+ * (256 / 512 / 1024).  Affects speed only, never results. */
+void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
+
+#define LAGO_DECLARE(REAL, SUF)                                                                                      \
+    /* interp_forward (extension.cpp:135-143 -> cuda/interp.cu:80-130):                                           \
+     * out[n,c,x] = lerp(I[n or 0,c], x + dt*u[n,:,x]), clamp boundary.                                             \
+     * I: (broadcast_I ? 1 : nn, nc, sp)  u: (nn, dim, sp)  out: (nn, nc, sp) */                                    \
+    int lago_interp_forward##SUF(REAL *out, const REAL *I, const REAL *u, double dt, int dim, int64_t nn,           \
+                                 int64_t nc, int64_t nx, int64_t ny, int64_t nz, int broadcast_I, void *stream);    \
+    /* interp_backward (extension.cpp:145-156 -> cuda/interp.cu:246-313): d_I like I (splat of grad_out),           \
+     * d_u like u.  Both are always produced; a gradient that is not needed is all zeros, as in the reference. */   \
+    int lago_interp_backward##SUF(REAL *d_I, REAL *d_u, const REAL *grad_out, const REAL *I, const REAL *u,         \
+                                  double dt, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz,   \
+                                  int broadcast_I, int need_I, int need_u, void *stream);                           \
+    /* interp_hessian_diagonal_image (cuda/interp.cu:351-381), 2D only.  out like I: (nI, nc, nx, ny);              \
+     * as in the reference every (n, c) accumulates into plane 0 of out. */                                         \
+    int lago_interp_hessian_diagonal_image##SUF(REAL *out, const REAL *u, double dt, int64_t nI, int64_t nn,        \
+                                                int64_t nc, int64_t nx, int64_t ny, void *stream);                  \
+    /* jacobian_times_vectorfield_forward (cuda/diff.cu:129-185).  v: (nn, nc, sp) is differentiated,               \
+     * w: (nn, dim, sp) is contracted; out like v.  displacement/transpose require nc == dim. */                    \
+    int lago_jtv_forward##SUF(REAL *out, const REAL *v, const REAL *w, int displacement, int transpose, int dim,    \
+                              int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, void *stream);            \
+    /* jacobian_times_vectorfield_backward (cuda/diff.cu:475-540): d_v like v, d_w like w, both always. */          \
+    int lago_jtv_backward##SUF(REAL *d_v, REAL *d_w, const REAL *grad_out, const REAL *v, const REAL *w,            \
+                               int displacement, int transpose, int dim, int64_t nn, int64_t nc, int64_t nx,        \
+                               int64_t ny, int64_t nz, void *stream);                                               \
+    /* jacobian_times_vectorfield_adjoint_forward (cuda/diff.cu:634-672): out[c] = sum_d D_d^T (w_d z_c).           \
+     * z: (nn, nc, sp), w: (nn, dim, sp), out like z. */                                                            \
+    int lago_jtv_adjoint_forward##SUF(REAL *out, const REAL *z, const REAL *w, int dim, int64_t nn, int64_t nc,     \
+                                      int64_t nx, int64_t ny, int64_t nz, void *stream);                            \
+    /* jacobian_times_vectorfield_adjoint_backward (cuda/diff.cu:783-835), nc == dim. */                            \
+    int lago_jtv_adjoint_backward##SUF(REAL *d_v, REAL *d_w, const REAL *grad_out, const REAL *v, const REAL *w,    \
+                                       int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream);      \
+    /* fluid_operator (extension.cpp:158-173 -> cuda/metric.cu:308-355): in place on the interleaved-complex        \
+     * rFFT buffer Fm of shape (nn, dim, nx, ny[, nz], 2) where the last spatial extent is the half-spectrum        \
+     * length; cos/sin LUTs have nx, ny, nz entries (cosZ/sinZ unused for dim == 2). */                             \
+    int lago_fluid_operator##SUF(REAL *Fm, int inverse, const REAL *cosX, const REAL *sinX, const REAL *cosY,       \
+                                 const REAL *sinY, const REAL *cosZ, const REAL *sinZ, double alpha, double beta,   \
+                                 double gamma, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz,             \
+                                 void *stream);                                                                     \
+    /* affine_interp_forward (extension.cpp:109-118 -> cuda/affine.cu:114-169).                                     \
+     * I: (broadcast_I ? 1 : nn, nc, sp)  A: (nn, dim, dim)  T: (nn, dim)  out: (nn, nc, sp) */                     \
+    int lago_affine_interp_forward##SUF(REAL *out, const REAL *I, const REAL *A, const REAL *T, int dim,            \
+                                        int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz,                 \
+                                        int broadcast_I, void *stream);                                             \
+    /* affine_interp_backward (extension.cpp:120-133 -> cuda/affine.cu:538-610).  Outputs that are not needed       \
+     * may be NULL (the reference returns size-0 tensors for them). */                                              \
+    int lago_affine_interp_backward##SUF(REAL *d_I, REAL *d_A, REAL *d_T, const REAL *grad_out, const REAL *I,      \
+                                         const REAL *A, const REAL *T, int dim, int64_t nn, int64_t nc,             \
+                                         int64_t nx, int64_t ny, int64_t nz, int broadcast_I, int need_I,           \
+                                         int need_A, int need_T, void *stream);                                     \
+    /* regrid_forward (cuda/affine.cu:683-734): resample I (nn, nc, nx, ny, nz) onto an (Nx, Ny, Nz) grid with      \
+     * the given origin/spacing (length-dim host arrays of doubles). */                                             \
+    int lago_regrid_forward##SUF(REAL *out, const REAL *I, int dim, int64_t nn, int64_t nc, int64_t nx,             \
+                                 int64_t ny, int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz, const double *origin,  \
+                                 const double *spacing, void *stream);                                              \
+    /* regrid_backward (cuda/affine.cu:802-855): splat grad_out (nn, nc, Nx, Ny, Nz) back onto (nx, ny, nz). */     \
+    int lago_regrid_backward##SUF(REAL *d_I, const REAL *grad_out, int dim, int64_t nn, int64_t nc, int64_t nx,     \
+                                  int64_t ny, int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz,                       \
+                                  const double *origin, const double *spacing, void *stream);
+
+LAGO_DECLARE(float, _f32)
+LAGO_DECLARE(double, _f64)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAGOMORPH_HIP_H */

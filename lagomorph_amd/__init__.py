@@ -1,0 +1,17 @@
+"""lagomorph_amd -- MI355X-native LDDMM hot path behind lagomorph's operator surface.
+
+Importing this package requires the built HIP library (no CPU fallback).
+"""
+from .adjrep import *  # noqa: F401,F403
+from .adjrep import Ad, Ad_dagger, Ad_star, ad, ad_dagger, ad_star, sym, sym_dagger  # noqa: F401
+from .affine import (AffineInterp, AffineInterpFunction, RegridFunction, RegridModule, affine_interp,  # noqa: F401
+                     affine_inverse, det_2x2, invert_2x2, invert_3x3, regrid, rigid_inverse, rotation_exp_map)
+from .deform import (InterpFunction, compose, compose_disp_vel, compose_vel_disp, identity, interp,  # noqa: F401
+                     interp_hessian_diagonal_image)
+from .diff import (JacobianTimesVectorFieldAdjointFunction, JacobianTimesVectorFieldFunction,  # noqa: F401
+                   jacobian_times_vectorfield, jacobian_times_vectorfield_adjoint)
+from .lagomorph_ext import set_debug_mode  # noqa: F401
+from .lddmm import EPDiff_step, LDDMMAtlasBuilder, expmap, expmap_advect, lddmm_step  # noqa: F401
+from .metric import FluidMetric, FluidMetricOperator, Metric  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,51 @@
+r"""Adjoint representation of Diff(R^d) on velocities and momenta.
+
+Host-side mirror of ``/root/reference/lagomorph/adjrep.py`` (same formulas).
+"""
+from .deform import interp
+from .diff import jacobian_times_vectorfield, jacobian_times_vectorfield_adjoint
+
+
+def ad(v, w):
+    r"""ad(v, w) = Dv w - Dw v   (adjrep.py:37-47)"""
+    return jacobian_times_vectorfield(v, w, displacement=False) - jacobian_times_vectorfield(
+        w, v, displacement=False
+    )
+
+
+def Ad(phi, v):
+    """Big adjoint action; not implemented in the reference either (adjrep.py:50-66)."""
+    raise NotImplementedError
+
+
+def ad_star(v, m):
+    r"""ad^*(v, m) = (Dv)^T m + Dm v + m div v, as the numerical adjoint of ad(v, .)  (adjrep.py:69-83)"""
+    return jacobian_times_vectorfield(v, m, displacement=False, transpose=True) - jacobian_times_vectorfield_adjoint(
+        m, v
+    )
+
+
+def Ad_star(phiinv, m):
+    r"""Ad^*(phi, m)(x) = (D phi(x)) m(phi(x)); note the non-transposed product (adjrep.py:86-97)"""
+    mphiinv = interp(m, phiinv)
+    return jacobian_times_vectorfield(phiinv, mphiinv, displacement=True)
+
+
+def ad_dagger(x, y, metric):
+    r"""ad^dagger(x, y) = ad^*(x, y^flat)^sharp   (adjrep.py:104-113)"""
+    return metric.sharp(ad_star(x, metric.flat(y)))
+
+
+def Ad_dagger(phi, y, metric):
+    r"""Ad^dagger(phi, y) = Ad^*(phi, y^flat)^sharp   (adjrep.py:116-122)"""
+    return metric.sharp(Ad_star(phi, metric.flat(y)))
+
+
+def sym(x, y, metric):
+    r"""sym(x, y) = -(ad^dagger(x, y) + ad^dagger(y, x))   (adjrep.py:125-135)"""
+    return -(ad_dagger(x, y, metric) + ad_dagger(y, x, metric))
+
+
+def sym_dagger(x, y, metric):
+    r"""sym^dagger(x, y) = ad^dagger(y, x) - ad(x, y)   (adjrep.py:138-145)"""
+    return ad_dagger(y, x, metric) - ad(x, y)

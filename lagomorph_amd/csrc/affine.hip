@@ -1,0 +1,401 @@
+// Affine interpolation and regridding -- gfx950 HIP kernels.
+//
+// Replaces cuda/affine.cu of the reference: affine_interp_kernel_{2,3}d
+// (:23-112), affine_interp_kernel_backward_{2,3}d (:171-536),
+// regrid_forward_kernel_{2,3}d (:612-681), regrid_backward_kernel_{2,3}d
+// (:736-800).  Sample positions are analytic (h = A(x - o) + T + o), so only
+// the image / grad_out rows stream and the lerp corners are gathers.
+//
+// The backward pass of affine_interp reduces g (x) (x - o) and g over a whole
+// image.  The reference uses one 512-thread block per (n, c) with a shared
+// memory tree; here every workgroup reduces its 256 voxels with wavefront
+// shuffles (64 lanes), combines its 4 waves through LDS and issues one float
+// atomic per matrix entry, so the launch fills all 256 CUs.
+#include "common.hpp"
+
+namespace lago {
+
+template <typename R>
+__device__ __forceinline__ R half_extent(int n) {  // `.5*static_cast<Real>(n-1)`, cuda/affine.cu:42-43
+    return (R)(.5 * (double)(R)(n - 1));
+}
+
+// ------------------------------------------------------------------ affine forward
+
+template <typename R, int DIM, bool BC>
+__global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out, const R *__restrict__ I,
+                                                            const R *__restrict__ A, const R *__restrict__ T,
+                                                            int nc, Geom g) {
+    const Vox v = locate(g);
+    if (!v.valid) return;
+    const size_t nv = g.nvox;
+    const R *An = A + (size_t)v.n * DIM * DIM;
+    const R *Tn = T + (size_t)v.n * DIM;
+    const R *In = BC ? I : I + (size_t)v.n * nc * nv;
+    R *on = out + (size_t)v.n * nc * nv + v.s;
+    if (DIM == 3) {
+        const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
+        const R fi = (R)v.i - ox, fj = (R)v.j - oy, fk = (R)v.k - oz;
+        const R hx = An[0] * fi + An[1] * fj + An[2] * fk + Tn[0] + ox;
+        const R hy = An[3] * fi + An[4] * fj + An[5] * fk + Tn[1] + oy;
+        const R hz = An[6] * fi + An[7] * fj + An[8] * fk + Tn[2] + oz;
+        Lerp3<R> L;
+        L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
+        for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
+    } else {
+        const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
+        const R fi = (R)v.j - ox, fj = (R)v.k - oy;
+        const R hx = An[0] * fi + An[1] * fj + Tn[0] + ox;
+        const R hy = An[2] * fi + An[3] * fj + Tn[1] + oy;
+        Lerp2<R> L;
+        L.setup(hx, hy, g.ny, g.nz);
+        for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
+    }
+}
+
+// ------------------------------------------------------------------ affine backward
+
+template <typename R>
+__device__ __forceinline__ R wave_sum(R x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+template <typename R, int DIM, bool BC, bool NEED_I, bool NEED_A, bool NEED_T>
+__global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I, R *__restrict__ d_A,
+                                                            R *__restrict__ d_T, const R *__restrict__ go,
+                                                            const R *__restrict__ I, const R *__restrict__ A,
+                                                            const R *__restrict__ T, int nc, Geom g) {
+    constexpr int NP = DIM * DIM + DIM;
+    __shared__ R red[kBlock / 64][NP];
+    const Vox v = locate(g);  // v.n is uniform per workgroup
+    const size_t nv = g.nvox;
+    R p[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) p[q] = 0;
+    if (v.valid) {
+        const R *An = A + (size_t)v.n * DIM * DIM;
+        const R *Tn = T + (size_t)v.n * DIM;
+        const R *In = BC ? I : I + (size_t)v.n * nc * nv;
+        R *dIn = NEED_I ? (BC ? d_I : d_I + (size_t)v.n * nc * nv) : nullptr;
+        const R *gon = go + (size_t)v.n * nc * nv + v.s;
+        if (DIM == 3) {
+            const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
+            const R fi = (R)v.i - ox, fj = (R)v.j - oy, fk = (R)v.k - oz;
+            const R hx = An[0] * fi + An[1] * fj + An[2] * fk + Tn[0] + ox;
+            const R hy = An[3] * fi + An[4] * fj + An[5] * fk + Tn[1] + oy;
+            const R hz = An[6] * fi + An[7] * fj + An[8] * fk + Tn[2] + oz;
+            Splat3<R> S;
+            Lerp3<R> L;
+            if (NEED_I) S.setup(hx, hy, hz, g.nx, g.ny, g.nz);
+            if (NEED_A || NEED_T) L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
+            for (int c = 0; c < nc; ++c) {
+                const R diff = gon[(size_t)c * nv];
+                if (NEED_I) {
+                    R *dIc = dIn + (size_t)c * nv;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) atomic_add(dIc + S.o[q], S.w[q] * diff);
+                }
+                if (NEED_A || NEED_T) {
+                    R gx, gy, gz;
+                    L.grad(In + (size_t)c * nv, gx, gy, gz);
+                    gx *= diff; gy *= diff; gz *= diff;  // cuda/affine.cu:415-417
+                    if (NEED_A) {
+                        p[0] += gx * fi; p[1] += gx * fj; p[2] += gx * fk;
+                        p[3] += gy * fi; p[4] += gy * fj; p[5] += gy * fk;
+                        p[6] += gz * fi; p[7] += gz * fj; p[8] += gz * fk;
+                    }
+                    if (NEED_T) { p[9] += gx; p[10] += gy; p[11] += gz; }
+                }
+            }
+        } else {
+            const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
+            const R fi = (R)v.j - ox, fj = (R)v.k - oy;
+            const R hx = An[0] * fi + An[1] * fj + Tn[0] + ox;
+            const R hy = An[2] * fi + An[3] * fj + Tn[1] + oy;
+            Splat2<R> S;
+            Lerp2<R> L;
+            if (NEED_I) S.setup(hx, hy, g.ny, g.nz);
+            if (NEED_A || NEED_T) L.setup(hx, hy, g.ny, g.nz);
+            for (int c = 0; c < nc; ++c) {
+                const R diff = gon[(size_t)c * nv];
+                if (NEED_I) {
+                    R *dIc = dIn + (size_t)c * nv;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) atomic_add(dIc + S.o[q], S.w[q] * diff);
+                }
+                if (NEED_A || NEED_T) {
+                    R gx, gy;
+                    L.grad(In + (size_t)c * nv, gx, gy);
+                    gx *= diff; gy *= diff;  // cuda/affine.cu:241-242
+                    if (NEED_A) { p[0] += gx * fi; p[1] += gx * fj; p[2] += gy * fi; p[3] += gy * fj; }
+                    if (NEED_T) { p[4] += gx; p[5] += gy; }
+                }
+            }
+        }
+    }
+    if (NEED_A || NEED_T) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            R s = wave_sum(p[q]);
+            if (lane == 0) red[wave][q] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < NP) {
+            const int q = threadIdx.x;
+            R s = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+            if (q < DIM * DIM) {
+                if (NEED_A) atomic_add(d_A + (size_t)v.n * DIM * DIM + q, s);
+            } else {
+                if (NEED_T) atomic_add(d_T + (size_t)v.n * DIM + (q - DIM * DIM), s);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ regrid
+
+struct RegridParams {
+    double O[3], S[3];
+    int nx, ny, nz;  // input (source) extents in geometry order (2D: nx = 1)
+};
+
+// Output-grid geometry in g; input extents in rp.
+template <typename R, int DIM>
+__global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out, const R *__restrict__ I,
+                                                            int nq, Geom g, RegridParams rp) {
+    const Vox v = locate(g);  // v.n unused: (n, c) planes are looped here
+    if (!v.valid) return;
+    const size_t Nv = g.nvox;
+    const size_t nvin = (size_t)rp.nx * rp.ny * rp.nz;
+    if (DIM == 3) {
+        const R Ox = (R)rp.O[0], Oy = (R)rp.O[1], Oz = (R)rp.O[2];
+        const R Sx = (R)rp.S[0], Sy = (R)rp.S[1], Sz = (R)rp.S[2];
+        const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
+        const R hx = ((R)v.i - ox) * Sx + Ox;
+        const R hy = ((R)v.j - oy) * Sy + Oy;
+        // The reference advances hz by `hz += Sz` per output k (cuda/affine.cu:669-675):
+        // a sequentially rounded running sum, reproduced here so positions match bit for bit.
+        R hz = Oz - oz * Sz;
+        for (int k = 0; k < v.k; ++k) hz += Sz;
+        Lerp3<R> L;
+        L.setup(hx, hy, hz, rp.nx, rp.ny, rp.nz);
+        for (int q = 0; q < nq; ++q) out[(size_t)q * Nv + v.s] = L.value(I + (size_t)q * nvin);
+    } else {
+        const R Ox = (R)rp.O[0], Oy = (R)rp.O[1];
+        const R Sx = (R)rp.S[0], Sy = (R)rp.S[1];
+        const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
+        const R hx = ((R)v.j - ox) * Sx + Ox;
+        const R hy = ((R)v.k - oy) * Sy + Oy;
+        Lerp2<R> L;
+        L.setup(hx, hy, rp.ny, rp.nz);
+        for (int q = 0; q < nq; ++q) out[(size_t)q * Nv + v.s] = L.value(I + (size_t)q * nvin);
+    }
+}
+
+template <typename R, int DIM>
+__global__ __launch_bounds__(kBlock) void regrid_bwd_kernel(R *__restrict__ d_I, const R *__restrict__ go, int nq,
+                                                            Geom g, RegridParams rp) {
+    const Vox v = locate(g);
+    if (!v.valid) return;
+    const size_t Nv = g.nvox;
+    const size_t nvin = (size_t)rp.nx * rp.ny * rp.nz;
+    if (DIM == 3) {
+        const R Ox = (R)rp.O[0], Oy = (R)rp.O[1], Oz = (R)rp.O[2];
+        const R Sx = (R)rp.S[0], Sy = (R)rp.S[1], Sz = (R)rp.S[2];
+        const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
+        const R hx = ((R)v.i - ox) * Sx + Ox;
+        const R hy = ((R)v.j - oy) * Sy + Oy;
+        const R hz = ((R)v.k - oz) * Sz + Oz;  // cuda/affine.cu:791: per voxel, no running sum
+        Splat3<R> S;
+        S.setup(hx, hy, hz, rp.nx, rp.ny, rp.nz);
+        for (int q = 0; q < nq; ++q) {
+            const R m = go[(size_t)q * Nv + v.s];
+            R *d = d_I + (size_t)q * nvin;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomic_add(d + S.o[e], S.w[e] * m);
+        }
+    } else {
+        const R Ox = (R)rp.O[0], Oy = (R)rp.O[1];
+        const R Sx = (R)rp.S[0], Sy = (R)rp.S[1];
+        const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
+        const R hx = ((R)v.j - ox) * Sx + Ox;
+        const R hy = ((R)v.k - oy) * Sy + Oy;
+        Splat2<R> S;
+        S.setup(hx, hy, rp.ny, rp.nz);
+        for (int q = 0; q < nq; ++q) {
+            const R m = go[(size_t)q * Nv + v.s];
+            R *d = d_I + (size_t)q * nvin;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomic_add(d + S.o[e], S.w[e] * m);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host entry points
+
+template <typename R>
+static int affine_forward_impl(R *out, const R *I, const R *A, const R *T, int dim, int64_t nn, int64_t nc,
+                               int64_t nx, int64_t ny, int64_t nz, int bc, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional affine interpolation is supported");
+    Geom g;
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("affine_interp_forward: bad extent");
+    if (g.nblocks == 0 || nc == 0) return LAGO_OK;
+    if (!out || !I || !A || !T) return fail_invalid("affine_interp_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(D, B) \
+    hipLaunchKernelGGL((affine_fwd_kernel<R, D, B>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, g)
+    if (dim == 3) {
+        if (bc) LAUNCH(3, true); else LAUNCH(3, false);
+    } else {
+        if (bc) LAUNCH(2, true); else LAUNCH(2, false);
+    }
+#undef LAUNCH
+    return finish_launch(s, "affine_interp_forward");
+}
+
+template <typename R, int DIM, bool BC>
+static void launch_affine_bwd(R *d_I, R *d_A, R *d_T, const R *go, const R *I, const R *A, const R *T, int nc,
+                              const Geom &g, bool nI, bool nA, bool nT, hipStream_t s) {
+#define LAUNCH(a, b, c)                                                                                             \
+    hipLaunchKernelGGL((affine_bwd_kernel<R, DIM, BC, a, b, c>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, d_A, d_T, \
+                       go, I, A, T, nc, g)
+    const int m = (nI ? 4 : 0) | (nA ? 2 : 0) | (nT ? 1 : 0);
+    switch (m) {
+        case 7: LAUNCH(true, true, true); break;
+        case 6: LAUNCH(true, true, false); break;
+        case 5: LAUNCH(true, false, true); break;
+        case 4: LAUNCH(true, false, false); break;
+        case 3: LAUNCH(false, true, true); break;
+        case 2: LAUNCH(false, true, false); break;
+        case 1: LAUNCH(false, false, true); break;
+        default: break;
+    }
+#undef LAUNCH
+}
+
+template <typename R>
+static int affine_backward_impl(R *d_I, R *d_A, R *d_T, const R *go, const R *I, const R *A, const R *T, int dim,
+                                int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc, int need_I,
+                                int need_A, int need_T, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional affine interpolation is supported");
+    Geom g;
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("affine_interp_backward: bad extent");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nI = (size_t)(bc ? 1 : nn) * nc * g.nvox;
+    if ((need_I && nI && !d_I) || (need_A && nn && !d_A) || (need_T && nn && !d_T) ||
+        (g.nblocks && nc && (!go || !I || !A || !T)))
+        return fail_invalid("affine_interp_backward: null pointer");
+    if (need_I && nI) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
+    if (need_A && nn) LAGO_HIP_TRY(hipMemsetAsync(d_A, 0, (size_t)nn * dim * dim * sizeof(R), s));
+    if (need_T && nn) LAGO_HIP_TRY(hipMemsetAsync(d_T, 0, (size_t)nn * dim * sizeof(R), s));
+    if (g.nblocks && nc && (need_I || need_A || need_T)) {
+        if (dim == 3) {
+            if (bc) launch_affine_bwd<R, 3, true>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
+            else launch_affine_bwd<R, 3, false>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
+        } else {
+            if (bc) launch_affine_bwd<R, 2, true>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
+            else launch_affine_bwd<R, 2, false>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
+        }
+    }
+    return finish_launch(s, "affine_interp_backward");
+}
+
+static bool make_regrid(RegridParams &rp, int dim, int64_t nx, int64_t ny, int64_t nz, const double *origin,
+                        const double *spacing) {
+    if (!origin || !spacing) return false;
+    if (dim == 2) {
+        nz = ny;
+        ny = nx;
+        nx = 1;
+    }
+    if (nx < 1 || ny < 1 || nz < 1 || nx * ny * nz >= (1ll << 31)) return false;
+    rp.nx = (int)nx;
+    rp.ny = (int)ny;
+    rp.nz = (int)nz;
+    for (int d = 0; d < 3; ++d) {
+        rp.O[d] = d < dim ? origin[d] : 0.0;
+        rp.S[d] = d < dim ? spacing[d] : 0.0;
+    }
+    return true;
+}
+
+template <typename R>
+static int regrid_forward_impl(R *out, const R *I, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny,
+                               int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz, const double *origin,
+                               const double *spacing, void *stream) {
+    if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional regridding is supported");
+    Geom g;
+    RegridParams rp;
+    if (nn < 0 || nc < 0 || nn * nc >= (1ll << 31) || !make_geom(g, dim, 1, Nx, Ny, Nz) ||
+        !make_regrid(rp, dim, nx, ny, nz, origin, spacing))
+        return fail_invalid("regrid_forward: bad extent");
+    if (g.nblocks == 0 || nn * nc == 0) return LAGO_OK;
+    if (!out || !I) return fail_invalid("regrid_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dim == 3)
+        hipLaunchKernelGGL((regrid_fwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp);
+    else
+        hipLaunchKernelGGL((regrid_fwd_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp);
+    return finish_launch(s, "regrid_forward");
+}
+
+template <typename R>
+static int regrid_backward_impl(R *d_I, const R *go, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny,
+                                int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz, const double *origin,
+                                const double *spacing, void *stream) {
+    if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional regridding is supported");
+    Geom g;
+    RegridParams rp;
+    if (nn < 0 || nc < 0 || nn * nc >= (1ll << 31) || !make_geom(g, dim, 1, Nx, Ny, Nz) ||
+        !make_regrid(rp, dim, nx, ny, nz, origin, spacing))
+        return fail_invalid("regrid_backward: bad extent");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nI = (size_t)nn * nc * rp.nx * rp.ny * rp.nz;
+    if ((nI && !d_I) || (nI && g.nblocks && !go)) return fail_invalid("regrid_backward: null pointer");
+    if (nI) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
+    if (g.nblocks && nn * nc) {
+        if (dim == 3)
+            hipLaunchKernelGGL((regrid_bwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, go, (int)(nn * nc), g, rp);
+        else
+            hipLaunchKernelGGL((regrid_bwd_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, go, (int)(nn * nc), g, rp);
+    }
+    return finish_launch(s, "regrid_backward");
+}
+
+}  // namespace lago
+
+extern "C" {
+#define LAGO_DEFINE(REAL, SUF)                                                                                      \
+    int lago_affine_interp_forward##SUF(REAL *out, const REAL *I, const REAL *A, const REAL *T, int dim,           \
+                                        int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc,        \
+                                        void *stream) {                                                            \
+        return lago::affine_forward_impl<REAL>(out, I, A, T, dim, nn, nc, nx, ny, nz, bc, stream);                 \
+    }                                                                                                               \
+    int lago_affine_interp_backward##SUF(REAL *d_I, REAL *d_A, REAL *d_T, const REAL *go, const REAL *I,           \
+                                         const REAL *A, const REAL *T, int dim, int64_t nn, int64_t nc,            \
+                                         int64_t nx, int64_t ny, int64_t nz, int bc, int need_I, int need_A,       \
+                                         int need_T, void *stream) {                                               \
+        return lago::affine_backward_impl<REAL>(d_I, d_A, d_T, go, I, A, T, dim, nn, nc, nx, ny, nz, bc, need_I,   \
+                                                need_A, need_T, stream);                                           \
+    }                                                                                                               \
+    int lago_regrid_forward##SUF(REAL *out, const REAL *I, int dim, int64_t nn, int64_t nc, int64_t nx,            \
+                                 int64_t ny, int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz, const double *origin, \
+                                 const double *spacing, void *stream) {                                            \
+        return lago::regrid_forward_impl<REAL>(out, I, dim, nn, nc, nx, ny, nz, Nx, Ny, Nz, origin, spacing,       \
+                                               stream);                                                            \
+    }                                                                                                               \
+    int lago_regrid_backward##SUF(REAL *d_I, const REAL *go, int dim, int64_t nn, int64_t nc, int64_t nx,          \
+                                  int64_t ny, int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz,                      \
+                                  const double *origin, const double *spacing, void *stream) {                     \
+        return lago::regrid_backward_impl<REAL>(d_I, go, dim, nn, nc, nx, ny, nz, Nx, Ny, Nz, origin, spacing,     \
+                                                stream);                                                           \
+    }
+LAGO_DEFINE(float, _f32)
+LAGO_DEFINE(double, _f64)
+#undef LAGO_DEFINE
+}

@@ -1,0 +1,329 @@
+// Finite-difference Jacobian-times-vector-field family -- gfx950 HIP kernels.
+//
+// Replaces cuda/diff.cu of the reference: forward (:17-127), backward
+// (:187-473), adjoint forward (:546-632) and adjoint backward (:674-780).
+// Central differences with index clamp (include/diff.h:7-76 over
+// get_value_safe<CLAMP>, include/extrap.h:110-192), i.e. a one-sided half
+// difference at the borders; the adjoint stencils are the reference's explicit
+// three-case border formulas.
+//
+// One lane per voxel of the flattened (i, j, k) index, last axis fastest: the
+// centre row of every operand streams as 256-byte wavefront rows, the +-1 row
+// and +-1 slab neighbours are re-reads served by L1 / the XCD's L2 (workgroups
+// of one XCD walk a contiguous range, common.hpp).
+#include "common.hpp"
+
+namespace lago {
+
+// Signed element offsets of the clamped +-1 neighbours along the DIM axes, the
+// position/extent on each axis and the plain axis strides.
+template <int DIM>
+struct Stencil {
+    int plus[DIM], minus[DIM];  // clamped: 0 at the respective border
+    int stride[DIM];
+    int pos[DIM], len[DIM];
+    __device__ __forceinline__ Stencil(const Geom &g, const Vox &v) {
+        const int P[3] = {v.i, v.j, v.k};
+        const int Ln[3] = {g.nx, g.ny, g.nz};
+        const int St[3] = {g.ny * g.nz, g.nz, 1};
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            const int a = d + 3 - DIM;  // 2D fields live on geometry axes (y, z)
+            pos[d] = P[a];
+            len[d] = Ln[a];
+            stride[d] = St[a];
+            plus[d] = P[a] + 1 < Ln[a] ? St[a] : 0;
+            minus[d] = P[a] > 0 ? -St[a] : 0;
+        }
+    }
+    // include/diff.h:55-76 grad_point
+    template <typename R>
+    __device__ __forceinline__ void grad(const R *__restrict__ f, R *gq) const {
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) gq[d] = (R)0.5f * (f[plus[d]] - f[minus[d]]);
+    }
+    // Adjoint of the clamped central difference along axis d applied to a*b
+    // (cuda/diff.cu:224-248, 334-391, 560-573, 603-620).  a, b point at the centre voxel.
+    template <typename R>
+    __device__ __forceinline__ R dT(const R *__restrict__ a, const R *__restrict__ b, int d) const {
+        const int st = stride[d];
+        if (pos[d] == 0) return (R)(-.5) * (a[0] * b[0] + a[st] * b[st]);
+        if (pos[d] == len[d] - 1) return (R)(.5) * (a[0] * b[0] + a[-st] * b[-st]);
+        return (R)(-.5) * (a[st] * b[st] - a[-st] * b[-st]);
+    }
+};
+
+template <typename R, int DIM>
+__device__ __forceinline__ R dotw(const R *g, const R *w) {
+    R s = g[0] * w[0] + g[1] * w[1];
+    if (DIM == 3) s = s + g[2] * w[2];
+    return s;
+}
+
+// ------------------------------------------------------------------ (Dv + delta) w and its transpose
+
+template <typename R, int DIM, bool DISP, bool TRANS>
+__global__ __launch_bounds__(kBlock) void jtv_fwd_kernel(R *__restrict__ out, const R *__restrict__ v,
+                                                         const R *__restrict__ w, int nc, Geom g) {
+    const Vox vx = locate(g);
+    if (!vx.valid) return;
+    const size_t nv = g.nvox;
+    const Stencil<DIM> st(g, vx);
+    const R *vn = v + (size_t)vx.n * nc * nv + vx.s;
+    const R *wn = w + (size_t)vx.n * DIM * nv + vx.s;
+    R *on = out + (size_t)vx.n * nc * nv + vx.s;
+    R wv[DIM], gq[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) wv[d] = wn[(size_t)d * nv];
+    if (TRANS) {
+        R acc[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            st.grad(vn + (size_t)c * nv, gq);
+            if (DISP) gq[c] = gq[c] + (R)1.0;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) acc[d] = c == 0 ? gq[d] * wv[c] : acc[d] + gq[d] * wv[c];
+        }
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) on[(size_t)d * nv] = acc[d];
+    } else {
+        for (int c = 0; c < nc; ++c) {
+            st.grad(vn + (size_t)c * nv, gq);
+            if (DISP) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d)
+                    if (c == d) gq[d] = gq[d] + (R)1.0;
+            }
+            on[(size_t)c * nv] = dotw<R, DIM>(gq, wv);
+        }
+    }
+}
+
+template <typename R, int DIM, bool DISP, bool TRANS>
+__global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R *__restrict__ d_w,
+                                                         const R *__restrict__ go, const R *__restrict__ v,
+                                                         const R *__restrict__ w, int nc, Geom g) {
+    const Vox vx = locate(g);
+    if (!vx.valid) return;
+    const size_t nv = g.nvox;
+    const Stencil<DIM> st(g, vx);
+    const R *vn = v + (size_t)vx.n * nc * nv + vx.s;
+    const R *wn = w + (size_t)vx.n * DIM * nv + vx.s;
+    const R *gon = go + (size_t)vx.n * nc * nv + vx.s;
+    R *dvn = d_v + (size_t)vx.n * nc * nv + vx.s;
+    R *dwn = d_w + (size_t)vx.n * DIM * nv + vx.s;
+    R gq[DIM];
+    if (TRANS) {
+        R gov[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) gov[d] = gon[(size_t)d * nv];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            st.grad(vn + (size_t)c * nv, gq);
+            if (DISP) gq[c] = gq[c] + (R)1.0;
+            dwn[(size_t)c * nv] = (R)0 + dotw<R, DIM>(gq, gov);
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            R acc = 0;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) acc = acc + st.dT(wn + (size_t)c * nv, gon + (size_t)d * nv, d);
+            dvn[(size_t)c * nv] = acc;
+        }
+    } else {
+        R dw[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) dw[d] = 0;
+        for (int c = 0; c < nc; ++c) {
+            st.grad(vn + (size_t)c * nv, gq);
+            if (DISP) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d)
+                    if (c == d) gq[d] = gq[d] + (R)1.0;
+            }
+            const R goc = gon[(size_t)c * nv];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) dw[d] = dw[d] + gq[d] * goc;
+            R acc = 0;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) acc = acc + st.dT(wn + (size_t)d * nv, gon + (size_t)c * nv, d);
+            dvn[(size_t)c * nv] = acc;
+        }
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) dwn[(size_t)d * nv] = dw[d];
+    }
+}
+
+// ------------------------------------------------------------------ adjoint in the differentiated argument
+
+template <typename R, int DIM>
+__global__ __launch_bounds__(kBlock) void jtv_adj_fwd_kernel(R *__restrict__ out, const R *__restrict__ z,
+                                                             const R *__restrict__ w, int nc, Geom g) {
+    const Vox vx = locate(g);
+    if (!vx.valid) return;
+    const size_t nv = g.nvox;
+    const Stencil<DIM> st(g, vx);
+    const R *zn = z + (size_t)vx.n * nc * nv + vx.s;
+    const R *wn = w + (size_t)vx.n * DIM * nv + vx.s;
+    R *on = out + (size_t)vx.n * nc * nv + vx.s;
+    for (int c = 0; c < nc; ++c) {
+        R acc = 0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) acc = acc + st.dT(wn + (size_t)d * nv, zn + (size_t)c * nv, d);
+        on[(size_t)c * nv] = acc;
+    }
+}
+
+template <typename R, int DIM>
+__global__ __launch_bounds__(kBlock) void jtv_adj_bwd_kernel(R *__restrict__ d_v, R *__restrict__ d_w,
+                                                             const R *__restrict__ go, const R *__restrict__ v,
+                                                             const R *__restrict__ w, Geom g) {
+    const Vox vx = locate(g);
+    if (!vx.valid) return;
+    const size_t nv = g.nvox;
+    const Stencil<DIM> st(g, vx);
+    const size_t base = (size_t)vx.n * DIM * nv + vx.s;
+    const R *vn = v + base, *wn = w + base, *gon = go + base;
+    R *dvn = d_v + base, *dwn = d_w + base;
+    R wv[DIM], dw[DIM], gq[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) wv[d] = wn[(size_t)d * nv];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+        st.grad(gon + (size_t)c * nv, gq);
+        const R vc = vn[(size_t)c * nv];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) dw[d] = c == 0 ? gq[d] * vc : dw[d] + gq[d] * vc;
+        dvn[(size_t)c * nv] = (R)0 + dotw<R, DIM>(gq, wv);
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) dwn[(size_t)d * nv] = dw[d];
+}
+
+// ------------------------------------------------------------------ host entry points
+
+static bool thin(int dim, int64_t nx, int64_t ny, int64_t nz) {
+    return nx <= 1 || ny <= 1 || (dim == 3 && nz <= 1);
+}
+
+template <typename R>
+static int jtv_forward_impl(R *out, const R *v, const R *w, int disp, int trans, int dim, int64_t nn, int64_t nc,
+                            int64_t nx, int64_t ny, int64_t nz, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional jacobian times vectorfield is supported");
+    if (thin(dim, nx, ny, nz)) return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
+    if (disp && nc != dim) return fail_invalid("Displacement mode only defined for vector fields");
+    if (trans && nc != dim) return fail_invalid("Jacobian transpose only implemented for vector fields");
+    Geom g;
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz))
+        return fail_invalid("jacobian_times_vectorfield_forward: bad extent");
+    if (g.nblocks == 0 || nc == 0) return LAGO_OK;
+    if (!out || !v || !w) return fail_invalid("jacobian_times_vectorfield_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(D, DS, TR) \
+    hipLaunchKernelGGL((jtv_fwd_kernel<R, D, DS, TR>), dim3(g.nblocks), dim3(kBlock), 0, s, out, v, w, (int)nc, g)
+#define BY_FLAGS(D)                                        \
+    do {                                                   \
+        if (disp && trans) LAUNCH(D, true, true);          \
+        else if (disp) LAUNCH(D, true, false);             \
+        else if (trans) LAUNCH(D, false, true);            \
+        else LAUNCH(D, false, false);                      \
+    } while (0)
+    if (dim == 3) BY_FLAGS(3); else BY_FLAGS(2);
+#undef LAUNCH
+    return finish_launch(s, "jacobian_times_vectorfield_forward");
+}
+
+template <typename R>
+static int jtv_backward_impl(R *d_v, R *d_w, const R *go, const R *v, const R *w, int disp, int trans, int dim,
+                             int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional jacobian times vectorfield is supported");
+    if (thin(dim, nx, ny, nz)) return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
+    if (disp && nc != dim) return fail_invalid("Displacement mode only defined for vector fields");
+    if (trans && nc != dim) return fail_invalid("Jacobian transpose only implemented for vector fields");
+    Geom g;
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz))
+        return fail_invalid("jacobian_times_vectorfield_backward: bad extent");
+    hipStream_t s = (hipStream_t)stream;
+    if (g.nblocks == 0) return LAGO_OK;
+    if (!d_w || (nc && (!d_v || !go || !v || !w)))
+        return fail_invalid("jacobian_times_vectorfield_backward: null pointer");
+    if (nc == 0) {  // d_w is all zeros, d_v is empty
+        LAGO_HIP_TRY(hipMemsetAsync(d_w, 0, (size_t)nn * dim * g.nvox * sizeof(R), s));
+        return finish_launch(s, "jacobian_times_vectorfield_backward");
+    }
+#define LAUNCH(D, DS, TR)                                                                                       \
+    hipLaunchKernelGGL((jtv_bwd_kernel<R, D, DS, TR>), dim3(g.nblocks), dim3(kBlock), 0, s, d_v, d_w, go, v, w, \
+                       (int)nc, g)
+    if (dim == 3) BY_FLAGS(3); else BY_FLAGS(2);
+#undef LAUNCH
+#undef BY_FLAGS
+    return finish_launch(s, "jacobian_times_vectorfield_backward");
+}
+
+template <typename R>
+static int jtv_adjoint_forward_impl(R *out, const R *z, const R *w, int dim, int64_t nn, int64_t nc, int64_t nx,
+                                    int64_t ny, int64_t nz, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional jacobian times vectorfield is supported");
+    if (thin(dim, nx, ny, nz)) return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
+    Geom g;
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz))
+        return fail_invalid("jacobian_times_vectorfield_adjoint_forward: bad extent");
+    if (g.nblocks == 0 || nc == 0) return LAGO_OK;
+    if (!out || !z || !w) return fail_invalid("jacobian_times_vectorfield_adjoint_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dim == 3)
+        hipLaunchKernelGGL((jtv_adj_fwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, z, w, (int)nc, g);
+    else
+        hipLaunchKernelGGL((jtv_adj_fwd_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, out, z, w, (int)nc, g);
+    return finish_launch(s, "jacobian_times_vectorfield_adjoint_forward");
+}
+
+template <typename R>
+static int jtv_adjoint_backward_impl(R *d_v, R *d_w, const R *go, const R *v, const R *w, int dim, int64_t nn,
+                                     int64_t nx, int64_t ny, int64_t nz, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional jacobian times vectorfield is supported");
+    if (thin(dim, nx, ny, nz)) return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
+    Geom g;
+    if (!make_geom(g, dim, nn, nx, ny, nz))
+        return fail_invalid("jacobian_times_vectorfield_adjoint_backward: bad extent");
+    if (g.nblocks == 0) return LAGO_OK;
+    if (!d_v || !d_w || !go || !v || !w)
+        return fail_invalid("jacobian_times_vectorfield_adjoint_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dim == 3)
+        hipLaunchKernelGGL((jtv_adj_bwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, d_v, d_w, go, v, w, g);
+    else
+        hipLaunchKernelGGL((jtv_adj_bwd_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, d_v, d_w, go, v, w, g);
+    return finish_launch(s, "jacobian_times_vectorfield_adjoint_backward");
+}
+
+}  // namespace lago
+
+extern "C" {
+#define LAGO_DEFINE(REAL, SUF)                                                                                      \
+    int lago_jtv_forward##SUF(REAL *out, const REAL *v, const REAL *w, int displacement, int transpose, int dim,   \
+                              int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, void *stream) {          \
+        return lago::jtv_forward_impl<REAL>(out, v, w, displacement, transpose, dim, nn, nc, nx, ny, nz, stream);  \
+    }                                                                                                               \
+    int lago_jtv_backward##SUF(REAL *d_v, REAL *d_w, const REAL *go, const REAL *v, const REAL *w,                 \
+                               int displacement, int transpose, int dim, int64_t nn, int64_t nc, int64_t nx,       \
+                               int64_t ny, int64_t nz, void *stream) {                                             \
+        return lago::jtv_backward_impl<REAL>(d_v, d_w, go, v, w, displacement, transpose, dim, nn, nc, nx, ny, nz, \
+                                             stream);                                                              \
+    }                                                                                                               \
+    int lago_jtv_adjoint_forward##SUF(REAL *out, const REAL *z, const REAL *w, int dim, int64_t nn, int64_t nc,    \
+                                      int64_t nx, int64_t ny, int64_t nz, void *stream) {                          \
+        return lago::jtv_adjoint_forward_impl<REAL>(out, z, w, dim, nn, nc, nx, ny, nz, stream);                   \
+    }                                                                                                               \
+    int lago_jtv_adjoint_backward##SUF(REAL *d_v, REAL *d_w, const REAL *go, const REAL *v, const REAL *w,         \
+                                       int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {    \
+        return lago::jtv_adjoint_backward_impl<REAL>(d_v, d_w, go, v, w, dim, nn, nx, ny, nz, stream);             \
+    }
+LAGO_DEFINE(float, _f32)
+LAGO_DEFINE(double, _f64)
+#undef LAGO_DEFINE
+}

@@ -1,0 +1,246 @@
+// Free-form interpolation and its adjoint (splat) -- gfx950 HIP kernels.
+//
+// Replaces cuda/interp.cu of the reference: interp_kernel_{2,3}d (:16-78),
+// interp_kernel_backward_{2,3}d (:132-244) and
+// interp_hessian_diagonal_image_kernel_2d (:317-349).  One lane per output
+// voxel, last axis fastest: u / grad_out / out / d_u stream as 256-byte
+// wavefront rows, the 8 (4) lerp corners are gathers served by L1/L2.
+#include "common.hpp"
+
+namespace lago {
+
+// ------------------------------------------------------------------ forward
+
+template <typename R, int DIM, bool BC>
+__global__ __launch_bounds__(kBlock) void interp_fwd_kernel(R *__restrict__ out, const R *__restrict__ I,
+                                                            const R *__restrict__ u, double dt, int nc, Geom g) {
+    const Vox v = locate(g);
+    if (!v.valid) return;
+    const size_t nv = g.nvox;
+    const R *un = u + (size_t)v.n * DIM * nv + v.s;
+    const R *In = BC ? I : I + (size_t)v.n * nc * nv;
+    R *on = out + (size_t)v.n * nc * nv + v.s;
+    if (DIM == 3) {
+        R hx = sample_pos<R>(v.i, dt, un[0]);
+        R hy = sample_pos<R>(v.j, dt, un[nv]);
+        R hz = sample_pos<R>(v.k, dt, un[2 * nv]);
+        Lerp3<R> L;
+        L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
+        for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
+    } else {
+        R hx = sample_pos<R>(v.j, dt, un[0]);
+        R hy = sample_pos<R>(v.k, dt, un[nv]);
+        Lerp2<R> L;
+        L.setup(hx, hy, g.ny, g.nz);
+        for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
+    }
+}
+
+// ------------------------------------------------------------------ backward, global atomics
+
+template <typename R, int DIM, bool BC, bool NEED_I, bool NEED_U>
+__global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I, R *__restrict__ d_u,
+                                                            const R *__restrict__ go, const R *__restrict__ I,
+                                                            const R *__restrict__ u, double dt, int nc, Geom g) {
+    const Vox v = locate(g);
+    if (!v.valid) return;
+    const size_t nv = g.nvox;
+    const R *un = u + (size_t)v.n * DIM * nv + v.s;
+    const R *In = BC ? I : I + (size_t)v.n * nc * nv;
+    R *dIn = BC ? d_I : d_I + (size_t)v.n * nc * nv;
+    const R *gon = go + (size_t)v.n * nc * nv + v.s;
+    if (DIM == 3) {
+        R hx = sample_pos<R>(v.i, dt, un[0]);
+        R hy = sample_pos<R>(v.j, dt, un[nv]);
+        R hz = sample_pos<R>(v.k, dt, un[2 * nv]);
+        Splat3<R> S;
+        Lerp3<R> L;
+        if (NEED_I) S.setup(hx, hy, hz, g.nx, g.ny, g.nz);
+        if (NEED_U) L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
+        R ax = 0, ay = 0, az = 0;
+        for (int c = 0; c < nc; ++c) {
+            R diff = gon[(size_t)c * nv];
+            if (NEED_I) {
+                R *dIc = dIn + (size_t)c * nv;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) atomic_add(dIc + S.o[q], S.w[q] * diff);
+            }
+            if (NEED_U) {
+                R gx, gy, gz;
+                L.grad(In + (size_t)c * nv, gx, gy, gz);
+                diff = (R)((double)diff * dt);  // cuda/interp.cu:230
+                ax = ax + gx * diff;
+                ay = ay + gy * diff;
+                az = az + gz * diff;
+            }
+        }
+        if (NEED_U) {
+            R *dun = d_u + (size_t)v.n * DIM * nv + v.s;
+            dun[0] = ax;
+            dun[nv] = ay;
+            dun[2 * nv] = az;
+        }
+    } else {
+        R hx = sample_pos<R>(v.j, dt, un[0]);
+        R hy = sample_pos<R>(v.k, dt, un[nv]);
+        Splat2<R> S;
+        Lerp2<R> L;
+        if (NEED_I) S.setup(hx, hy, g.ny, g.nz);
+        if (NEED_U) L.setup(hx, hy, g.ny, g.nz);
+        R ax = 0, ay = 0;
+        for (int c = 0; c < nc; ++c) {
+            R diff = gon[(size_t)c * nv];
+            if (NEED_I) {
+                R *dIc = dIn + (size_t)c * nv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomic_add(dIc + S.o[q], S.w[q] * diff);
+            }
+            if (NEED_U) {
+                R gx, gy;
+                L.grad(In + (size_t)c * nv, gx, gy);
+                diff = (R)((double)diff * dt);  // cuda/interp.cu:171
+                ax = ax + gx * diff;
+                ay = ay + gy * diff;
+            }
+        }
+        if (NEED_U) {
+            R *dun = d_u + (size_t)v.n * DIM * nv + v.s;
+            dun[0] = ax;
+            dun[nv] = ay;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Hessian diagonal (2D)
+
+template <typename R>
+__global__ __launch_bounds__(kBlock) void interp_hessdiag_kernel(R *__restrict__ out, const R *__restrict__ u,
+                                                                 double dt, int nc, Geom g) {
+    const Vox v = locate(g);
+    if (!v.valid) return;
+    const size_t nv = g.nvox;
+    const R *un = u + (size_t)v.n * 2 * nv + v.s;
+    R x = sample_pos<R>(v.j, dt, un[0]);
+    R y = sample_pos<R>(v.k, dt, un[nv]);
+    Lerp2<R> L;
+    L.setup(x, y, g.ny, g.nz);
+    R omt = (R)1.f - L.t, omu = (R)1.f - L.u;
+    R w0 = omt * omu, w1 = L.t * omu, w2 = L.t * L.u, w3 = omt * L.u;  // include/interp.h:522-525
+    for (int c = 0; c < nc; ++c) {  // every (n, c) lands in plane 0 (cuda/interp.cu:342)
+        atomic_add(out + L.o[0], w0 * w0);
+        atomic_add(out + L.o[1], w1 * w1);
+        atomic_add(out + L.o[2], w2 * w2);
+        atomic_add(out + L.o[3], w3 * w3);
+    }
+}
+
+// ------------------------------------------------------------------ host entry points
+
+template <typename R>
+static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int dim, int64_t nn, int64_t nc,
+                               int64_t nx, int64_t ny, int64_t nz, int bc, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional interpolation is supported");
+    Geom g;
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("interp_forward: bad extent");
+    if (g.nblocks == 0 || nc == 0) return LAGO_OK;  // empty batch / no channels: nothing to write
+    if (!out || !I || !u) return fail_invalid("interp_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(D, B) \
+    hipLaunchKernelGGL((interp_fwd_kernel<R, D, B>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, u, dt, (int)nc, g)
+    if (dim == 3) {
+        if (bc) LAUNCH(3, true); else LAUNCH(3, false);
+    } else {
+        if (bc) LAUNCH(2, true); else LAUNCH(2, false);
+    }
+#undef LAUNCH
+    return finish_launch(s, "interp_forward");
+}
+
+template <typename R, int DIM, bool BC>
+static void launch_bwd(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, const Geom &g,
+                       bool need_I, bool need_u, hipStream_t s) {
+#define LAUNCH(NI, NU)                                                                                          \
+    hipLaunchKernelGGL((interp_bwd_kernel<R, DIM, BC, NI, NU>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, d_u, \
+                       go, I, u, dt, nc, g)
+    if (need_I && need_u) LAUNCH(true, true);
+    else if (need_I) LAUNCH(true, false);
+    else if (need_u) LAUNCH(false, true);
+#undef LAUNCH
+}
+
+template <typename R>
+int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
+                        const Geom &g, bool bc, bool need_u, hipStream_t s);  // splat.hip
+
+template <typename R>
+static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int dim,
+                                int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc, int need_I,
+                                int need_u, void *stream) {
+    if (dim != 2 && dim != 3)
+        return fail_invalid("Only two- and three-dimensional interpolation is supported");
+    Geom g;
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("interp_backward: bad extent");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nI = (size_t)(bc ? 1 : nn) * nc * g.nvox;
+    const size_t nu = (size_t)nn * dim * g.nvox;
+    if ((nI && !d_I) || (nu && !d_u) || (nu && nc && (!go || !I || !u)))
+        return fail_invalid("interp_backward: null pointer");
+    // d_I is a scatter target (or unused): zero it.  d_u is fully overwritten when needed.
+    if (nI) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
+    if (!need_u && nu) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
+    if (g.nblocks == 0 || nc == 0 || !(need_I || need_u)) {
+        if (need_u && nu) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
+        return finish_launch(s, "interp_backward");
+    }
+    if (dim == 3 && need_I && g_splat_mode == 1) {
+        int rc = interp_backward_lds<R>(d_I, d_u, go, I, u, dt, (int)nc, nn, g, bc != 0, need_u != 0, s);
+        if (rc != 1) return rc;  // 1 = shape not supported by the tiled kernel, fall through
+    }
+    if (dim == 3) {
+        if (bc) launch_bwd<R, 3, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
+        else launch_bwd<R, 3, false>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
+    } else {
+        if (bc) launch_bwd<R, 2, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
+        else launch_bwd<R, 2, false>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
+    }
+    return finish_launch(s, "interp_backward");
+}
+
+template <typename R>
+static int hessdiag_impl(R *out, const R *u, double dt, int64_t nI, int64_t nn, int64_t nc, int64_t nx, int64_t ny,
+                         void *stream) {
+    Geom g;
+    if (nc < 0 || nI < 0 || !make_geom(g, 2, nn, nx, ny, 1))
+        return fail_invalid("interp_hessian_diagonal_image: bad extent");
+    hipStream_t s = (hipStream_t)stream;
+    size_t no = (size_t)nI * nc * g.nvox;
+    if ((no && !out) || (no && g.nblocks && !u)) return fail_invalid("interp_hessian_diagonal_image: null pointer");
+    if (no) LAGO_HIP_TRY(hipMemsetAsync(out, 0, no * sizeof(R), s));
+    if (g.nblocks && nc && no)
+        hipLaunchKernelGGL((interp_hessdiag_kernel<R>), dim3(g.nblocks), dim3(kBlock), 0, s, out, u, dt, (int)nc, g);
+    return finish_launch(s, "interp_hessian_diagonal_image");
+}
+
+}  // namespace lago
+
+extern "C" {
+#define LAGO_DEFINE(REAL, SUF)                                                                                     \
+    int lago_interp_forward##SUF(REAL *out, const REAL *I, const REAL *u, double dt, int dim, int64_t nn,         \
+                                 int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc, void *stream) {          \
+        return lago::interp_forward_impl<REAL>(out, I, u, dt, dim, nn, nc, nx, ny, nz, bc, stream);               \
+    }                                                                                                              \
+    int lago_interp_backward##SUF(REAL *d_I, REAL *d_u, const REAL *go, const REAL *I, const REAL *u, double dt,  \
+                                  int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc,    \
+                                  int need_I, int need_u, void *stream) {                                         \
+        return lago::interp_backward_impl<REAL>(d_I, d_u, go, I, u, dt, dim, nn, nc, nx, ny, nz, bc, need_I,      \
+                                                need_u, stream);                                                  \
+    }                                                                                                              \
+    int lago_interp_hessian_diagonal_image##SUF(REAL *out, const REAL *u, double dt, int64_t nI, int64_t nn,      \
+                                                int64_t nc, int64_t nx, int64_t ny, void *stream) {               \
+        return lago::hessdiag_impl<REAL>(out, u, dt, nI, nn, nc, nx, ny, stream);                                 \
+    }
+LAGO_DEFINE(float, _f32)
+LAGO_DEFINE(double, _f64)
+#undef LAGO_DEFINE
+}

@@ -1,0 +1,178 @@
+// Fluid metric operator in the Fourier domain -- gfx950 HIP kernel.
+//
+// Replaces cuda/metric.cu of the reference (fluid_kernel_2d :162-218,
+// fluid_kernel_3d :220-306, Cholesky helpers :20-130, OperatorMultiply
+// :132-160).  Per frequency bin the symmetric matrix l (lambda on the diagonal,
+// beta*sin*sin off it) is squared to L = l*l and either applied (flat) or
+// inverted through its Cholesky factor (sharp), on the real and imaginary part
+// of every vector component, in place on the interleaved-complex rFFT buffer.
+//
+// One lane per complex bin of the flattened (kx, ky, kz) index (kz fastest, 8 or
+// 16 contiguous bytes per lane), batch loop inside the lane so the factor is
+// computed once per bin exactly as the reference does.  Pure streaming: every
+// byte of Fm is read once and written once.
+#include "common.hpp"
+
+namespace lago {
+
+template <typename R>
+struct alignas(2 * sizeof(R)) Cplx {
+    R re, im;
+};
+
+// cuda/metric.cu:14-18
+template <typename R>
+__device__ __forceinline__ R safe_sqrt(R x) {
+    if ((double)x < 1e-8) return (R)1e-4;
+    return sizeof(R) == 4 ? (R)__fsqrt_rn((float)x) : (R)__dsqrt_rn((double)x);
+}
+
+template <typename R>
+__device__ __forceinline__ R recip_via_double(R x) {  // `1./x` with x a Real: double division, narrowed
+    return (R)(1. / (double)x);
+}
+
+template <typename R, int DIM, bool INV>
+__global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm, const R *__restrict__ cosX,
+                                                       const R *__restrict__ sinX, const R *__restrict__ cosY,
+                                                       const R *__restrict__ sinY, const R *__restrict__ cosZ,
+                                                       const R *__restrict__ sinZ, double alpha, double beta,
+                                                       double gamma, int nn, Geom g) {
+    const Vox v = locate(g);
+    if (!v.valid) return;
+    const size_t nv = g.nvox;  // complex bins per component
+    Cplx<R> *F = Fm + v.s;
+    if (DIM == 3) {
+        const R wx = cosX[v.i], wy = cosY[v.j], wz = cosZ[v.k];
+        const R sx = sinX[v.i], sy = sinY[v.j], sz = sinZ[v.k];
+        const R lambda = (R)(gamma + alpha * (double)(wx + wy + wz));
+        const R l00 = (R)((double)lambda - beta * (double)wx);
+        const R l11 = (R)((double)lambda - beta * (double)wy);
+        const R l22 = (R)((double)lambda - beta * (double)wz);
+        const R l10 = (R)(beta * (double)sx * (double)sy);
+        const R l20 = (R)(beta * (double)sx * (double)sz);
+        const R l21 = (R)(beta * (double)sy * (double)sz);
+        const R L00 = l00 * l00 + l10 * l10 + l20 * l20;
+        const R L10 = l00 * l10 + l10 * l11 + l20 * l21;
+        const R L11 = l10 * l10 + l11 * l11 + l21 * l21;
+        const R L20 = l00 * l20 + l10 * l21 + l20 * l22;
+        const R L21 = l10 * l20 + l11 * l21 + l21 * l22;
+        const R L22 = l20 * l20 + l21 * l21 + l22 * l22;
+        R ooG00 = 0, G10 = 0, ooG11 = 0, G20 = 0, G21 = 0, ooG22 = 0;
+        if (INV) {  // cuda/metric.cu:47-78
+            ooG00 = recip_via_double(safe_sqrt(L00));
+            G10 = L10 * ooG00;
+            G20 = L20 * ooG00;
+            ooG11 = L11 - G10 * G10;
+            ooG11 = recip_via_double(safe_sqrt(ooG11));
+            G21 = (L21 - G20 * G10) * ooG11;
+            ooG22 = L22 - G20 * G20 - G21 * G21;
+            ooG22 = recip_via_double(safe_sqrt(ooG22));
+        }
+        for (int n = 0; n < nn; ++n, F += 3 * nv) {
+            Cplx<R> a = F[0], b = F[nv], c = F[2 * nv];
+            R X[2] = {a.re, a.im}, Y[2] = {b.re, b.im}, Z[2] = {c.re, c.im};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                R bX = X[q], bY = Y[q], bZ = Z[q];
+                if (INV) {  // cuda/metric.cu:103-130
+                    R y0 = bX * ooG00;
+                    R y1 = (bY - G10 * y0) * ooG11;
+                    R y2 = (bZ - G20 * y0 - G21 * y1) * ooG22;
+                    bZ = y2 * ooG22;
+                    bY = (y1 - G21 * bZ) * ooG11;
+                    bX = (y0 - G10 * bY - G20 * bZ) * ooG00;
+                } else {  // cuda/metric.cu:145-160
+                    R x = L00 * bX + L10 * bY + L20 * bZ;
+                    R y = L10 * bX + L11 * bY + L21 * bZ;
+                    bZ = L20 * bX + L21 * bY + L22 * bZ;
+                    bX = x;
+                    bY = y;
+                }
+                X[q] = bX; Y[q] = bY; Z[q] = bZ;
+            }
+            F[0] = Cplx<R>{X[0], X[1]};
+            F[nv] = Cplx<R>{Y[0], Y[1]};
+            F[2 * nv] = Cplx<R>{Z[0], Z[1]};
+        }
+    } else {
+        const R wx = cosX[v.j], wy = cosY[v.k];
+        const R lambda = (R)(gamma + alpha * (double)(wx + wy));
+        const R l00 = (R)((double)lambda - beta * (double)wx);
+        const R l11 = (R)((double)lambda - beta * (double)wy);
+        const R l10 = (R)(beta * (double)sinX[v.j] * (double)sinY[v.k]);
+        const R L00 = l00 * l00 + l10 * l10;
+        const R L10 = l00 * l10 + l10 * l11;
+        const R L11 = l11 * l11 + l10 * l10;
+        R ooG00 = 0, G10 = 0, ooG11 = 0;
+        if (INV) {  // cuda/metric.cu:20-45
+            ooG00 = recip_via_double(safe_sqrt(L00));
+            G10 = L10 * ooG00;
+            ooG11 = L11 - G10 * G10;
+            ooG11 = recip_via_double(safe_sqrt(ooG11));
+        }
+        for (int n = 0; n < nn; ++n, F += 2 * nv) {
+            Cplx<R> a = F[0], b = F[nv];
+            R X[2] = {a.re, a.im}, Y[2] = {b.re, b.im};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                R bX = X[q], bY = Y[q];
+                if (INV) {  // cuda/metric.cu:80-101
+                    R y0 = bX * ooG00;
+                    R y1 = (bY - G10 * y0) * ooG11;
+                    bY = y1 * ooG11;
+                    bX = (y0 - G10 * bY) * ooG00;
+                } else {  // cuda/metric.cu:132-143
+                    R x = L00 * bX + L10 * bY;
+                    bY = L10 * bX + L11 * bY;
+                    bX = x;
+                }
+                X[q] = bX; Y[q] = bY;
+            }
+            F[0] = Cplx<R>{X[0], X[1]};
+            F[nv] = Cplx<R>{Y[0], Y[1]};
+        }
+    }
+}
+
+template <typename R>
+static int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
+                               const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim,
+                               int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {
+    if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional fluid metric is supported");
+    Geom g;
+    if (nn < 0 || nn >= (1ll << 31) || !make_geom(g, dim, 1, nx, ny, nz))
+        return fail_invalid("fluid_operator: bad extent");
+    if (g.nblocks == 0 || nn == 0) return LAGO_OK;
+    if (!Fm || !cosX || !sinX || !cosY || !sinY || (dim == 3 && (!cosZ || !sinZ)))
+        return fail_invalid("fluid_operator: null pointer");
+    if (((uintptr_t)Fm) % (2 * sizeof(R))) return fail_invalid("fluid_operator: Fmv must be aligned to a complex element");
+    hipStream_t s = (hipStream_t)stream;
+    Cplx<R> *F = reinterpret_cast<Cplx<R> *>(Fm);
+#define LAUNCH(D, INV)                                                                                           \
+    hipLaunchKernelGGL((fluid_kernel<R, D, INV>), dim3(g.nblocks), dim3(kBlock), 0, s, F, cosX, sinX, cosY, sinY, \
+                       cosZ, sinZ, alpha, beta, gamma, (int)nn, g)
+    if (dim == 3) {
+        if (inverse) LAUNCH(3, true); else LAUNCH(3, false);
+    } else {
+        if (inverse) LAUNCH(2, true); else LAUNCH(2, false);
+    }
+#undef LAUNCH
+    return finish_launch(s, "fluid_operator");
+}
+
+}  // namespace lago
+
+extern "C" {
+#define LAGO_DEFINE(REAL, SUF)                                                                                    \
+    int lago_fluid_operator##SUF(REAL *Fm, int inverse, const REAL *cosX, const REAL *sinX, const REAL *cosY,     \
+                                 const REAL *sinY, const REAL *cosZ, const REAL *sinZ, double alpha, double beta, \
+                                 double gamma, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz,           \
+                                 void *stream) {                                                                  \
+        return lago::fluid_operator_impl<REAL>(Fm, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta,      \
+                                               gamma, dim, nn, nx, ny, nz, stream);                               \
+    }
+LAGO_DEFINE(float, _f32)
+LAGO_DEFINE(double, _f64)
+#undef LAGO_DEFINE
+}

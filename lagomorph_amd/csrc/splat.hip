@@ -1,0 +1,258 @@
+// LDS-privatised 3D splat (adjoint of trilinear interpolation) -- gfx950.
+//
+// Same contract as interp_kernel_backward_3d of the reference
+// (cuda/interp.cu:185-244 + atomicSplat include/interp.h:426-454), re-designed
+// around the MI355X cost model: global float atomics execute at the memory side
+// at ~1.3 TB/s of added bytes chip-wide (one 64-byte request per ~12 ns per CU),
+// so issuing the reference's 8 atomics per voxel-channel caps the kernel at a
+// fraction of the HBM roofline.  Here a workgroup owns a TX x TY x TZ tile of
+// *source* voxels and accumulates their 8 corner contributions in an LDS window
+// (ds_add_f32) that is positioned at tile origin + displacement at the tile
+// centre - margin.  Smooth displacement fields keep nearly every corner inside
+// the window; corners that fall outside take the global-atomic path, so any
+// displacement is handled correctly.  The window is then flushed with one
+// global atomic per *touched* cell, in 256-byte wavefront rows whose start is
+// 64-byte aligned (window z origin is a multiple of 16 floats).
+//
+// d_u (the analytic gradient term, include/interp.h:207-327) is produced by the
+// same pass: the thread that owns a voxel owns its d_u entries, so the channel
+// sum is a plain read-modify-write in ascending channel order, bit-identical to
+// the reference's thread-owned accumulation.
+#include "common.hpp"
+
+namespace lago {
+
+struct TileGeom {
+    int nx, ny, nz;
+    int TX, TY, TZ;     // source tile
+    int WX, WY, WZ;     // LDS window (cells)
+    int MX, MY, MZ;     // margin below the displaced tile origin
+    uint32_t ntx, nty, ntz, tiles_per_item, total;
+    uint32_t tile_vox, win_cells;
+    FastDiv d_tiles, d_tyz, d_tz;      // block id -> (n, bx, by, bz)
+    FastDiv d_TyTz, d_Tz;              // tile voxel id -> (a, b, c)
+    FastDiv d_WyWz, d_Wz;              // window cell id -> (lx, ly, lz)
+};
+
+static int g_tile_cfg[7] = {8, 8, 0, 2, 2, 16, 512};  // TX TY TZ(0=whole rows up to 192) MX MY MZ threads
+
+__device__ __forceinline__ void lds_add(float *p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <typename R, bool BC, bool NEED_U, int NT>
+__global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R *__restrict__ d_u,
+                                                         const R *__restrict__ go, const R *__restrict__ I,
+                                                         const R *__restrict__ u, double dt, int nc, TileGeom tg) {
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    R *win = reinterpret_cast<R *>(lago_smem);
+    const int nx = tg.nx, ny = tg.ny, nz = tg.nz;
+    const size_t nv = (size_t)nx * ny * nz;
+
+    // workgroup -> (batch item, tile)
+    const uint32_t L = xcd_swizzle(blockIdx.x, tg.total);
+    const uint32_t n = tg.d_tiles.div(L);
+    uint32_t r = L - n * tg.tiles_per_item;
+    const uint32_t bx = tg.d_tyz.div(r);
+    r -= bx * (tg.nty * tg.ntz);
+    const uint32_t by = tg.d_tz.div(r);
+    const uint32_t bz = r - by * tg.ntz;
+    const int x0 = bx * tg.TX, y0 = by * tg.TY, z0 = bz * tg.TZ;
+    const int ex = min(tg.TX, nx - x0), ey = min(tg.TY, ny - y0), ez = min(tg.TZ, nz - z0);
+
+    const R *un = u + (size_t)n * 3 * nv;
+    const R *In = BC ? I : I + (size_t)n * nc * nv;
+    R *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
+    const R *gon = go + (size_t)n * nc * nv;
+    R *dun = NEED_U ? d_u + (size_t)n * 3 * nv : nullptr;
+
+    // window origin from the displacement at the tile centre (placement only
+    // affects speed, never the result)
+    const size_t sc = ((size_t)(x0 + ex / 2) * ny + (y0 + ey / 2)) * nz + (z0 + ez / 2);
+    const float fdt = (float)dt;
+    const int offx = (int)floorf(fdt * (float)un[sc]);
+    const int offy = (int)floorf(fdt * (float)un[sc + nv]);
+    const int offz = (int)floorf(fdt * (float)un[sc + 2 * nv]);
+    const int wex = min(tg.WX, nx), wey = min(tg.WY, ny), wez = min(tg.WZ, nz);
+    const int wx0 = max(0, min(x0 + offx - tg.MX, nx - wex));
+    const int wy0 = max(0, min(y0 + offy - tg.MY, ny - wey));
+    const int wz0 = max(0, min((z0 + offz - tg.MZ) & ~15, nz - wez));
+    const int WY = tg.WY, WZ = tg.WZ;
+
+    for (int c = 0; c < nc; ++c) {
+        for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0;
+        __syncthreads();
+        const R *Ic = In + (size_t)c * nv;
+        R *dIc = dIn + (size_t)c * nv;
+        const R *gc = gon + (size_t)c * nv;
+        for (uint32_t t = threadIdx.x; t < tg.tile_vox; t += NT) {
+            const uint32_t a = tg.d_TyTz.div(t);
+            const uint32_t rr = t - a * (uint32_t)(tg.TY * tg.TZ);
+            const uint32_t b = tg.d_Tz.div(rr);
+            const uint32_t cc = rr - b * (uint32_t)tg.TZ;
+            if ((int)a >= ex || (int)b >= ey || (int)cc >= ez) continue;
+            const int i = x0 + a, j = y0 + b, k = z0 + cc;
+            const size_t s = ((size_t)i * ny + j) * nz + k;
+            const R hx = sample_pos<R>(i, dt, un[s]);
+            const R hy = sample_pos<R>(j, dt, un[s + nv]);
+            const R hz = sample_pos<R>(k, dt, un[s + 2 * nv]);
+            R diff = gc[s];
+            // include/interp.h:431-453: floor corner, sequentially flipped weights
+            const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+            R dx = (R)1.f - (hx - (R)fx);
+            R dy = (R)1.f - (hy - (R)fy);
+            R dz = (R)1.f - (hz - (R)fz);
+            int gi[2] = {clamp1(fx, nx), clamp1(fx + 1, nx)};
+            int gj[2] = {clamp1(fy, ny), clamp1(fy + 1, ny)};
+            int gk[2] = {clamp1(fz, nz), clamp1(fz + 1, nz)};
+#pragma unroll
+            for (int qa = 0; qa < 2; ++qa) {
+                const int lx = gi[qa] - wx0;
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int ly = gj[qb] - wy0;
+#pragma unroll
+                    for (int qc = 0; qc < 2; ++qc) {
+                        const int lz = gk[qc] - wz0;
+                        const R val = (dx * dy * dz) * diff;
+                        const bool inside = (unsigned)lx < (unsigned)wex && (unsigned)ly < (unsigned)wey &&
+                                            (unsigned)lz < (unsigned)wez;
+                        if (inside)
+                            lds_add(&win[(lx * WY + ly) * WZ + lz], val);
+                        else
+                            atomic_add(dIc + ((size_t)gi[qa] * ny + gj[qb]) * nz + gk[qc], val);
+                        dz = (R)1.f - dz;
+                    }
+                    dy = (R)1.f - dy;
+                }
+                dx = (R)1.f - dx;
+            }
+            if (NEED_U) {
+                Lerp3<R> Lq;
+                Lq.setup(hx, hy, hz, nx, ny, nz);
+                R gx, gy, gz;
+                Lq.grad(Ic, gx, gy, gz);
+                diff = (R)((double)diff * dt);  // cuda/interp.cu:230
+                if (c == 0) {
+                    dun[s] = (R)0 + gx * diff;
+                    dun[s + nv] = (R)0 + gy * diff;
+                    dun[s + 2 * nv] = (R)0 + gz * diff;
+                } else {
+                    dun[s] = dun[s] + gx * diff;
+                    dun[s + nv] = dun[s + nv] + gy * diff;
+                    dun[s + 2 * nv] = dun[s + 2 * nv] + gz * diff;
+                }
+            }
+        }
+        __syncthreads();
+        // flush touched cells: consecutive lanes -> consecutive z of one window row
+        for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) {
+            const R val = win[f];
+            if (val != (R)0) {
+                const uint32_t lx = tg.d_WyWz.div(f);
+                const uint32_t rr = f - lx * (uint32_t)(WY * WZ);
+                const uint32_t ly = tg.d_Wz.div(rr);
+                const uint32_t lz = rr - ly * (uint32_t)WZ;
+                atomic_add(dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + (wz0 + lz), val);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, size_t elem, size_t &smem, int &nthreads) {
+    int TX = g_tile_cfg[0], TY = g_tile_cfg[1], TZ = g_tile_cfg[2];
+    const int MX = g_tile_cfg[3], MY = g_tile_cfg[4], MZ = g_tile_cfg[5];
+    nthreads = g_tile_cfg[6];
+    if (TX < 1 || TY < 1 || MX < 0 || MY < 0 || MZ < 0) return false;
+    if (TZ <= 0) TZ = g.nz <= 192 ? g.nz : 128;
+    TX = TX < g.nx ? TX : g.nx;
+    TY = TY < g.ny ? TY : g.ny;
+    TZ = TZ < g.nz ? TZ : g.nz;
+    tg.nx = g.nx; tg.ny = g.ny; tg.nz = g.nz;
+    tg.TX = TX; tg.TY = TY; tg.TZ = TZ;
+    tg.MX = MX; tg.MY = MY; tg.MZ = MZ;
+    tg.WX = TX + 1 + 2 * MX;
+    tg.WY = TY + 1 + 2 * MY;
+    tg.WZ = TZ >= g.nz ? g.nz : ((TZ + 1 + 2 * MZ + 15 + 15) / 16) * 16;  // +15: origin is aligned down
+    if (tg.WZ > g.nz) tg.WZ = g.nz;
+    tg.win_cells = (uint32_t)tg.WX * tg.WY * tg.WZ;
+    smem = (size_t)tg.win_cells * elem;
+    if (smem > 160 * 1024) return false;
+    tg.ntx = (g.nx + TX - 1) / TX;
+    tg.nty = (g.ny + TY - 1) / TY;
+    tg.ntz = (g.nz + TZ - 1) / TZ;
+    tg.tiles_per_item = tg.ntx * tg.nty * tg.ntz;
+    int64_t total = (int64_t)tg.tiles_per_item * nn;
+    if (total >= (1ll << 31)) return false;
+    tg.total = (uint32_t)total;
+    tg.tile_vox = (uint32_t)TX * TY * TZ;
+    tg.d_tiles = FastDiv(tg.tiles_per_item);
+    tg.d_tyz = FastDiv(tg.nty * tg.ntz);
+    tg.d_tz = FastDiv(tg.ntz);
+    tg.d_TyTz = FastDiv((uint32_t)(TY * TZ));
+    tg.d_Tz = FastDiv((uint32_t)TZ);
+    tg.d_WyWz = FastDiv((uint32_t)(tg.WY * tg.WZ));
+    tg.d_Wz = FastDiv((uint32_t)tg.WZ);
+    return true;
+}
+
+template <typename R, bool BC, bool NEED_U, int NT>
+static hipError_t launch_tiled(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc,
+                               const TileGeom &tg, size_t smem, hipStream_t s) {
+    auto k = splat_tiled_kernel<R, BC, NEED_U, NT>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(tg.total), dim3(NT), smem, s, d_I, d_u, go, I, u, dt, nc, tg);
+    return hipSuccess;
+}
+
+// Returns LAGO_OK / error, or 1 when this shape/dtype is left to the plain kernel.
+// The caller has already zeroed d_I (and d_u when it is not needed).
+template <typename R>
+int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
+                        const Geom &g, bool bc, bool need_u, hipStream_t s) {
+    TileGeom tg;
+    size_t smem;
+    int nt;
+    if (!make_tiles(tg, g, nn, sizeof(R), smem, nt)) return 1;
+    hipError_t e = hipSuccess;
+#define GO(B, U, T) e = launch_tiled<R, B, U, T>(d_I, d_u, go, I, u, dt, nc, tg, smem, s)
+#define BY_NT(B, U)                          \
+    do {                                     \
+        if (nt >= 1024) GO(B, U, 1024);      \
+        else if (nt >= 512) GO(B, U, 512);   \
+        else GO(B, U, 256);                  \
+    } while (0)
+    if (bc) {
+        if (need_u) BY_NT(true, true); else BY_NT(true, false);
+    } else {
+        if (need_u) BY_NT(false, true); else BY_NT(false, false);
+    }
+#undef BY_NT
+#undef GO
+    if (e != hipSuccess) return fail_hip(e, "interp_backward (tiled splat)");
+    return finish_launch(s, "interp_backward (tiled splat)");
+}
+
+template int interp_backward_lds<float>(float *, float *, const float *, const float *, const float *, double, int,
+                                        int64_t, const Geom &, bool, bool, hipStream_t);
+template int interp_backward_lds<double>(double *, double *, const double *, const double *, const double *, double,
+                                         int, int64_t, const Geom &, bool, bool, hipStream_t);
+
+}  // namespace lago
+
+extern "C" {
+// Tuning hook (bench / tests): tile TX, TY, TZ (0 = whole rows), margins MX, MY, MZ, threads per workgroup.
+void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
+    lago::g_tile_cfg[0] = tx; lago::g_tile_cfg[1] = ty; lago::g_tile_cfg[2] = tz;
+    lago::g_tile_cfg[3] = mx; lago::g_tile_cfg[4] = my; lago::g_tile_cfg[5] = mz;
+    lago::g_tile_cfg[6] = nthreads;
+}
+}

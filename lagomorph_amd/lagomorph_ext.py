@@ -1,0 +1,385 @@
+"""``lagomorph_ext`` for MI355X: the reference's 13-function extension surface
+(``/root/reference/lagomorph/extension/extension.cpp:175-189``) bound with
+ctypes onto ``liblagomorph_hip.so`` (C ABI in ``include/lagomorph_hip.h``).
+
+Same names, argument order, defaults and return conventions as the pybind11
+module the reference builds with ``CUDAExtension`` (``setup.py:18-31``):
+inputs are borrowed contiguous device tensors, outputs are freshly allocated
+tensors, ``fluid_operator`` mutates its first argument, argument violations
+raise ``RuntimeError`` (the reference's ``TORCH_CHECK``).  Kernels are launched
+on torch's *current* HIP stream (the reference used the legacy default stream).
+
+There is no CPU path: every entry point raises on a CPU tensor, and importing
+this module raises if the HIP library has not been built
+(``python -m lagomorph_amd.build`` / ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+import torch  # must be imported first: it loads the process's libamdhip64.so.7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "liblagomorph_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP extension is not built "
+        "(run `python -m lagomorph_amd.build`); lagomorph_amd has no CPU fallback"
+    )
+_lib = ctypes.CDLL(LIB_PATH)
+_lib.lago_last_error.restype = ctypes.c_char_p
+_lib.lago_version.restype = ctypes.c_char_p
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+
+# argtypes per entry point (both precisions) -- mirrors include/lagomorph_hip.h
+_SIGS = {
+    "lago_interp_forward": [_vp, _vp, _vp, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp],
+    "lago_interp_backward": [_vp, _vp, _vp, _vp, _vp, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _vp],
+    "lago_interp_hessian_diagonal_image": [_vp, _vp, _dbl, _i64, _i64, _i64, _i64, _i64, _vp],
+    "lago_jtv_forward": [_vp, _vp, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _vp],
+    "lago_jtv_backward": [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _vp],
+    "lago_jtv_adjoint_forward": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp],
+    "lago_jtv_adjoint_backward": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
+    "lago_fluid_operator": [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
+    "lago_affine_interp_forward": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp],
+    "lago_affine_interp_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int, _int,
+                                    _int, _int, _vp],
+    "lago_regrid_forward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
+    "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
+    "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _vp],
+}
+_fn = {}
+for _name, _args in _SIGS.items():
+    for _suf in ("_f32", "_f64"):
+        _f = getattr(_lib, _name + _suf, None)
+        if _f is None:
+            continue
+        _f.argtypes = _args
+        _f.restype = _int
+        _fn[_name + _suf] = _f
+_lib.lago_set_debug.argtypes = [_int]
+_lib.lago_set_splat_mode.argtypes = [_int]
+_lib.lago_set_splat_tile.argtypes = [_int] * 7
+
+
+def _suffix(t):
+    if t.dtype == torch.float32:
+        return "_f32"
+    if t.dtype == torch.float64:
+        return "_f64"
+    raise RuntimeError(f"lagomorph_ext: only float32 and float64 are supported (got {t.dtype})")
+
+
+def _check_input(x, name):
+    # CHECK_INPUT, extension.cpp:8-10
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _same(ref, *others):
+    for o in others:
+        if o.dtype != ref.dtype:
+            raise RuntimeError(f"lagomorph_ext: dtype mismatch ({ref.dtype} vs {o.dtype})")
+        if o.device != ref.device:
+            raise RuntimeError(f"lagomorph_ext: device mismatch ({ref.device} vs {o.device})")
+
+
+def _spatial(t):
+    d = t.dim() - 2
+    if d == 2:
+        return 2, t.size(2), t.size(3), 1
+    if d == 3:
+        return 3, t.size(2), t.size(3), t.size(4)
+    return d, 0, 0, 0
+
+
+def _call(name, ref, *args):
+    """Launch on torch's current stream of ref's device; raise RuntimeError on failure."""
+    f = _fn[name + _suffix(ref)]
+    if ref.device.index != torch.cuda.current_device():
+        with torch.cuda.device(ref.device):
+            rc = f(*args, torch.cuda.current_stream().cuda_stream)
+    else:
+        rc = f(*args, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(_lib.lago_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None and t.numel() > 0 else None
+
+
+# ---------------------------------------------------------------------------
+
+
+def set_debug_mode(mode):
+    """extension.cpp:105-107.  In debug mode every launch is followed by a
+    stream synchronise and kernel faults raise (the reference printed them)."""
+    _lib.lago_set_debug(1 if mode else 0)
+
+
+def set_splat_mode(mode):
+    """0 = global atomics only, 1 = LDS-privatised splat (default)."""
+    _lib.lago_set_splat_mode(int(mode))
+
+
+def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
+    _lib.lago_set_splat_tile(int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
+
+
+def version():
+    return _lib.lago_version().decode()
+
+
+def interp_forward(Iv, u, dt=1.0):
+    """extension.cpp:135-143 -> cuda/interp.cu:80-130"""
+    _check_input(Iv, "Iv")
+    _check_input(u, "u")
+    _same(Iv, u)
+    dim, nx, ny, nz = _spatial(Iv)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional interpolation is supported")
+    if u.dim() != Iv.dim() or u.size(1) != dim or tuple(u.shape[2:]) != tuple(Iv.shape[2:]):
+        raise RuntimeError(f"interp_forward: displacement of shape {tuple(u.shape)} does not match image {tuple(Iv.shape)}")
+    nn = max(u.size(0), Iv.size(0))
+    bc = Iv.size(0) < nn
+    if (bc and Iv.size(0) != 1) or u.size(0) != nn:
+        raise RuntimeError("interp_forward: batch sizes of I and u are incompatible")
+    out = torch.empty((nn, Iv.size(1)) + tuple(Iv.shape[2:]), dtype=Iv.dtype, device=Iv.device)
+    _call("lago_interp_forward", Iv, _ptr(out), _ptr(Iv), _ptr(u), float(dt), dim, nn, Iv.size(1), nx, ny, nz, int(bc))
+    return out
+
+
+def interp_backward(grad_out, I, u, dt, need_I, need_u):
+    """extension.cpp:145-156 -> cuda/interp.cu:246-313.  Returns [d_I, d_u]; both always allocated."""
+    _check_input(grad_out, "grad_out")
+    _check_input(I, "I")
+    _check_input(u, "u")
+    _same(I, u, grad_out)
+    dim, nx, ny, nz = _spatial(I)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional interpolation is supported")
+    nn = max(u.size(0), I.size(0))
+    bc = I.size(0) < nn
+    if tuple(grad_out.shape) != (nn, I.size(1)) + tuple(I.shape[2:]) or u.size(1) != dim or u.size(0) != nn:
+        raise RuntimeError("interp_backward: grad_out / I / u shapes are inconsistent")
+    d_I = torch.empty_like(I)
+    d_u = torch.empty_like(u)
+    _call("lago_interp_backward", I, _ptr(d_I), _ptr(d_u), _ptr(grad_out), _ptr(I), _ptr(u), float(dt), dim, nn,
+          I.size(1), nx, ny, nz, int(bc), int(bool(need_I)), int(bool(need_u)))
+    return [d_I, d_u]
+
+
+def interp_hessian_diagonal_image(Iv, u, dt):
+    """cuda/interp.cu:351-381 (2D only; accumulates into plane 0 like the reference)."""
+    _check_input(Iv, "Iv")
+    _check_input(u, "u")
+    _same(Iv, u)
+    if Iv.dim() != 4 or u.dim() != 4 or u.size(1) != 2:
+        raise RuntimeError("interp_hessian_diagonal_image is only implemented for two-dimensional images")
+    nn = max(u.size(0), Iv.size(0))
+    out = torch.empty_like(Iv)
+    _call("lago_interp_hessian_diagonal_image", Iv, _ptr(out), _ptr(u), float(dt), Iv.size(0), nn, Iv.size(1),
+          Iv.size(2), Iv.size(3))
+    return out
+
+
+def _check_jtv(g, v):
+    for x, nm in ((g, "g"), (v, "v")):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise RuntimeError(f"{nm} must be a CUDA tensor")
+    _same(g, v)
+
+
+def jacobian_times_vectorfield_forward(g, v, displacement, transpose):
+    """cuda/diff.cu:129-185: (Dg + [displacement] I) v, or its transpose."""
+    _check_jtv(g, v)
+    g, v = g.contiguous(), v.contiguous()
+    dim, nx, ny, nz = _spatial(g)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional jacobian times vectorfield is supported")
+    if g.size(0) != v.size(0):
+        raise RuntimeError("arguments must have same batch size dimension")
+    if v.size(1) != dim or tuple(v.shape[2:]) != tuple(g.shape[2:]):
+        raise RuntimeError("vector field is of wrong dimension")
+    out = torch.empty_like(g)
+    _call("lago_jtv_forward", g, _ptr(out), _ptr(g), _ptr(v), int(bool(displacement)), int(bool(transpose)), dim,
+          g.size(0), g.size(1), nx, ny, nz)
+    return out
+
+
+def jacobian_times_vectorfield_backward(grad_out, v, w, displacement, transpose, need_v, need_w):
+    """cuda/diff.cu:475-540 (need_v / need_w are ignored there: both gradients are always computed)."""
+    _check_jtv(v, w)
+    _check_jtv(v, grad_out)
+    grad_out, v, w = grad_out.contiguous(), v.contiguous(), w.contiguous()
+    dim, nx, ny, nz = _spatial(v)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional jacobian times vectorfield is supported")
+    if v.size(0) != w.size(0):
+        raise RuntimeError("arguments must have same batch size dimension")
+    if w.size(1) != dim or tuple(w.shape[2:]) != tuple(v.shape[2:]) or grad_out.shape != v.shape:
+        raise RuntimeError("vector field is of wrong dimension")
+    d_v, d_w = torch.empty_like(v), torch.empty_like(w)
+    _call("lago_jtv_backward", v, _ptr(d_v), _ptr(d_w), _ptr(grad_out), _ptr(v), _ptr(w), int(bool(displacement)),
+          int(bool(transpose)), dim, v.size(0), v.size(1), nx, ny, nz)
+    return [d_v, d_w]
+
+
+def jacobian_times_vectorfield_adjoint_forward(g, v):
+    """cuda/diff.cu:634-672"""
+    _check_jtv(g, v)
+    g, v = g.contiguous(), v.contiguous()
+    dim, nx, ny, nz = _spatial(g)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional jacobian times vectorfield is supported")
+    if v.size(1) != dim or v.size(0) != g.size(0) or tuple(v.shape[2:]) != tuple(g.shape[2:]):
+        raise RuntimeError("vector field is of wrong dimension")
+    out = torch.empty_like(g)
+    _call("lago_jtv_adjoint_forward", g, _ptr(out), _ptr(g), _ptr(v), dim, g.size(0), g.size(1), nx, ny, nz)
+    return out
+
+
+def jacobian_times_vectorfield_adjoint_backward(grad_out, v, w, need_v, need_w):
+    """cuda/diff.cu:783-835"""
+    _check_jtv(v, w)
+    _check_jtv(v, grad_out)
+    grad_out, v, w = grad_out.contiguous(), v.contiguous(), w.contiguous()
+    dim, nx, ny, nz = _spatial(v)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional jacobian times vectorfield is supported")
+    if w.size(1) != dim or v.size(1) != dim or v.shape != w.shape or grad_out.shape != v.shape:
+        raise RuntimeError("vector field is of wrong dimension")
+    d_v, d_w = torch.empty_like(v), torch.empty_like(w)
+    _call("lago_jtv_adjoint_backward", v, _ptr(d_v), _ptr(d_w), _ptr(grad_out), _ptr(v), _ptr(w), dim, v.size(0), nx,
+          ny, nz)
+    return [d_v, d_w]
+
+
+def fluid_operator(Fmv, inverse, cosluts, sinluts, alpha, beta, gamma):
+    """extension.cpp:158-173 -> cuda/metric.cu:308-355.  In place on Fmv (N, d, nx, ny[, nzc], 2)."""
+    _check_input(Fmv, "Fmv")
+    dim = Fmv.dim() - 3
+    if len(cosluts) != dim:
+        raise RuntimeError(f"Must provide same number cosine LUTs ({len(cosluts)}) as spatial dimension '{dim}'")
+    if len(sinluts) != dim:
+        raise RuntimeError(f"Must provide same number sine LUTs ({len(sinluts)}) as spatial dimension '{dim}'")
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional fluid metric is supported")
+    if Fmv.size(1) != dim or Fmv.size(-1) != 2:
+        raise RuntimeError("Vector field has incorrect shape for dimension")
+    luts = []
+    for d in range(dim):
+        for t in (cosluts[d], sinluts[d]):
+            if t.dtype != Fmv.dtype:
+                raise RuntimeError("Type of LUTs must equal that of image")
+            if not t.is_cuda or t.device != Fmv.device or t.numel() != Fmv.size(2 + d):
+                raise RuntimeError("fluid_operator: LUT on wrong device or of wrong length")
+            luts.append(t.contiguous())
+    sh = [Fmv.size(2 + d) for d in range(dim)] + [1] * (3 - dim)
+    p = [_ptr(t) for t in luts] + [None] * (6 - 2 * dim)
+    _call("lago_fluid_operator", Fmv, _ptr(Fmv), int(bool(inverse)), *p, float(alpha), float(beta), float(gamma), dim,
+          Fmv.size(0), sh[0], sh[1], sh[2])
+    return None
+
+
+def affine_interp_forward(I, A, T):
+    """extension.cpp:109-118 -> cuda/affine.cu:114-169.  The reference falls back to
+    cpu/affine.cpp for CPU tensors; this build is HIP-only and raises instead."""
+    _check_input(I, "I")
+    _check_input(A, "A")
+    _check_input(T, "T")
+    _same(I, A, T)
+    if A.size(0) != T.size(0):
+        raise RuntimeError("A and T must have same first dimension")
+    dim, nx, ny, nz = _spatial(I)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional affine interpolation is supported")
+    if tuple(A.shape[1:]) != (dim, dim) or tuple(T.shape[1:]) != (dim,):
+        raise RuntimeError("affine_interp_forward: A must be (N, d, d) and T (N, d)")
+    nn = A.size(0)
+    bc = I.size(0) == 1 and nn > 1
+    if not bc and I.size(0) != nn:
+        raise RuntimeError("affine_interp_forward: batch sizes of I and A are incompatible")
+    out = torch.empty((nn, I.size(1)) + tuple(I.shape[2:]), dtype=I.dtype, device=I.device)
+    _call("lago_affine_interp_forward", I, _ptr(out), _ptr(I), _ptr(A), _ptr(T), dim, nn, I.size(1), nx, ny, nz, int(bc))
+    return out
+
+
+def affine_interp_backward(grad_out, I, A, T, need_I, need_A, need_T):
+    """extension.cpp:120-133 -> cuda/affine.cu:538-610.  Unneeded gradients are size-0 tensors."""
+    _check_input(grad_out, "grad_out")
+    _check_input(I, "I")
+    _check_input(A, "A")
+    _check_input(T, "T")
+    _same(I, A, T, grad_out)
+    if I.size(1) != grad_out.size(1):
+        raise RuntimeError("I and grad_out must have same number of channels")
+    if A.size(0) != T.size(0):
+        raise RuntimeError("A and T must have same first dimension")
+    dim, nx, ny, nz = _spatial(I)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional affine interpolation is supported")
+    nn = grad_out.size(0)
+    bc = I.size(0) == 1 and nn > 1
+    if A.size(0) != nn or tuple(grad_out.shape[2:]) != tuple(I.shape[2:]) or (not bc and I.size(0) != nn):
+        raise RuntimeError("affine_interp_backward: grad_out / I / A shapes are inconsistent")
+    empty = lambda: torch.zeros((0,), dtype=I.dtype, device=I.device)
+    d_I = torch.empty_like(I) if need_I else empty()
+    d_A = torch.empty_like(A) if need_A else empty()
+    d_T = torch.empty_like(T) if need_T else empty()
+    _call("lago_affine_interp_backward", I, _ptr(d_I), _ptr(d_A), _ptr(d_T), _ptr(grad_out), _ptr(I), _ptr(A), _ptr(T),
+          dim, nn, I.size(1), nx, ny, nz, int(bc), int(bool(need_I)), int(bool(need_A)), int(bool(need_T)))
+    return [d_I, d_A, d_T]
+
+
+def _vec3(x, dim, what):
+    x = list(x)
+    if len(x) != dim:
+        raise RuntimeError(f"{what} should be vector of size d (not 2+d)")
+    return (ctypes.c_double * 3)(*([float(v) for v in x] + [0.0] * (3 - dim)))
+
+
+def regrid_forward(I, shape, origin, spacing):
+    """cuda/affine.cu:683-734"""
+    _check_input(I, "I")
+    dim, nx, ny, nz = _spatial(I)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional regridding is supported")
+    shape = [int(s) for s in shape]
+    if len(shape) != dim:
+        raise RuntimeError("Shape should be vector of size d (not 2+d)")
+    O, S = _vec3(origin, dim, "Origin"), _vec3(spacing, dim, "Spacing")
+    N = shape + [1] * (3 - dim)
+    out = torch.empty(tuple(I.shape[:2]) + tuple(shape), dtype=I.dtype, device=I.device)
+    _call("lago_regrid_forward", I, _ptr(out), _ptr(I), dim, I.size(0), I.size(1), nx, ny, nz, N[0], N[1], N[2], O, S)
+    return out
+
+
+def regrid_backward(grad_out, inshape, shape, origin, spacing):
+    """cuda/affine.cu:802-855"""
+    _check_input(grad_out, "grad_out")
+    dim = grad_out.dim() - 2
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional regridding is supported")
+    inshape = [int(s) for s in inshape]
+    shape = [int(s) for s in shape]
+    if len(inshape) != dim:
+        raise RuntimeError("Input shape should be vector of size d (not 2+d)")
+    if len(shape) != dim or list(grad_out.shape[2:]) != shape:
+        raise RuntimeError("Shape should be vector of size d (not 2+d)")
+    O, S = _vec3(origin, dim, "Origin"), _vec3(spacing, dim, "Spacing")
+    n3 = inshape + [1] * (3 - dim)
+    N = shape + [1] * (3 - dim)
+    d_I = torch.empty(tuple(grad_out.shape[:2]) + tuple(inshape), dtype=grad_out.dtype, device=grad_out.device)
+    _call("lago_regrid_backward", grad_out, _ptr(d_I), _ptr(grad_out), dim, grad_out.size(0), grad_out.size(1), n3[0],
+          n3[1], n3[2], N[0], N[1], N[2], O, S)
+    return d_I

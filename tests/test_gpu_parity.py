@@ -1,0 +1,320 @@
+"""GPU: the HIP path (through lagomorph_ext -> C ABI) against the CPU oracle on identical
+seeded inputs.  Bit-exact wherever no atomic is involved (the library is built with
+-ffp-contract=off and follows the reference's expression order); tolerance-based for
+scatter-add results, whose summation order is unspecified in the reference too.
+"""
+import numpy as np
+import pytest
+import torch
+
+import kat
+from oracle import lago_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float64]
+# fp32 tolerance from BASELINE.json north_star: <=1e-5 relative for interp/metric outputs
+RTOL = {torch.float32: 1e-5, torch.float64: 1e-12}
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import lagomorph_amd
+
+    lagomorph_amd.set_debug_mode(True)
+    return lagomorph_amd.lagomorph_ext
+
+
+def rnd(rng, shape, dtype, scale=1.0):
+    a = (scale * rng.standard_normal(shape)).astype(np.float32 if dtype == torch.float32 else np.float64)
+    return a
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_bits(got, want, what):
+    got, want = host(got), np.asarray(want)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    if not np.array_equal(got, want):
+        d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        raise AssertionError(f"{what}: not bit-identical, max abs diff {d.max():.3e} at {np.unravel_index(d.argmax(), d.shape)}")
+
+
+def assert_close(got, want, dtype, what, scale=None, mult=1.0):
+    got, want = host(got).astype(np.float64), np.asarray(want).astype(np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    ref = np.abs(want).max() if scale is None else scale
+    err = np.abs(got - want).max() if got.size else 0.0
+    assert err <= mult * RTOL[dtype] * max(ref, 1e-30), f"{what}: max err {err:.3e} vs scale {ref:.3e}"
+
+
+SHAPES3 = [(5, 6, 7), (8, 8, 8), (3, 4, 1), (2, 2, 2), (9, 5, 70)]
+SHAPES2 = [(7, 9), (16, 16), (2, 2), (5, 1), (3, 130)]
+
+
+def _disp(rng, nn, sp, dtype):
+    """Displacements that exercise clamp (far out of range), the negative floor rule, and
+    exact-integer positions."""
+    u = rnd(rng, (nn, len(sp)) + sp, dtype, 1.7)
+    flat = u.reshape(-1)
+    flat[::11] *= 9.0          # far outside
+    flat[::7] = np.round(flat[::7])  # exact integers (weights exactly 0/1)
+    flat[::13] = -np.abs(flat[::13]) - 0.25
+    return u
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", SHAPES3 + SHAPES2)
+@pytest.mark.parametrize("nn,nc,bc", [(2, 1, False), (3, 3, True), (1, 4, False)])
+def test_interp_forward_bit_exact(ext, dtype, sp, nn, nc, bc):
+    rng = np.random.default_rng(hash((sp, nn, nc)) % 2**31)
+    I = rnd(rng, ((1 if bc else nn), nc) + sp, dtype)
+    u = _disp(rng, nn, sp, dtype)
+    for dt in (1.0, -0.37):
+        assert_bits(ext.interp_forward(dev(I), dev(u), dt), orc.interp_forward(I, u, dt), f"interp_forward dt={dt}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("sp", SHAPES3 + SHAPES2)
+@pytest.mark.parametrize("nn,nc,bc", [(2, 1, False), (3, 3, True), (2, 2, False)])
+def test_interp_backward(ext, dtype, mode, sp, nn, nc, bc):
+    rng = np.random.default_rng(hash((sp, nn, nc, 1)) % 2**31)
+    I = rnd(rng, ((1 if bc else nn), nc) + sp, dtype)
+    u = _disp(rng, nn, sp, dtype)
+    go = rnd(rng, (nn, nc) + sp, dtype)
+    ext.set_splat_mode(mode)
+    try:
+        for need_I, need_u in ((True, True), (True, False), (False, True)):
+            dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 0.8, need_I, need_u)
+            oI, ou = orc.interp_backward(go, I, u, 0.8, need_I, need_u)
+            assert_bits(du, ou, f"d_u (need_I={need_I}, need_u={need_u})")   # thread-owned: exact
+            assert_close(dI, oI, dtype, f"d_I (need_I={need_I}, need_u={need_u})", mult=4.0)  # atomic order
+    finally:
+        ext.set_splat_mode(1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [(4, 4, 0, 1, 1, 16, 256), (2, 3, 16, 0, 0, 0, 256), (8, 8, 0, 2, 2, 16, 512),
+                                  (16, 16, 16, 2, 2, 2, 1024)])
+def test_tiled_splat_any_tile_config(ext, dtype, tile):
+    """Window placement / tile shape must never change the result: sweep configurations,
+    including windows too small for the displacement (global-atomic fallback path)."""
+    rng = np.random.default_rng(5)
+    sp = (12, 10, 40)
+    I = rnd(rng, (2, 2) + sp, dtype)
+    u = _disp(rng, 2, sp, dtype)
+    go = rnd(rng, (2, 2) + sp, dtype)
+    oI, ou = orc.interp_backward(go, I, u, 1.0, True, True)
+    ext.set_splat_tile(*tile)
+    try:
+        dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 1.0, True, True)
+    finally:
+        ext.set_splat_tile(8, 8, 0, 2, 2, 16, 512)
+    assert_bits(du, ou, "d_u")
+    assert_close(dI, oI, dtype, "d_I", mult=4.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_index_math_bit_exact(ext, dtype):
+    """Integer displacements (incl. negative and out of range) on a ramp image: every weight is
+    exactly 0 or 1, so the output *is* the clamped gather index -- exact integer compare."""
+    sp = (6, 7, 9)
+    nv = int(np.prod(sp))
+    I = np.arange(nv, dtype=np.float64).reshape((1, 1) + sp)
+    rng = np.random.default_rng(3)
+    u = rng.integers(-12, 13, size=(4, 3) + sp).astype(np.float64)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    out = host(ext.interp_forward(dev(I.astype(npdt)), dev(u.astype(npdt)), 1.0))
+    ii, jj, kk = np.meshgrid(*[np.arange(s) for s in sp], indexing="ij")
+    want = (np.clip(ii + u[:, 0], 0, sp[0] - 1) * sp[1] + np.clip(jj + u[:, 1], 0, sp[1] - 1)) * sp[2] + np.clip(
+        kk + u[:, 2], 0, sp[2] - 1)
+    assert np.array_equal(out[:, 0].astype(np.int64), want.astype(np.int64))
+    # the splat of ones under the same integer map is an exact histogram of those indices
+    dI, _ = ext.interp_backward(dev(np.ones((4, 1) + sp, npdt)), dev(I.astype(npdt)), dev(u.astype(npdt)), 1.0, True, False)
+    hist = np.bincount(want.astype(np.int64).ravel(), minlength=nv).reshape(sp)
+    assert np.array_equal(host(dI)[0, 0], hist.astype(npdt))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_interp_hessian_diagonal(ext, dtype):
+    rng = np.random.default_rng(11)
+    I = rnd(rng, (2, 3, 9, 8), dtype)
+    u = _disp(rng, 2, (9, 8), dtype)
+    assert_close(ext.interp_hessian_diagonal_image(dev(I), dev(u), 0.6), orc.interp_hessian_diagonal_image(I, u, 0.6),
+                 dtype, "hessian diagonal", mult=8.0)
+
+
+JSHAPES = [(5, 6, 7), (2, 2, 2), (8, 4, 66), (7, 9), (2, 2), (3, 70)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", JSHAPES)
+@pytest.mark.parametrize("disp", [True, False])
+@pytest.mark.parametrize("trans", [True, False])
+def test_jtv_forward_backward_bit_exact(ext, dtype, sp, disp, trans):
+    rng = np.random.default_rng(hash((sp, disp, trans)) % 2**31)
+    d = len(sp)
+    v = rnd(rng, (2, d) + sp, dtype)
+    w = rnd(rng, (2, d) + sp, dtype)
+    go = rnd(rng, (2, d) + sp, dtype)
+    assert_bits(ext.jacobian_times_vectorfield_forward(dev(v), dev(w), disp, trans),
+                orc.jacobian_times_vectorfield_forward(v, w, disp, trans), "jtv forward")
+    dv, dw = ext.jacobian_times_vectorfield_backward(dev(go), dev(v), dev(w), disp, trans, True, True)
+    ov, ow = orc.jacobian_times_vectorfield_backward(go, v, w, disp, trans)
+    assert_bits(dv, ov, "jtv backward d_v")
+    assert_bits(dw, ow, "jtv backward d_w")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", JSHAPES)
+@pytest.mark.parametrize("nc", [1, 3])
+def test_jtv_scalar_channels_and_adjoint_bit_exact(ext, dtype, sp, nc):
+    rng = np.random.default_rng(hash((sp, nc, 9)) % 2**31)
+    d = len(sp)
+    g = rnd(rng, (2, nc) + sp, dtype)
+    w = rnd(rng, (2, d) + sp, dtype)
+    # non-displacement, non-transposed mode accepts any channel count (e.g. image gradient . w)
+    assert_bits(ext.jacobian_times_vectorfield_forward(dev(g), dev(w), False, False),
+                orc.jacobian_times_vectorfield_forward(g, w, False, False), "jtv forward nc")
+    assert_bits(ext.jacobian_times_vectorfield_adjoint_forward(dev(g), dev(w)),
+                orc.jacobian_times_vectorfield_adjoint_forward(g, w), "jtv adjoint forward")
+    go = rnd(rng, (2, nc) + sp, dtype)
+    dv, dw = ext.jacobian_times_vectorfield_backward(dev(go), dev(g), dev(w), False, False, True, True)
+    ov, ow = orc.jacobian_times_vectorfield_backward(go, g, w, False, False)
+    assert_bits(dv, ov, "jtv backward d_v nc")
+    assert_bits(dw, ow, "jtv backward d_w nc")
+    if nc == d or True:
+        v = rnd(rng, (2, d) + sp, dtype)
+        go = rnd(rng, (2, d) + sp, dtype)
+        dv, dw = ext.jacobian_times_vectorfield_adjoint_backward(dev(go), dev(v), dev(w), True, True)
+        ov, ow = orc.jacobian_times_vectorfield_adjoint_backward(go, v, w)
+        assert_bits(dv, ov, "jtv adjoint backward d_v")
+        assert_bits(dw, ow, "jtv adjoint backward d_w")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(6, 5, 8), (4, 4, 4), (3, 3, 3), (8, 6), (3, 3), (5, 9, 130)])
+@pytest.mark.parametrize("inverse", [True, False])
+@pytest.mark.parametrize("params", [(0.1, 0.05, 0.01), (1.0, 0.0, 0.01), (0.0, 0.0, 0.0)])
+def test_fluid_operator_bit_exact(ext, dtype, sp, inverse, params):
+    """The per-frequency kernel alone, on an arbitrary interleaved-complex buffer."""
+    rng = np.random.default_rng(hash((sp, inverse)) % 2**31)
+    d = len(sp)
+    csp = sp[:-1] + (sp[-1] // 2 + 1,)
+    F = rnd(rng, (3, d) + csp + (2,), dtype)
+    npdt = F.dtype
+    cos, sin = orc.fluid_luts(sp, npdt)
+    Fo = F.copy()
+    orc.fluid_operator(Fo, inverse, cos, sin, *params)
+    Fd = dev(F)
+    r = ext.fluid_operator(Fd, inverse, [dev(c) for c in cos], [dev(s) for s in sin], *params)
+    assert r is None
+    assert_bits(Fd, Fo, "fluid operator")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(8, 6, 10), (7, 5, 9), (12, 10)])
+def test_fluid_metric_sharp_flat_vs_oracle(ext, dtype, sp):
+    """Full sharp/flat: rocFFT (product) vs pocketfft (oracle) around the same kernel."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(21)
+    m = rnd(rng, (2, len(sp)) + sp, dtype)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    for inv, f in ((True, met.sharp), (False, met.flat)):
+        want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inv)
+        assert_close(f(dev(m)), want, dtype, f"fluid inverse={inv}", mult=10.0)
+    # LUT values: float64 numpy rounded through float32 (metric.py:66-75), bit for bit
+    cos, sin = orc.fluid_luts(sp, m.dtype)
+    for a, b in zip(met.luts["cos"] + met.luts["sin"], cos + sin):
+        assert_bits(a, b, "LUT")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(5, 6, 7), (2, 2, 2), (4, 3, 1), (7, 9), (2, 2), (64, 64)])
+@pytest.mark.parametrize("nn,nc,bc", [(2, 1, False), (3, 2, True), (2, 4, False)])
+def test_affine_interp(ext, dtype, sp, nn, nc, bc):
+    rng = np.random.default_rng(hash((sp, nn, nc, 2)) % 2**31)
+    d = len(sp)
+    I = rnd(rng, ((1 if bc else nn), nc) + sp, dtype)
+    A = (np.eye(d)[None] + 0.3 * rng.standard_normal((nn, d, d))).astype(I.dtype)
+    T = (1.5 * rng.standard_normal((nn, d))).astype(I.dtype)
+    go = rnd(rng, (nn, nc) + sp, dtype)
+    assert_bits(ext.affine_interp_forward(dev(I), dev(A), dev(T)), orc.affine_interp_forward(I, A, T), "affine forward")
+    for needs in ((True, True, True), (False, True, True), (True, False, False), (False, False, True)):
+        dI, dA, dT = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), *needs)
+        oI, oA, oT = orc.affine_interp_backward(go, I, A, T, *needs)
+        nvox = float(np.prod(sp)) * nc
+        if needs[0]:
+            assert_close(dI, oI, dtype, "affine d_I", mult=4.0)
+        else:
+            assert dI.numel() == 0
+        # dA/dT are sums over nvox terms; fp32 summation order differs from the reference's tree
+        if needs[1]:
+            assert_close(dA, oA, dtype, "affine d_A", scale=np.abs(oA).max() + np.sqrt(nvox) * max(sp), mult=8.0)
+        else:
+            assert dA.numel() == 0
+        if needs[2]:
+            assert_close(dT, oT, dtype, "affine d_T", scale=np.abs(oT).max() + np.sqrt(nvox), mult=8.0)
+        else:
+            assert dT.numel() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp,out", [((4, 5, 6), (5, 7, 9)), ((6, 6, 6), (3, 3, 3)), ((4, 5), (9, 4)), ((2, 2, 2), (3, 3, 70))])
+def test_regrid(ext, dtype, sp, out):
+    rng = np.random.default_rng(hash((sp, out)) % 2**31)
+    d = len(sp)
+    I = rnd(rng, (2, 3) + sp, dtype)
+    origin = [(s - 1) * 0.5 + 0.3 for s in sp]
+    spacing = [(a - 1) / (b - 1) * 1.1 for a, b in zip(sp, out)]
+    assert_bits(ext.regrid_forward(dev(I), out, origin, spacing), orc.regrid_forward(I, out, origin, spacing), "regrid forward")
+    go = rnd(rng, (2, 3) + out, dtype)
+    assert_close(ext.regrid_backward(dev(go), sp, out, origin, spacing), orc.regrid_backward(go, sp, out, origin, spacing),
+                 dtype, "regrid backward", mult=4.0)
+
+
+def test_reference_known_answers_through_hip(ext):
+    """SURVEY 8(c) table (outputs of the reference's own kernels), float64, through the HIP path."""
+    import lagomorph_amd as lm
+
+    res = kat.evaluate(ext, lm, torch.float64, "cuda")
+    kat.check(res, rel=2e-12, abs_floor=2e-9)
+    res = kat.evaluate(ext, lm, torch.float32, "cuda")
+    kat.check(res, rel=2e-5, abs_floor=2e-4)
+
+
+def test_empty_and_error_behaviour(ext):
+    """Empty batches are no-ops; CPU or non-contiguous inputs raise like CHECK_INPUT
+    (extension.cpp:8-10); dimension violations raise the reference's messages."""
+    I = torch.zeros((0, 1, 4, 4, 4), device="cuda")
+    u = torch.zeros((0, 3, 4, 4, 4), device="cuda")
+    assert ext.interp_forward(I, u, 1.0).shape == (0, 1, 4, 4, 4)
+    dI, du = ext.interp_backward(I, I, u, 1.0, True, True)
+    assert dI.shape == I.shape and du.shape == u.shape
+    assert ext.jacobian_times_vectorfield_forward(u, u, True, False).shape == u.shape
+    I = torch.randn((2, 1, 4, 4, 4), device="cuda")
+    u = torch.randn((2, 3, 4, 4, 4), device="cuda")
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        ext.interp_forward(I.cpu(), u, 1.0)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        ext.interp_forward(I, u.transpose(3, 4), 1.0)
+    with pytest.raises(RuntimeError, match="Only two- and three-dimensional"):
+        ext.interp_forward(I[:, :, 0, 0], u[:, :, 0, 0], 1.0)
+    with pytest.raises(RuntimeError, match="thin"):
+        ext.jacobian_times_vectorfield_forward(u[:, :, :, :, :1].contiguous(), u[:, :, :, :, :1].contiguous(), True, False)
+    with pytest.raises(RuntimeError, match="Displacement mode only defined for vector fields"):
+        ext.jacobian_times_vectorfield_forward(I, u, True, False)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ext.affine_interp_forward(I.cpu(), torch.eye(3)[None].repeat(2, 1, 1), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError, match="Type of LUTs must equal that of image"):
+        F = torch.zeros((1, 2, 4, 3, 2), device="cuda")
+        l = [torch.zeros(4, device="cuda", dtype=torch.float64), torch.zeros(3, device="cuda", dtype=torch.float64)]
+        ext.fluid_operator(F, True, l, l, 0.1, 0.0, 0.01)
