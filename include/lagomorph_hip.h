@@ -21,8 +21,8 @@
  *  - Return value: LAGO_OK (0), LAGO_ERR_INVALID (-1: bad argument; nothing
  *    was launched) or LAGO_ERR_HIP (-2: a HIP runtime call failed).
  *    lago_last_error() returns a thread-local description.
- *  - Extent limits: nx*ny*nz < 2^31 per batch item; total elements per tensor
- *    are addressed with 64-bit offsets.
+ *  - Extent limits: nx*ny*nz < 2^29 per batch item (one channel plane is addressed
+ *    with 32-bit byte offsets); whole tensors are addressed with 64-bit offsets.
  */
 #ifndef LAGOMORPH_HIP_H
 #define LAGOMORPH_HIP_H
@@ -119,6 +119,31 @@ void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nth
 
 LAGO_DECLARE(float, _f32)
 LAGO_DECLARE(double, _f64)
+
+/* ---- fused geometry operators (beyond the reference's extension surface) -------------
+ * compose: out = ds*u + dt*interp(v, u, ds) in one pass -- deform.compose
+ * (/root/reference/lagomorph/deform.py:53-55), which the reference evaluates as one interp
+ * kernel plus three elementwise kernels.  u, v, out: (nn, dim, sp).  Bit-identical to the
+ * unfused expression (the three roundings are kept). */
+int lago_compose_f32(float *out, const float *u, const float *v, double ds, double dt, int dim, int64_t nn,
+                     int64_t nx, int64_t ny, int64_t nz, void *stream);
+int lago_compose_f64(double *out, const double *u, const double *v, double ds, double dt, int dim, int64_t nn,
+                     int64_t nx, int64_t ny, int64_t nz, void *stream);
+
+/* fluid_metric: the whole FluidMetricOperator.forward of the reference
+ * (/root/reference/lagomorph/metric.py:11-19) in one call: out = irfft(L^(+-2) rfft(m)).
+ * m, out: (nn, dim, nx, ny[, nz]) real; work: caller-provided scratch for the half spectrum,
+ * nn*dim*nx*ny*(nz/2+1)*2 reals for dim == 3 (nn*dim*nx*(ny/2+1)*2 for dim == 2), clobbered.
+ * m is not modified; out may not alias m.  LUTs as for lago_fluid_operator.  rocFFT (via hipFFT)
+ * does the transforms; plans are cached inside the library per shape. */
+int lago_fluid_metric_f32(float *out, const float *m, float *work, int inverse, const float *cosX,
+                          const float *sinX, const float *cosY, const float *sinY, const float *cosZ,
+                          const float *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn,
+                          int64_t nx, int64_t ny, int64_t nz, void *stream);
+int lago_fluid_metric_f64(double *out, const double *m, double *work, int inverse, const double *cosX,
+                          const double *sinX, const double *cosY, const double *sinY, const double *cosZ,
+                          const double *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn,
+                          int64_t nx, int64_t ny, int64_t nz, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblagomorph_hip.so")
-SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip"]
+SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3",
@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhipfft"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

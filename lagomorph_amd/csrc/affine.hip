@@ -36,17 +36,17 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out,
     if (DIM == 3) {
         const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
         const R fi = (R)v.i - ox, fj = (R)v.j - oy, fk = (R)v.k - oz;
-        const R hx = An[0] * fi + An[1] * fj + An[2] * fk + Tn[0] + ox;
-        const R hy = An[3] * fi + An[4] * fj + An[5] * fk + Tn[1] + oy;
-        const R hz = An[6] * fi + An[7] * fj + An[8] * fk + Tn[2] + oz;
+        const R hx = lg_fma(An[2], fk, lg_fma(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+        const R hy = lg_fma(An[5], fk, lg_fma(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+        const R hz = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
         Lerp3<R> L;
         L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
         for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
     } else {
         const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
         const R fi = (R)v.j - ox, fj = (R)v.k - oy;
-        const R hx = An[0] * fi + An[1] * fj + Tn[0] + ox;
-        const R hy = An[2] * fi + An[3] * fj + Tn[1] + oy;
+        const R hx = lg_fma(An[0], fi, An[1] * fj) + Tn[0] + ox;
+        const R hy = lg_fma(An[2], fi, An[3] * fj) + Tn[1] + oy;
         Lerp2<R> L;
         L.setup(hx, hy, g.ny, g.nz);
         for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
@@ -83,9 +83,9 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I,
         if (DIM == 3) {
             const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
             const R fi = (R)v.i - ox, fj = (R)v.j - oy, fk = (R)v.k - oz;
-            const R hx = An[0] * fi + An[1] * fj + An[2] * fk + Tn[0] + ox;
-            const R hy = An[3] * fi + An[4] * fj + An[5] * fk + Tn[1] + oy;
-            const R hz = An[6] * fi + An[7] * fj + An[8] * fk + Tn[2] + oz;
+            const R hx = lg_fma(An[2], fk, lg_fma(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+            const R hy = lg_fma(An[5], fk, lg_fma(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+            const R hz = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
             Splat3<R> S;
             Lerp3<R> L;
             if (NEED_I) S.setup(hx, hy, hz, g.nx, g.ny, g.nz);
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I,
                     L.grad(In + (size_t)c * nv, gx, gy, gz);
                     gx *= diff; gy *= diff; gz *= diff;  // cuda/affine.cu:415-417
                     if (NEED_A) {
-                        p[0] += gx * fi; p[1] += gx * fj; p[2] += gx * fk;
-                        p[3] += gy * fi; p[4] += gy * fj; p[5] += gy * fk;
-                        p[6] += gz * fi; p[7] += gz * fj; p[8] += gz * fk;
+                        p[0] = lg_fma(gx, fi, p[0]); p[1] = lg_fma(gx, fj, p[1]); p[2] = lg_fma(gx, fk, p[2]);
+                        p[3] = lg_fma(gy, fi, p[3]); p[4] = lg_fma(gy, fj, p[4]); p[5] = lg_fma(gy, fk, p[5]);
+                        p[6] = lg_fma(gz, fi, p[6]); p[7] = lg_fma(gz, fj, p[7]); p[8] = lg_fma(gz, fk, p[8]);
                     }
                     if (NEED_T) { p[9] += gx; p[10] += gy; p[11] += gz; }
                 }
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I,
         } else {
             const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
             const R fi = (R)v.j - ox, fj = (R)v.k - oy;
-            const R hx = An[0] * fi + An[1] * fj + Tn[0] + ox;
-            const R hy = An[2] * fi + An[3] * fj + Tn[1] + oy;
+            const R hx = lg_fma(An[0], fi, An[1] * fj) + Tn[0] + ox;
+            const R hy = lg_fma(An[2], fi, An[3] * fj) + Tn[1] + oy;
             Splat2<R> S;
             Lerp2<R> L;
             if (NEED_I) S.setup(hx, hy, g.ny, g.nz);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I,
                     R gx, gy;
                     L.grad(In + (size_t)c * nv, gx, gy);
                     gx *= diff; gy *= diff;  // cuda/affine.cu:241-242
-                    if (NEED_A) { p[0] += gx * fi; p[1] += gx * fj; p[2] += gy * fi; p[3] += gy * fj; }
+                    if (NEED_A) { p[0] = lg_fma(gx, fi, p[0]); p[1] = lg_fma(gx, fj, p[1]); p[2] = lg_fma(gy, fi, p[2]); p[3] = lg_fma(gy, fj, p[3]); }
                     if (NEED_T) { p[4] += gx; p[5] += gy; }
                 }
             }
@@ -174,11 +174,11 @@ __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out,
         const R Ox = (R)rp.O[0], Oy = (R)rp.O[1], Oz = (R)rp.O[2];
         const R Sx = (R)rp.S[0], Sy = (R)rp.S[1], Sz = (R)rp.S[2];
         const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
-        const R hx = ((R)v.i - ox) * Sx + Ox;
-        const R hy = ((R)v.j - oy) * Sy + Oy;
+        const R hx = lg_fma((R)v.i - ox, Sx, Ox);
+        const R hy = lg_fma((R)v.j - oy, Sy, Oy);
         // The reference advances hz by `hz += Sz` per output k (cuda/affine.cu:669-675):
         // a sequentially rounded running sum, reproduced here so positions match bit for bit.
-        R hz = Oz - oz * Sz;
+        R hz = lg_fma(-oz, Sz, Oz);
         for (int k = 0; k < v.k; ++k) hz += Sz;
         Lerp3<R> L;
         L.setup(hx, hy, hz, rp.nx, rp.ny, rp.nz);
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out,
         const R Ox = (R)rp.O[0], Oy = (R)rp.O[1];
         const R Sx = (R)rp.S[0], Sy = (R)rp.S[1];
         const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
-        const R hx = ((R)v.j - ox) * Sx + Ox;
-        const R hy = ((R)v.k - oy) * Sy + Oy;
+        const R hx = lg_fma((R)v.j - ox, Sx, Ox);
+        const R hy = lg_fma((R)v.k - oy, Sy, Oy);
         Lerp2<R> L;
         L.setup(hx, hy, rp.ny, rp.nz);
         for (int q = 0; q < nq; ++q) out[(size_t)q * Nv + v.s] = L.value(I + (size_t)q * nvin);
@@ -206,9 +206,9 @@ __global__ __launch_bounds__(kBlock) void regrid_bwd_kernel(R *__restrict__ d_I,
         const R Ox = (R)rp.O[0], Oy = (R)rp.O[1], Oz = (R)rp.O[2];
         const R Sx = (R)rp.S[0], Sy = (R)rp.S[1], Sz = (R)rp.S[2];
         const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
-        const R hx = ((R)v.i - ox) * Sx + Ox;
-        const R hy = ((R)v.j - oy) * Sy + Oy;
-        const R hz = ((R)v.k - oz) * Sz + Oz;  // cuda/affine.cu:791: per voxel, no running sum
+        const R hx = lg_fma((R)v.i - ox, Sx, Ox);
+        const R hy = lg_fma((R)v.j - oy, Sy, Oy);
+        const R hz = lg_fma((R)v.k - oz, Sz, Oz);  // cuda/affine.cu:791: per voxel, no running sum
         Splat3<R> S;
         S.setup(hx, hy, hz, rp.nx, rp.ny, rp.nz);
         for (int q = 0; q < nq; ++q) {
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(kBlock) void regrid_bwd_kernel(R *__restrict__ d_I,
         const R Ox = (R)rp.O[0], Oy = (R)rp.O[1];
         const R Sx = (R)rp.S[0], Sy = (R)rp.S[1];
         const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
-        const R hx = ((R)v.j - ox) * Sx + Ox;
-        const R hy = ((R)v.k - oy) * Sy + Oy;
+        const R hx = lg_fma((R)v.j - ox, Sx, Ox);
+        const R hy = lg_fma((R)v.k - oy, Sy, Oy);
         Splat2<R> S;
         S.setup(hx, hy, rp.ny, rp.nz);
         for (int q = 0; q < nq; ++q) {

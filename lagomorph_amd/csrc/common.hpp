@@ -63,6 +63,7 @@ struct Geom {
 };
 
 inline bool make_geom(Geom &g, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, int vox_per_block = kBlock) {
+    // one channel of one batch item is addressed with 32-bit byte offsets: nvox * 8 < 2^32
     if (dim == 2) {
         nz = ny;
         ny = nx;
@@ -70,7 +71,7 @@ inline bool make_geom(Geom &g, int dim, int64_t nn, int64_t nx, int64_t ny, int6
     }
     if (nn < 0 || nx < 1 || ny < 1 || nz < 1) return false;
     int64_t nv = nx * ny * nz;
-    if (nv >= (1ll << 31)) return false;
+    if (nv >= (1ll << 29)) return false;
     g.nx = (int)nx;
     g.ny = (int)ny;
     g.nz = (int)nz;
@@ -120,73 +121,144 @@ __device__ __forceinline__ Vox locate(const Geom &g) {
     return v;
 }
 
-// include/interp.h:64-70 (floor rule), saturated like the oracle.
+// ---- arithmetic contract ----------------------------------------------------
+// Every `a*b + c` of the reference is evaluated as one fused multiply-add and a
+// sum of two products `a*b + c*d` as fma(a, b, c*d) (left product fused): the
+// contraction nvcc applies by default to the reference.  The CPU oracle spells
+// out the identical pattern (oracle/lago_oracle_impl.h, LG_FMA), and the library
+// is compiled with -ffp-contract=off so that nothing else fuses.
+__device__ __forceinline__ float lg_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double lg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// include/interp.h:64-70: (int)x, minus one for negative non-integers == floor(x).
+// Saturated to +-2^30 (as the oracle does) so that floor + 1 cannot overflow.
 template <typename R>
 __device__ __forceinline__ int lg_floor(R x) {
     x = x > (R)1073741824.0 ? (R)1073741824.0 : x;
     x = x < (R)-1073741824.0 ? (R)-1073741824.0 : x;
-    int f = (int)x;
-    if (x < 0 && x != (R)f) --f;
-    return f;
+    return (int)(sizeof(R) == 4 ? (R)__builtin_floorf((float)x) : (R)__builtin_floor((double)x));
 }
 
-// include/extrap.h:46-57 clampBackground on a (floor, ceil) pair
-__device__ __forceinline__ void clamp_pair(int &fl, int &ce, int size) {
-    if (fl < 0) {
-        fl = 0;
-        if (ce < 0) ce = 0;
-    }
-    if (ce >= size) {
-        ce = size - 1;
-        if (fl >= size) fl = size - 1;
-    }
-}
-
-// include/extrap.h:41-44
-__device__ __forceinline__ int clamp1(int r, int b) { return r < 0 ? 0 : (r >= b ? b - 1 : r); }
+// include/extrap.h:41-44 clamp(); clampBackground (extrap.h:46-57) on a
+// (floor, floor+1) pair is this clamp applied to both members.
+__device__ __forceinline__ int clamp1(int r, int b) { return max(0, min(r, b - 1)); }
 
 // Sample position x + dt*u: computed in double (dt is a double in the
 // reference, cuda/interp.cu:36-37,68-70) and narrowed to R.
 template <typename R>
 __device__ __forceinline__ R sample_pos(int i, double dt, R u) {
-    return (R)((double)(R)i + dt * (double)u);
+    return (R)__builtin_fma(dt, (double)u, (double)(R)i);
 }
 
-// 2D/3D lerp stencils: clamped corner offsets plus the fractional parts.
+// Gathers go through buffer loads: a 128-bit descriptor in SGPRs (built from a
+// wave-uniform plane pointer) plus a 32-bit per-lane byte offset -- no 64-bit
+// address arithmetic per load, and out-of-range offsets read 0 instead of faulting.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned int lg_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int lg_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ BufRsrc make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+template <typename R>
+__device__ __forceinline__ R buf_load1(BufRsrc r, uint32_t off);
+template <>
+__device__ __forceinline__ float buf_load1<float>(BufRsrc r, uint32_t off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ double buf_load1<double>(BufRsrc r, uint32_t off) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+// two adjacent elements with ONE load (element-aligned, not pair-aligned)
+template <typename R>
+__device__ __forceinline__ void buf_load2(BufRsrc r, uint32_t off, R &lo, R &hi);
+template <>
+__device__ __forceinline__ void buf_load2<float>(BufRsrc r, uint32_t off, float &lo, float &hi) {
+    lg_u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    // Opaque to the optimiser on purpose: hipcc 7.2 narrows a b64/b128 buffer load to its first
+    // dword when the elements are only consumed through selects (observed miscompile).
+    asm volatile("" : "+v"(p));
+    lo = __builtin_bit_cast(float, p.x);
+    hi = __builtin_bit_cast(float, p.y);
+}
+template <>
+__device__ __forceinline__ void buf_load2<double>(BufRsrc r, uint32_t off, double &lo, double &hi) {
+    lg_u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    asm volatile("" : "+v"(p));
+    lo = __builtin_bit_cast(double, lg_u32x2{p.x, p.y});
+    hi = __builtin_bit_cast(double, lg_u32x2{p.z, p.w});
+}
+
+// Trilinear stencil.  The 8 corners are 4 (x, y) rows times the z pair
+// (floor, floor+1), which is contiguous in memory: each row is fetched with ONE
+// pair load at z = zb = min(clamped floor, nz-2); when the sample lies beyond a z
+// border both members of the clamped pair coincide and are picked from the same
+// half.  Offsets are 32-bit byte offsets from a wave-uniform base pointer, so the
+// loads use the scalar-base addressing mode and need no 64-bit address math.
 template <typename R>
 struct Lerp3 {
-    uint32_t o[8];  // v0..v7 in the reference's corner order (include/interp.h:91-98)
+    uint32_t rb[4];   // byte offsets of rows (fx,fy) (cx,fy) (cx,cy) (fx,cy) at z = zb: v0/v4 v1/v5 v2/v6 v3/v7
     R t, u, v;
+    bool f_hi, c_lo;  // floor-z value is the pair's .hi / ceil-z value is the pair's .lo
+    bool thin;        // nz == 1: no pair exists
+    uint32_t bytes;   // size of one channel plane (uniform)
     __device__ __forceinline__ void setup(R x, R y, R z, int sx, int sy, int sz) {
-        int fx = lg_floor(x), fy = lg_floor(y), fz = lg_floor(z);
-        int cx = fx + 1, cy = fy + 1, cz = fz + 1;
-        t = x - (R)fx;
-        u = y - (R)fy;
-        v = z - (R)fz;
-        clamp_pair(fx, cx, sx);
-        clamp_pair(fy, cy, sy);
-        clamp_pair(fz, cz, sz);
-        uint32_t ff = ((uint32_t)fx * sy + fy) * sz, cf = ((uint32_t)cx * sy + fy) * sz;
-        uint32_t cc = ((uint32_t)cx * sy + cy) * sz, fc = ((uint32_t)fx * sy + cy) * sz;
-        o[0] = ff + fz; o[1] = cf + fz; o[2] = cc + fz; o[3] = fc + fz;
-        o[4] = ff + cz; o[5] = cf + cz; o[6] = cc + cz; o[7] = fc + cz;
+        const int flx = lg_floor(x), fly = lg_floor(y), flz = lg_floor(z);
+        t = x - (R)flx;
+        u = y - (R)fly;
+        v = z - (R)flz;
+        const int fx = clamp1(flx, sx), cx = clamp1(flx + 1, sx);
+        const int fy = clamp1(fly, sy), cy = clamp1(fly + 1, sy);
+        const int fz = clamp1(flz, sz), cz = clamp1(flz + 1, sz);
+        thin = sz < 2;
+        const int zb = thin ? 0 : min(fz, sz - 2);
+        f_hi = fz != zb;
+        c_lo = cz == zb;
+        const uint32_t rowB = (uint32_t)sz * (uint32_t)sizeof(R);   // uniform
+        const uint32_t slabB = (uint32_t)sy * rowB;                  // uniform
+        bytes = (uint32_t)sx * slabB;
+        const uint32_t ff = ((uint32_t)fx * (uint32_t)sy + (uint32_t)fy) * rowB + (uint32_t)zb * (uint32_t)sizeof(R);
+        const uint32_t dX = cx != fx ? slabB : 0u;
+        const uint32_t dY = cy != fy ? rowB : 0u;
+        rb[0] = ff;
+        rb[1] = ff + dX;
+        rb[2] = ff + dX + dY;
+        rb[3] = ff + dY;
+    }
+    // `img` must be wave-uniform (one channel plane): it becomes a buffer
+    // descriptor held in SGPRs, the per-lane part is the 32-bit byte offset.
+    __device__ __forceinline__ void fetch(const R *__restrict__ img, R (&c)[8]) const {
+        const BufRsrc r = make_rsrc(img, bytes);
+        if (thin) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = c[q + 4] = buf_load1<R>(r, rb[q]);
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            R lo, hi;
+            buf_load2<R>(r, rb[q], lo, hi);
+            c[q] = f_hi ? hi : lo;
+            c[q + 4] = c_lo ? lo : hi;
+        }
     }
     // include/interp.h:115-122
     __device__ __forceinline__ R value(const R *__restrict__ img) const {
-        R omt = (R)1.f - t, omu = (R)1.f - u, omv = (R)1.f - v;
-        R v0 = img[o[0]], v1 = img[o[1]], v2 = img[o[2]], v3 = img[o[3]];
-        R v4 = img[o[4]], v5 = img[o[5]], v6 = img[o[6]], v7 = img[o[7]];
-        return omv * (omu * (omt * v0 + t * v1) + u * (omt * v3 + t * v2)) +
-               v * (omu * (omt * v4 + t * v5) + u * (omt * v7 + t * v6));
+        R c[8];
+        fetch(img, c);
+        const R omt = (R)1.f - t, omu = (R)1.f - u, omv = (R)1.f - v;
+        return lg_fma(omv, lg_fma(omu, lg_fma(omt, c[0], t * c[1]), u * lg_fma(omt, c[3], t * c[2])),
+                      v * lg_fma(omu, lg_fma(omt, c[4], t * c[5]), u * lg_fma(omt, c[7], t * c[6])));
     }
     // include/interp.h:315-326
     __device__ __forceinline__ void grad(const R *__restrict__ img, R &gx, R &gy, R &gz) const {
-        R omt = (R)1.f - t, omu = (R)1.f - u, omv = (R)1.f - v;
-        R v0 = img[o[0]], v1 = img[o[1]], v2 = img[o[2]], v3 = img[o[3]];
-        R v4 = img[o[4]], v5 = img[o[5]], v6 = img[o[6]], v7 = img[o[7]];
-        gx = omv * (omu * (v1 - v0) + u * (v2 - v3)) + v * (omu * (v5 - v4) + u * (v6 - v7));
-        gy = omv * (omt * (v3 - v0) + t * (v2 - v1)) + v * (omt * (v7 - v4) + t * (v6 - v5));
-        gz = omu * (omt * (v4 - v0) + t * (v5 - v1)) + u * (omt * (v7 - v3) + t * (v6 - v2));
+        R c[8];
+        fetch(img, c);
+        const R omt = (R)1.f - t, omu = (R)1.f - u, omv = (R)1.f - v;
+        gx = lg_fma(omv, lg_fma(omu, c[1] - c[0], u * (c[2] - c[3])), v * lg_fma(omu, c[5] - c[4], u * (c[6] - c[7])));
+        gy = lg_fma(omv, lg_fma(omt, c[3] - c[0], t * (c[2] - c[1])), v * lg_fma(omt, c[7] - c[4], t * (c[6] - c[5])));
+        gz = lg_fma(omu, lg_fma(omt, c[4] - c[0], t * (c[5] - c[1])), u * lg_fma(omt, c[7] - c[3], t * (c[6] - c[2])));
     }
 };
 
@@ -195,12 +267,11 @@ struct Lerp2 {
     uint32_t o[4];  // v0..v3 (include/interp.h:36-39)
     R t, u;
     __device__ __forceinline__ void setup(R x, R y, int sx, int sy) {
-        int fx = lg_floor(x), fy = lg_floor(y);
-        int cx = fx + 1, cy = fy + 1;
-        t = x - (R)fx;
-        u = y - (R)fy;
-        clamp_pair(fx, cx, sx);
-        clamp_pair(fy, cy, sy);
+        const int flx = lg_floor(x), fly = lg_floor(y);
+        t = x - (R)flx;
+        u = y - (R)fly;
+        const int fx = clamp1(flx, sx), cx = clamp1(flx + 1, sx);
+        const int fy = clamp1(fly, sy), cy = clamp1(fly + 1, sy);
         o[0] = (uint32_t)fx * sy + fy;
         o[1] = (uint32_t)cx * sy + fy;
         o[2] = (uint32_t)cx * sy + cy;
@@ -208,15 +279,15 @@ struct Lerp2 {
     }
     // include/interp.h:52-55
     __device__ __forceinline__ R value(const R *__restrict__ img) const {
-        R omt = (R)1.f - t, omu = (R)1.f - u;
-        R v0 = img[o[0]], v1 = img[o[1]], v2 = img[o[2]], v3 = img[o[3]];
-        return omt * (omu * v0 + u * v3) + t * (omu * v1 + u * v2);
+        const R omt = (R)1.f - t, omu = (R)1.f - u;
+        const R v0 = img[o[0]], v1 = img[o[1]], v2 = img[o[2]], v3 = img[o[3]];
+        return lg_fma(omt, lg_fma(omu, v0, u * v3), t * lg_fma(omu, v1, u * v2));
     }
     // include/interp.h:202-203
     __device__ __forceinline__ void grad(const R *__restrict__ img, R &gx, R &gy) const {
-        R v0 = img[o[0]], v1 = img[o[1]], v2 = img[o[2]], v3 = img[o[3]];
-        gx = v1 - v0 + u * (v2 - v3 - v1 + v0);
-        gy = v3 - v0 + t * (v2 - v1 - v3 + v0);
+        const R v0 = img[o[0]], v1 = img[o[1]], v2 = img[o[2]], v3 = img[o[3]];
+        gx = lg_fma(u, v2 - v3 - v1 + v0, v1 - v0);
+        gy = lg_fma(t, v2 - v1 - v3 + v0, v3 - v0);
     }
 };
 

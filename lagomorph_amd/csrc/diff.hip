@@ -47,16 +47,16 @@ struct Stencil {
     template <typename R>
     __device__ __forceinline__ R dT(const R *__restrict__ a, const R *__restrict__ b, int d) const {
         const int st = stride[d];
-        if (pos[d] == 0) return (R)(-.5) * (a[0] * b[0] + a[st] * b[st]);
-        if (pos[d] == len[d] - 1) return (R)(.5) * (a[0] * b[0] + a[-st] * b[-st]);
-        return (R)(-.5) * (a[st] * b[st] - a[-st] * b[-st]);
+        if (pos[d] == 0) return (R)(-.5) * lg_fma(a[0], b[0], a[st] * b[st]);
+        if (pos[d] == len[d] - 1) return (R)(.5) * lg_fma(a[0], b[0], a[-st] * b[-st]);
+        return (R)(-.5) * lg_fma(a[st], b[st], -(a[-st] * b[-st]));
     }
 };
 
 template <typename R, int DIM>
 __device__ __forceinline__ R dotw(const R *g, const R *w) {
-    R s = g[0] * w[0] + g[1] * w[1];
-    if (DIM == 3) s = s + g[2] * w[2];
+    R s = lg_fma(g[0], w[0], g[1] * w[1]);
+    if (DIM == 3) s = lg_fma(g[2], w[2], s);
     return s;
 }
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void jtv_fwd_kernel(R *__restrict__ out, co
             st.grad(vn + (size_t)c * nv, gq);
             if (DISP) gq[c] = gq[c] + (R)1.0;
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) acc[d] = c == 0 ? gq[d] * wv[c] : acc[d] + gq[d] * wv[c];
+            for (int d = 0; d < DIM; ++d) acc[d] = c == 0 ? gq[d] * wv[c] : lg_fma(gq[d], wv[c], acc[d]);
         }
 #pragma unroll
         for (int d = 0; d < DIM; ++d) on[(size_t)d * nv] = acc[d];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
             }
             const R goc = gon[(size_t)c * nv];
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) dw[d] = dw[d] + gq[d] * goc;
+            for (int d = 0; d < DIM; ++d) dw[d] = lg_fma(gq[d], goc, dw[d]);
             R acc = 0;
 #pragma unroll
             for (int d = 0; d < DIM; ++d) acc = acc + st.dT(wn + (size_t)d * nv, gon + (size_t)c * nv, d);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void jtv_adj_bwd_kernel(R *__restrict__ d_v
         st.grad(gon + (size_t)c * nv, gq);
         const R vc = vn[(size_t)c * nv];
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) dw[d] = c == 0 ? gq[d] * vc : dw[d] + gq[d] * vc;
+        for (int d = 0; d < DIM; ++d) dw[d] = c == 0 ? gq[d] * vc : lg_fma(gq[d], vc, dw[d]);
         dvn[(size_t)c * nv] = (R)0 + dotw<R, DIM>(gq, wv);
     }
 #pragma unroll

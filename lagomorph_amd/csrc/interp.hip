@@ -69,9 +69,9 @@ __global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I,
                 R gx, gy, gz;
                 L.grad(In + (size_t)c * nv, gx, gy, gz);
                 diff = (R)((double)diff * dt);  // cuda/interp.cu:230
-                ax = ax + gx * diff;
-                ay = ay + gy * diff;
-                az = az + gz * diff;
+                ax = lg_fma(gx, diff, ax);
+                ay = lg_fma(gy, diff, ay);
+                az = lg_fma(gz, diff, az);
             }
         }
         if (NEED_U) {
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I,
                 R gx, gy;
                 L.grad(In + (size_t)c * nv, gx, gy);
                 diff = (R)((double)diff * dt);  // cuda/interp.cu:171
-                ax = ax + gx * diff;
-                ay = ay + gy * diff;
+                ax = lg_fma(gx, diff, ax);
+                ay = lg_fma(gy, diff, ay);
             }
         }
         if (NEED_U) {

@@ -24,7 +24,7 @@ struct alignas(2 * sizeof(R)) Cplx {
 template <typename R>
 __device__ __forceinline__ R safe_sqrt(R x) {
     if ((double)x < 1e-8) return (R)1e-4;
-    return sizeof(R) == 4 ? (R)__fsqrt_rn((float)x) : (R)__dsqrt_rn((double)x);
+    return sizeof(R) == 4 ? (R)sqrtf((float)x) : (R)sqrt((double)x);  // correctly rounded (IEEE) forms
 }
 
 template <typename R>
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm,
                                                        const R *__restrict__ sinX, const R *__restrict__ cosY,
                                                        const R *__restrict__ sinY, const R *__restrict__ cosZ,
                                                        const R *__restrict__ sinZ, double alpha, double beta,
-                                                       double gamma, int nn, Geom g) {
+                                                       double gamma, int nn, Geom g, R scale) {
     const Vox v = locate(g);
     if (!v.valid) return;
     const size_t nv = g.nvox;  // complex bins per component
@@ -45,28 +45,28 @@ __global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm,
     if (DIM == 3) {
         const R wx = cosX[v.i], wy = cosY[v.j], wz = cosZ[v.k];
         const R sx = sinX[v.i], sy = sinY[v.j], sz = sinZ[v.k];
-        const R lambda = (R)(gamma + alpha * (double)(wx + wy + wz));
-        const R l00 = (R)((double)lambda - beta * (double)wx);
-        const R l11 = (R)((double)lambda - beta * (double)wy);
-        const R l22 = (R)((double)lambda - beta * (double)wz);
+        const R lambda = (R)__builtin_fma(alpha, (double)(wx + wy + wz), gamma);
+        const R l00 = (R)__builtin_fma(-beta, (double)wx, (double)lambda);
+        const R l11 = (R)__builtin_fma(-beta, (double)wy, (double)lambda);
+        const R l22 = (R)__builtin_fma(-beta, (double)wz, (double)lambda);
         const R l10 = (R)(beta * (double)sx * (double)sy);
         const R l20 = (R)(beta * (double)sx * (double)sz);
         const R l21 = (R)(beta * (double)sy * (double)sz);
-        const R L00 = l00 * l00 + l10 * l10 + l20 * l20;
-        const R L10 = l00 * l10 + l10 * l11 + l20 * l21;
-        const R L11 = l10 * l10 + l11 * l11 + l21 * l21;
-        const R L20 = l00 * l20 + l10 * l21 + l20 * l22;
-        const R L21 = l10 * l20 + l11 * l21 + l21 * l22;
-        const R L22 = l20 * l20 + l21 * l21 + l22 * l22;
+        const R L00 = lg_fma(l20, l20, lg_fma(l00, l00, l10 * l10));
+        const R L10 = lg_fma(l20, l21, lg_fma(l00, l10, l10 * l11));
+        const R L11 = lg_fma(l21, l21, lg_fma(l10, l10, l11 * l11));
+        const R L20 = lg_fma(l20, l22, lg_fma(l00, l20, l10 * l21));
+        const R L21 = lg_fma(l21, l22, lg_fma(l10, l20, l11 * l21));
+        const R L22 = lg_fma(l22, l22, lg_fma(l20, l20, l21 * l21));
         R ooG00 = 0, G10 = 0, ooG11 = 0, G20 = 0, G21 = 0, ooG22 = 0;
         if (INV) {  // cuda/metric.cu:47-78
             ooG00 = recip_via_double(safe_sqrt(L00));
             G10 = L10 * ooG00;
             G20 = L20 * ooG00;
-            ooG11 = L11 - G10 * G10;
+            ooG11 = lg_fma(-G10, G10, L11);
             ooG11 = recip_via_double(safe_sqrt(ooG11));
-            G21 = (L21 - G20 * G10) * ooG11;
-            ooG22 = L22 - G20 * G20 - G21 * G21;
+            G21 = lg_fma(-G20, G10, L21) * ooG11;
+            ooG22 = lg_fma(-G21, G21, lg_fma(-G20, G20, L22));
             ooG22 = recip_via_double(safe_sqrt(ooG22));
         }
         for (int n = 0; n < nn; ++n, F += 3 * nv) {
@@ -77,38 +77,38 @@ __global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm,
                 R bX = X[q], bY = Y[q], bZ = Z[q];
                 if (INV) {  // cuda/metric.cu:103-130
                     R y0 = bX * ooG00;
-                    R y1 = (bY - G10 * y0) * ooG11;
-                    R y2 = (bZ - G20 * y0 - G21 * y1) * ooG22;
+                    R y1 = lg_fma(-G10, y0, bY) * ooG11;
+                    R y2 = lg_fma(-G21, y1, lg_fma(-G20, y0, bZ)) * ooG22;
                     bZ = y2 * ooG22;
-                    bY = (y1 - G21 * bZ) * ooG11;
-                    bX = (y0 - G10 * bY - G20 * bZ) * ooG00;
+                    bY = lg_fma(-G21, bZ, y1) * ooG11;
+                    bX = lg_fma(-G20, bZ, lg_fma(-G10, bY, y0)) * ooG00;
                 } else {  // cuda/metric.cu:145-160
-                    R x = L00 * bX + L10 * bY + L20 * bZ;
-                    R y = L10 * bX + L11 * bY + L21 * bZ;
-                    bZ = L20 * bX + L21 * bY + L22 * bZ;
+                    R x = lg_fma(L20, bZ, lg_fma(L00, bX, L10 * bY));
+                    R y = lg_fma(L21, bZ, lg_fma(L10, bX, L11 * bY));
+                    bZ = lg_fma(L22, bZ, lg_fma(L20, bX, L21 * bY));
                     bX = x;
                     bY = y;
                 }
                 X[q] = bX; Y[q] = bY; Z[q] = bZ;
             }
-            F[0] = Cplx<R>{X[0], X[1]};
-            F[nv] = Cplx<R>{Y[0], Y[1]};
-            F[2 * nv] = Cplx<R>{Z[0], Z[1]};
+            F[0] = Cplx<R>{X[0] * scale, X[1] * scale};  // scale == 1 is a bitwise no-op
+            F[nv] = Cplx<R>{Y[0] * scale, Y[1] * scale};
+            F[2 * nv] = Cplx<R>{Z[0] * scale, Z[1] * scale};
         }
     } else {
         const R wx = cosX[v.j], wy = cosY[v.k];
-        const R lambda = (R)(gamma + alpha * (double)(wx + wy));
-        const R l00 = (R)((double)lambda - beta * (double)wx);
-        const R l11 = (R)((double)lambda - beta * (double)wy);
+        const R lambda = (R)__builtin_fma(alpha, (double)(wx + wy), gamma);
+        const R l00 = (R)__builtin_fma(-beta, (double)wx, (double)lambda);
+        const R l11 = (R)__builtin_fma(-beta, (double)wy, (double)lambda);
         const R l10 = (R)(beta * (double)sinX[v.j] * (double)sinY[v.k]);
-        const R L00 = l00 * l00 + l10 * l10;
-        const R L10 = l00 * l10 + l10 * l11;
-        const R L11 = l11 * l11 + l10 * l10;
+        const R L00 = lg_fma(l00, l00, l10 * l10);
+        const R L10 = lg_fma(l00, l10, l10 * l11);
+        const R L11 = lg_fma(l11, l11, l10 * l10);
         R ooG00 = 0, G10 = 0, ooG11 = 0;
         if (INV) {  // cuda/metric.cu:20-45
             ooG00 = recip_via_double(safe_sqrt(L00));
             G10 = L10 * ooG00;
-            ooG11 = L11 - G10 * G10;
+            ooG11 = lg_fma(-G10, G10, L11);
             ooG11 = recip_via_double(safe_sqrt(ooG11));
         }
         for (int n = 0; n < nn; ++n, F += 2 * nv) {
@@ -119,26 +119,26 @@ __global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm,
                 R bX = X[q], bY = Y[q];
                 if (INV) {  // cuda/metric.cu:80-101
                     R y0 = bX * ooG00;
-                    R y1 = (bY - G10 * y0) * ooG11;
+                    R y1 = lg_fma(-G10, y0, bY) * ooG11;
                     bY = y1 * ooG11;
-                    bX = (y0 - G10 * bY) * ooG00;
+                    bX = lg_fma(-G10, bY, y0) * ooG00;
                 } else {  // cuda/metric.cu:132-143
-                    R x = L00 * bX + L10 * bY;
-                    bY = L10 * bX + L11 * bY;
+                    R x = lg_fma(L00, bX, L10 * bY);
+                    bY = lg_fma(L10, bX, L11 * bY);
                     bX = x;
                 }
                 X[q] = bX; Y[q] = bY;
             }
-            F[0] = Cplx<R>{X[0], X[1]};
-            F[nv] = Cplx<R>{Y[0], Y[1]};
+            F[0] = Cplx<R>{X[0] * scale, X[1] * scale};
+            F[nv] = Cplx<R>{Y[0] * scale, Y[1] * scale};
         }
     }
 }
 
 template <typename R>
-static int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
-                               const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim,
-                               int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {
+int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
+                        const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim,
+                        int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream, double scale) {
     if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional fluid metric is supported");
     Geom g;
     if (nn < 0 || nn >= (1ll << 31) || !make_geom(g, dim, 1, nx, ny, nz))
@@ -151,7 +151,7 @@ static int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX,
     Cplx<R> *F = reinterpret_cast<Cplx<R> *>(Fm);
 #define LAUNCH(D, INV)                                                                                           \
     hipLaunchKernelGGL((fluid_kernel<R, D, INV>), dim3(g.nblocks), dim3(kBlock), 0, s, F, cosX, sinX, cosY, sinY, \
-                       cosZ, sinZ, alpha, beta, gamma, (int)nn, g)
+                       cosZ, sinZ, alpha, beta, gamma, (int)nn, g, (R)scale)
     if (dim == 3) {
         if (inverse) LAUNCH(3, true); else LAUNCH(3, false);
     } else {
@@ -160,6 +160,13 @@ static int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX,
 #undef LAUNCH
     return finish_launch(s, "fluid_operator");
 }
+
+template int fluid_operator_impl<float>(float *, int, const float *, const float *, const float *, const float *,
+                                        const float *, const float *, double, double, double, int, int64_t, int64_t,
+                                        int64_t, int64_t, void *, double);
+template int fluid_operator_impl<double>(double *, int, const double *, const double *, const double *,
+                                         const double *, const double *, const double *, double, double, double, int,
+                                         int64_t, int64_t, int64_t, int64_t, void *, double);
 
 }  // namespace lago
 
@@ -170,7 +177,7 @@ extern "C" {
                                  double gamma, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz,           \
                                  void *stream) {                                                                  \
         return lago::fluid_operator_impl<REAL>(Fm, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta,      \
-                                               gamma, dim, nn, nx, ny, nz, stream);                               \
+                                               gamma, dim, nn, nx, ny, nz, stream, 1.0);                          \
     }
 LAGO_DEFINE(float, _f32)
 LAGO_DEFINE(double, _f64)

@@ -137,13 +137,13 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                 Lq.grad(Ic, gx, gy, gz);
                 diff = (R)((double)diff * dt);  // cuda/interp.cu:230
                 if (c == 0) {
-                    dun[s] = (R)0 + gx * diff;
-                    dun[s + nv] = (R)0 + gy * diff;
-                    dun[s + 2 * nv] = (R)0 + gz * diff;
+                    dun[s] = lg_fma(gx, diff, (R)0);
+                    dun[s + nv] = lg_fma(gy, diff, (R)0);
+                    dun[s + 2 * nv] = lg_fma(gz, diff, (R)0);
                 } else {
-                    dun[s] = dun[s] + gx * diff;
-                    dun[s + nv] = dun[s + nv] + gy * diff;
-                    dun[s + 2 * nv] = dun[s + 2 * nv] + gz * diff;
+                    dun[s] = lg_fma(gx, diff, dun[s]);
+                    dun[s + nv] = lg_fma(gy, diff, dun[s + nv]);
+                    dun[s + 2 * nv] = lg_fma(gz, diff, dun[s + 2 * nv]);
                 }
             }
         }

@@ -48,8 +48,31 @@ def interp_hessian_diagonal_image(I, u, dt=1.0):
     return lagomorph_ext.interp_hessian_diagonal_image(I, u, dt)
 
 
+class ComposeFunction(torch.autograd.Function):
+    """ds*u + dt*interp(v, u, ds) as ONE kernel (csrc/fused.hip).  Used by compose() when both
+    arguments are vector fields of the same shape; bit-identical to the unfused expression."""
+
+    @staticmethod
+    def forward(ctx, u, v, ds, dt):
+        ctx.ds, ctx.dt = ds, dt
+        ctx.save_for_backward(u, v)
+        return lagomorph_ext.compose(u.contiguous(), v.contiguous(), ds, dt)
+
+    @staticmethod
+    def backward(ctx, gradout):
+        u, v = ctx.saved_tensors
+        gi = (ctx.dt * gradout).contiguous()  # gradient reaching the interp output
+        d_v, d_u = lagomorph_ext.interp_backward(gi, v.contiguous(), u.contiguous(), ctx.ds,
+                                                 ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        if ctx.needs_input_grad[0]:
+            d_u = ctx.ds * gradout + d_u
+        return d_u, d_v, None, None
+
+
 def compose(u, v, ds=1.0, dt=1.0):
     """ds*u(x) + dt*v(x + ds*u(x))   (deform.py:53-55)"""
+    if u.shape == v.shape and u.size(1) == u.dim() - 2 and u.dtype == v.dtype:
+        return ComposeFunction.apply(u, v, ds, dt)
     return ds * u + dt * interp(v, u, dt=ds)
 
 

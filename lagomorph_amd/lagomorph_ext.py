@@ -51,6 +51,8 @@ _SIGS = {
     "lago_regrid_forward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _vp],
+    "lago_fluid_metric": [_vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64, _i64,
+                          _i64, _vp],
 }
 _fn = {}
 for _name, _args in _SIGS.items():
@@ -291,6 +293,35 @@ def fluid_operator(Fmv, inverse, cosluts, sinluts, alpha, beta, gamma):
     return None
 
 
+def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma):
+    """Whole FluidMetricOperator.forward (metric.py:11-19) in one call: irfft(L^(+-2) rfft(mv)).
+    Not part of the reference's extension surface.  Returns a new tensor; mv is not modified."""
+    _check_input(mv, "mv")
+    dim, nx, ny, nz = _spatial(mv)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional fluid metric is supported")
+    if mv.size(1) != dim:
+        raise RuntimeError("Vector field has incorrect shape for dimension")
+    if len(cosluts) != dim or len(sinluts) != dim:
+        raise RuntimeError(f"Must provide same number of LUTs as spatial dimension '{dim}'")
+    csh = list(mv.shape[2:])
+    csh[-1] = csh[-1] // 2 + 1
+    luts = []
+    for d in range(dim):
+        for t in (cosluts[d], sinluts[d]):
+            if t.dtype != mv.dtype:
+                raise RuntimeError("Type of LUTs must equal that of image")
+            if not t.is_cuda or t.device != mv.device or t.numel() != csh[d]:
+                raise RuntimeError("fluid_metric: LUT on wrong device or of wrong length")
+            luts.append(t.contiguous())
+    out = torch.empty_like(mv)
+    work = torch.empty((mv.size(0), dim, *csh, 2), dtype=mv.dtype, device=mv.device)
+    p = [_ptr(t) for t in luts] + [None] * (6 - 2 * dim)
+    _call("lago_fluid_metric", mv, _ptr(out), _ptr(mv), _ptr(work), int(bool(inverse)), *p, float(alpha), float(beta),
+          float(gamma), dim, mv.size(0), nx, ny, nz)
+    return out
+
+
 def affine_interp_forward(I, A, T):
     """extension.cpp:109-118 -> cuda/affine.cu:114-169.  The reference falls back to
     cpu/affine.cpp for CPU tensors; this build is HIP-only and raises instead."""
@@ -339,6 +370,22 @@ def affine_interp_backward(grad_out, I, A, T, need_I, need_A, need_T):
     _call("lago_affine_interp_backward", I, _ptr(d_I), _ptr(d_A), _ptr(d_T), _ptr(grad_out), _ptr(I), _ptr(A), _ptr(T),
           dim, nn, I.size(1), nx, ny, nz, int(bc), int(bool(need_I)), int(bool(need_A)), int(bool(need_T)))
     return [d_I, d_A, d_T]
+
+
+def compose(u, v, ds=1.0, dt=1.0):
+    """Fused deform.compose (deform.py:53-55): ds*u + dt*interp(v, u, dt=ds) in one kernel.
+    Not part of the reference's extension surface; u and v are (N, d, *spatial) vector fields."""
+    _check_input(u, "u")
+    _check_input(v, "v")
+    _same(u, v)
+    dim, nx, ny, nz = _spatial(u)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional interpolation is supported")
+    if u.shape != v.shape or u.size(1) != dim:
+        raise RuntimeError("compose: u and v must be vector fields of the same shape")
+    out = torch.empty_like(u)
+    _call("lago_compose", u, _ptr(out), _ptr(u), _ptr(v), float(ds), float(dt), dim, u.size(0), nx, ny, nz)
+    return out
 
 
 def _vec3(x, dim, what):

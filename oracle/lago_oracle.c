@@ -12,27 +12,50 @@
  * bit-exact agreement of oracle_affine_interp_forward_cpuref_* with
  * oracle/_ref (the reference's cpu/affine.cpp compiled where it lies).
  *
- * Build: make -C oracle   (gcc -O2 -ffp-contract=off; strict IEEE evaluation)
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -mfma: only the explicit LG_FMA sites fuse)
  */
 #include <math.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
+/* Contraction switch, see lago_oracle_impl.h. */
+#ifdef LAGO_ORACLE_STRICT
+#define LG_FMAD(a, b, c) ((a) * (b) + (c))
+#else
+#define LG_FMAD(a, b, c) fma((a), (b), (c))
+#endif
+
 #define REAL float
 #define SUF _f32
 #define LG_SQRT sqrtf
+#ifdef LAGO_ORACLE_STRICT
+#define LG_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define LG_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
 #include "lago_oracle_impl.h"
 #undef REAL
 #undef SUF
 #undef LG_SQRT
+#undef LG_FMA
 
 #define REAL double
 #define SUF _f64
 #define LG_SQRT sqrt
+#ifdef LAGO_ORACLE_STRICT
+#define LG_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define LG_FMA(a, b, c) fma((a), (b), (c))
+#endif
 #include "lago_oracle_impl.h"
 #undef REAL
 #undef SUF
 #undef LG_SQRT
+#undef LG_FMA
 
-const char *oracle_version(void) { return "lago-oracle 1 (scalar C, strict IEEE, 1 thread)"; }
+#ifdef LAGO_ORACLE_STRICT
+const char *oracle_version(void) { return "lago-oracle 2 (scalar C, 1 thread, unfused a*b+c)"; }
+#else
+const char *oracle_version(void) { return "lago-oracle 2 (scalar C, 1 thread, documented FMA contraction)"; }
+#endif

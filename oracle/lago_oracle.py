@@ -16,8 +16,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liblago_oracle.so")
-_lib = None
+_LIB_PATHS = {
+    False: os.path.join(_HERE, "_build", "liblago_oracle.so"),        # documented FMA contraction (matches HIP)
+    True: os.path.join(_HERE, "_build", "liblago_oracle_strict.so"),  # unfused a*b+c (matches oracle/_ref)
+}
+_libs = {}
+_strict = False
 
 c_long = ctypes.c_long
 c_int = ctypes.c_int
@@ -25,16 +29,21 @@ c_double = ctypes.c_double
 c_void_p = ctypes.c_void_p
 
 
+def set_strict(flag):
+    """Select the unfused build (True) or the FMA-contracted build (False, default)."""
+    global _strict
+    _strict = bool(flag)
+
+
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise RuntimeError(
-                f"oracle library missing: {_LIB_PATH}; run `make -C oracle` or __graft_entry__.build()"
-            )
-        _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.oracle_version.restype = ctypes.c_char_p
-    return _lib
+    if _strict not in _libs:
+        path = _LIB_PATHS[_strict]
+        if not os.path.exists(path):
+            raise RuntimeError(f"oracle library missing: {path}; run `make -C oracle` or __graft_entry__.build()")
+        L = ctypes.CDLL(path)
+        L.oracle_version.restype = ctypes.c_char_p
+        _libs[_strict] = L
+    return _libs[_strict]
 
 
 def _suf(dtype):
@@ -282,6 +291,12 @@ class OracleExt:
 
     def interp_forward(self, I, u, dt=1.0):
         return self._w(interp_forward(self._n(I), self._n(u), dt), I)
+
+    def compose(self, u, v, ds=1.0, dt=1.0):
+        # deform.py:53-55 with torch's rounding: scalars rounded to the tensor dtype, three roundings
+        un, vn = self._n(u), self._n(v)
+        k = un.dtype.type
+        return self._w(k(ds) * un + k(dt) * interp_forward(vn, un, ds), u)
 
     def interp_backward(self, go, I, u, dt, need_I, need_u):
         a, b = interp_backward(self._n(go), self._n(I), self._n(u), dt, need_I, need_u)

@@ -11,6 +11,15 @@
  * /root/reference/lagomorph/extension/) whose arithmetic it follows.  Loop
  * *order* over voxels is free (the reference is a parallel kernel); the order
  * of floating point operations inside one voxel is the reference's.
+ *
+ * Contraction: every `a*b + c` of the reference is written LG_FMA(a, b, c), and a
+ * sum of two products `a*b + c*d` as LG_FMA(a, b, c*d) (left product fused), the
+ * pattern nvcc's default -fmad=true / LLVM's contraction produces.  lago_oracle.c
+ * is built twice: with LG_FMA = fused multiply-add (liblago_oracle.so, bit-
+ * comparable with the HIP kernels, which use the identical pattern) and with
+ * LG_FMA(a,b,c) = a*b + c, strictly unfused (liblago_oracle_strict.so, bit-
+ * comparable with oracle/_ref, the reference's CPU source built with
+ * -ffp-contract=off).
  */
 
 #define LG_CAT_(a, b) a##b
@@ -66,7 +75,7 @@ static REAL FN(lg_bilerp)(const REAL *img, REAL x, REAL y, long sx, long sy) {
     REAL v1 = img[(size_t)cx * sy + fy];
     REAL v2 = img[(size_t)cx * sy + cy];
     REAL v3 = img[(size_t)fx * sy + cy];
-    return omt * (omu * v0 + u * v3) + t * (omu * v1 + u * v2);
+    return LG_FMA(omt, LG_FMA(omu, v0, u * v3), t * LG_FMA(omu, v1, u * v2));
 }
 
 /* include/interp.h:60-123 triLerp */
@@ -86,8 +95,8 @@ static REAL FN(lg_trilerp)(const REAL *img, REAL x, REAL y, REAL z, long sx, lon
     REAL v0 = LG_AT(fx, fy, fz), v1 = LG_AT(cx, fy, fz), v2 = LG_AT(cx, cy, fz), v3 = LG_AT(fx, cy, fz);
     REAL v4 = LG_AT(fx, fy, cz), v5 = LG_AT(cx, fy, cz), v6 = LG_AT(cx, cy, cz), v7 = LG_AT(fx, cy, cz);
 #undef LG_AT
-    return omv * (omu * (omt * v0 + t * v1) + u * (omt * v3 + t * v2)) +
-           v * (omu * (omt * v4 + t * v5) + u * (omt * v7 + t * v6));
+    return LG_FMA(omv, LG_FMA(omu, LG_FMA(omt, v0, t * v1), u * LG_FMA(omt, v3, t * v2)),
+                  v * LG_FMA(omu, LG_FMA(omt, v4, t * v5), u * LG_FMA(omt, v7, t * v6)));
 }
 
 /* include/interp.h:128-204 biLerp_grad (clamp => always "inside") */
@@ -102,8 +111,8 @@ static void FN(lg_bilerp_grad)(REAL *gx, REAL *gy, const REAL *img, REAL x, REAL
     REAL v1 = img[(size_t)cx * sy + fy];
     REAL v2 = img[(size_t)cx * sy + cy];
     REAL v3 = img[(size_t)fx * sy + cy];
-    *gx = v1 - v0 + u * (v2 - v3 - v1 + v0);
-    *gy = v3 - v0 + t * (v2 - v1 - v3 + v0);
+    *gx = LG_FMA(u, v2 - v3 - v1 + v0, v1 - v0);
+    *gy = LG_FMA(t, v2 - v1 - v3 + v0, v3 - v0);
 }
 
 /* include/interp.h:206-327 triLerp_grad */
@@ -124,9 +133,9 @@ static void FN(lg_trilerp_grad)(REAL *gx, REAL *gy, REAL *gz, const REAL *img, R
     REAL v0 = LG_AT(fx, fy, fz), v1 = LG_AT(cx, fy, fz), v2 = LG_AT(cx, cy, fz), v3 = LG_AT(fx, cy, fz);
     REAL v4 = LG_AT(fx, fy, cz), v5 = LG_AT(cx, fy, cz), v6 = LG_AT(cx, cy, cz), v7 = LG_AT(fx, cy, cz);
 #undef LG_AT
-    *gx = omv * (omu * (v1 - v0) + u * (v2 - v3)) + v * (omu * (v5 - v4) + u * (v6 - v7));
-    *gy = omv * (omt * (v3 - v0) + t * (v2 - v1)) + v * (omt * (v7 - v4) + t * (v6 - v5));
-    *gz = omu * (omt * (v4 - v0) + t * (v5 - v1)) + u * (omt * (v7 - v3) + t * (v6 - v2));
+    *gx = LG_FMA(omv, LG_FMA(omu, v1 - v0, u * (v2 - v3)), v * LG_FMA(omu, v5 - v4, u * (v6 - v7)));
+    *gy = LG_FMA(omv, LG_FMA(omt, v3 - v0, t * (v2 - v1)), v * LG_FMA(omt, v7 - v4, t * (v6 - v5)));
+    *gz = LG_FMA(omu, LG_FMA(omt, v4 - v0, t * (v5 - v1)), u * LG_FMA(omt, v7 - v3, t * (v6 - v2)));
 }
 
 /* ---- splat ---------------------------------------------------------------- */
@@ -188,15 +197,15 @@ int FN(oracle_interp_forward)(REAL *out, const REAL *I, const REAL *u, double dt
                 for (long j = 0; j < ny; ++j) {
                     if (dim == 2) {
                         size_t ix = (size_t)i * ny + j;
-                        double hx = (double)(REAL)i + dt * (double)un[ix];
-                        double hy = (double)(REAL)j + dt * (double)un[ix + nvox];
+                        double hx = LG_FMAD(dt, (double)un[ix], (double)(REAL)i);
+                        double hy = LG_FMAD(dt, (double)un[ix + nvox], (double)(REAL)j);
                         oc[ix] = FN(lg_bilerp)(Ic, (REAL)hx, (REAL)hy, nx, ny);
                     } else {
                         for (long k = 0; k < nz; ++k) {
                             size_t ix = ((size_t)i * ny + j) * nz + k;
-                            double hx = (double)(REAL)i + dt * (double)un[ix];
-                            double hy = (double)(REAL)j + dt * (double)un[ix + nvox];
-                            double hz = (double)(REAL)k + dt * (double)un[ix + 2 * nvox];
+                            double hx = LG_FMAD(dt, (double)un[ix], (double)(REAL)i);
+                            double hy = LG_FMAD(dt, (double)un[ix + nvox], (double)(REAL)j);
+                            double hz = LG_FMAD(dt, (double)un[ix + 2 * nvox], (double)(REAL)k);
                             oc[ix] = FN(lg_trilerp)(Ic, (REAL)hx, (REAL)hy, (REAL)hz, nx, ny, nz);
                         }
                     }
@@ -231,10 +240,10 @@ int FN(oracle_interp_backward)(REAL *d_I, REAL *d_u, const REAL *go, const REAL 
                 for (long j = 0; j < ny; ++j)
                     for (long k = 0; k < nz; ++k) {
                         size_t ix = ((size_t)i * ny + j) * nz + k;
-                        REAL hx = (REAL)((double)i + dt * (double)un[ix]);
-                        REAL hy = (REAL)((double)j + dt * (double)un[ix + nvox]);
+                        REAL hx = (REAL)LG_FMAD(dt, (double)un[ix], (double)i);
+                        REAL hy = (REAL)LG_FMAD(dt, (double)un[ix + nvox], (double)j);
                         REAL hz = 0;
-                        if (dim == 3) hz = (REAL)((double)k + dt * (double)un[ix + 2 * nvox]);
+                        if (dim == 3) hz = (REAL)LG_FMAD(dt, (double)un[ix + 2 * nvox], (double)k);
                         REAL diff = gc[ix];
                         if (need_I) {
                             if (dim == 2)
@@ -247,14 +256,14 @@ int FN(oracle_interp_backward)(REAL *d_I, REAL *d_u, const REAL *go, const REAL 
                             if (dim == 2) {
                                 FN(lg_bilerp_grad)(&gx, &gy, Ic, hx, hy, nx, ny);
                                 diff = (REAL)((double)diff * dt);
-                                dun[ix] = dun[ix] + gx * diff;
-                                dun[ix + nvox] = dun[ix + nvox] + gy * diff;
+                                dun[ix] = LG_FMA(gx, diff, dun[ix]);
+                                dun[ix + nvox] = LG_FMA(gy, diff, dun[ix + nvox]);
                             } else {
                                 FN(lg_trilerp_grad)(&gx, &gy, &gz, Ic, hx, hy, hz, nx, ny, nz);
                                 diff = (REAL)((double)diff * dt);
-                                dun[ix] = dun[ix] + gx * diff;
-                                dun[ix + nvox] = dun[ix + nvox] + gy * diff;
-                                dun[ix + 2 * nvox] = dun[ix + 2 * nvox] + gz * diff;
+                                dun[ix] = LG_FMA(gx, diff, dun[ix]);
+                                dun[ix + nvox] = LG_FMA(gy, diff, dun[ix + nvox]);
+                                dun[ix + 2 * nvox] = LG_FMA(gz, diff, dun[ix + 2 * nvox]);
                             }
                         }
                     }
@@ -275,8 +284,8 @@ int FN(oracle_interp_hessian_diagonal_image)(REAL *out, const REAL *u, double dt
         for (long i = 0; i < nx; ++i)
             for (long j = 0; j < ny; ++j) {
                 size_t ix = (size_t)i * ny + j;
-                REAL x = (REAL)((double)(REAL)i + dt * (double)un[ix]);
-                REAL y = (REAL)((double)(REAL)j + dt * (double)un[ix + nxy]);
+                REAL x = (REAL)LG_FMAD(dt, (double)un[ix], (double)(REAL)i);
+                REAL y = (REAL)LG_FMAD(dt, (double)un[ix + nxy], (double)(REAL)j);
                 int fx = FN(lg_floor)(x), fy = FN(lg_floor)(y);
                 int cx = fx + 1, cy = fy + 1;
                 REAL t = x - (REAL)fx, uu = y - (REAL)fy;
@@ -343,18 +352,16 @@ int FN(oracle_jtv_forward)(REAL *out, const REAL *v, const REAL *w, int displace
                                 if (c == 0)
                                     on[ix + (size_t)d * nvox] = g[d] * wc;
                                 else
-                                    on[ix + (size_t)d * nvox] += g[d] * wc;
+                                    on[ix + (size_t)d * nvox] = LG_FMA(g[d], wc, on[ix + (size_t)d * nvox]);
                             }
                         }
                     } else {
                         for (long c = 0; c < nc; ++c) {
                             FN(lg_grad_point)(g, vn + (size_t)c * nvox, dim, nx, ny, nz, i, j, k);
                             if (displacement && c < dim) g[c] = g[c] + (REAL)1.0;
-                            if (dim == 2)
-                                on[ix + (size_t)c * nvox] = g[0] * wn[ix] + g[1] * wn[ix + nvox];
-                            else
-                                on[ix + (size_t)c * nvox] =
-                                    g[0] * wn[ix] + g[1] * wn[ix + nvox] + g[2] * wn[ix + 2 * nvox];
+                            REAL s = LG_FMA(g[0], wn[ix], g[1] * wn[ix + nvox]);
+                            if (dim == 3) s = LG_FMA(g[2], wn[ix + 2 * nvox], s);
+                            on[ix + (size_t)c * nvox] = s;
                         }
                     }
                 }
@@ -369,13 +376,13 @@ int FN(oracle_jtv_forward)(REAL *out, const REAL *v, const REAL *w, int displace
  * the linear indices of the centre voxel inside a and b. */
 static inline REAL FN(lg_dT_term)(const REAL *a, size_t ia, const REAL *b, size_t ib, size_t s, long pos,
                                   long len) {
-    if (pos == 0) return (REAL)(-.5) * (a[ia] * b[ib] + a[ia + s] * b[ib + s]);
-    if (pos == len - 1) return (REAL)(.5) * (a[ia] * b[ib] + a[ia - s] * b[ib - s]);
-    return (REAL)(-.5) * (a[ia + s] * b[ib + s] - a[ia - s] * b[ib - s]);
+    if (pos == 0) return (REAL)(-.5) * LG_FMA(a[ia], b[ib], a[ia + s] * b[ib + s]);
+    if (pos == len - 1) return (REAL)(.5) * LG_FMA(a[ia], b[ib], a[ia - s] * b[ib - s]);
+    return (REAL)(-.5) * LG_FMA(a[ia + s], b[ib + s], -(a[ia - s] * b[ib - s]));
 }
 /* cuda/diff.cu:345-356 and :597-600 write the i==0 / j==0 / k==0 case of the 3D
- * kernels with the +stride product first; floating point addition commutes, so
- * the two-term sum is bit-identical either way. */
+ * kernels with the +stride product first; here the centre product is the fused
+ * one in every case (which product nvcc fuses is its choice). */
 
 /* cuda/diff.cu:187-473 (kernels), :475-540 (host; need_v/need_w forced true). */
 int FN(oracle_jtv_backward)(REAL *d_v, REAL *d_w, const REAL *go, const REAL *v, const REAL *w, int displacement,
@@ -405,8 +412,8 @@ int FN(oracle_jtv_backward)(REAL *d_v, REAL *d_w, const REAL *go, const REAL *v,
                         for (int c = 0; c < dim; ++c) {
                             FN(lg_grad_point)(g, vn + (size_t)c * nvox, dim, nx, ny, nz, i, j, k);
                             if (displacement) g[c] = g[c] + (REAL)1.0;
-                            REAL s = g[0] * gon[ix] + g[1] * gon[ix + nvox];
-                            if (dim == 3) s = s + g[2] * gon[ix + 2 * nvox];
+                            REAL s = LG_FMA(g[0], gon[ix], g[1] * gon[ix + nvox]);
+                            if (dim == 3) s = LG_FMA(g[2], gon[ix + 2 * nvox], s);
                             dwn[ix + (size_t)c * nvox] += s;
                         }
                         for (int d = 0; d < dim; ++d)     /* axis, in reference order x,y,z */
@@ -419,7 +426,7 @@ int FN(oracle_jtv_backward)(REAL *d_v, REAL *d_w, const REAL *go, const REAL *v,
                             FN(lg_grad_point)(g, vn + (size_t)c * nvox, dim, nx, ny, nz, i, j, k);
                             if (displacement && c < dim) g[c] = g[c] + (REAL)1.0;
                             REAL goc = gon[ix + (size_t)c * nvox];
-                            for (int d = 0; d < dim; ++d) dwn[ix + (size_t)d * nvox] += g[d] * goc;
+                            for (int d = 0; d < dim; ++d) dwn[ix + (size_t)d * nvox] = LG_FMA(g[d], goc, dwn[ix + (size_t)d * nvox]);
                             for (int d = 0; d < dim; ++d)
                                 dvn[ix + (size_t)c * nvox] +=
                                     FN(lg_dT_term)(wn + (size_t)d * nvox, ix, gon + (size_t)c * nvox, ix,
@@ -486,10 +493,10 @@ int FN(oracle_jtv_adjoint_backward)(REAL *d_v, REAL *d_w, const REAL *go, const 
                             if (c == 0)
                                 dwn[ix + (size_t)d * nvox] = g[d] * vc;
                             else
-                                dwn[ix + (size_t)d * nvox] += g[d] * vc;
+                                dwn[ix + (size_t)d * nvox] = LG_FMA(g[d], vc, dwn[ix + (size_t)d * nvox]);
                         }
-                        REAL s = g[0] * wn[ix] + g[1] * wn[ix + nvox];
-                        if (dim == 3) s = s + g[2] * wn[ix + 2 * nvox];
+                        REAL s = LG_FMA(g[0], wn[ix], g[1] * wn[ix + nvox]);
+                        if (dim == 3) s = LG_FMA(g[2], wn[ix + 2 * nvox], s);
                         dvn[ix + (size_t)c * nvox] += s;
                     }
                 }
@@ -518,18 +525,18 @@ int FN(oracle_fluid_operator)(REAL *Fm, int inverse, const REAL *cosX, const REA
         for (long i = 0; i < nx; ++i)
             for (long j = 0; j < ny; ++j) {
                 const REAL wx = cosX[i], wy = cosY[j];
-                const REAL lambda = (REAL)(gamma + alpha * (double)(wx + wy));
-                REAL l00 = (REAL)((double)lambda - beta * (double)wx);
-                REAL l11 = (REAL)((double)lambda - beta * (double)wy);
+                const REAL lambda = (REAL)LG_FMAD(alpha, (double)(wx + wy), gamma);
+                REAL l00 = (REAL)LG_FMAD(-beta, (double)wx, (double)lambda);
+                REAL l11 = (REAL)LG_FMAD(-beta, (double)wy, (double)lambda);
                 REAL l10 = (REAL)(beta * (double)sinX[i] * (double)sinY[j]);
-                REAL L00 = l00 * l00 + l10 * l10;
-                REAL L10 = l00 * l10 + l10 * l11;
-                REAL L11 = l11 * l11 + l10 * l10;
+                REAL L00 = LG_FMA(l00, l00, l10 * l10);
+                REAL L10 = LG_FMA(l00, l10, l10 * l11);
+                REAL L11 = LG_FMA(l11, l11, l10 * l10);
                 REAL ooG00 = 0, G10 = 0, ooG11 = 0;
                 if (inverse) { /* metric.cu:20-45 */
                     ooG00 = (REAL)(1. / (double)FN(lg_safe_sqrt)(L00));
                     G10 = L10 * ooG00;
-                    ooG11 = L11 - G10 * G10;
+                    ooG11 = LG_FMA(-G10, G10, L11);
                     ooG11 = (REAL)(1. / (double)FN(lg_safe_sqrt)(ooG11));
                 }
                 size_t ix = 2 * ((size_t)j + (size_t)i * ny);
@@ -539,12 +546,12 @@ int FN(oracle_fluid_operator)(REAL *Fm, int inverse, const REAL *cosX, const REA
                         REAL bX = Fm[ix + ri], bY = Fm[iy + ri];
                         if (inverse) { /* metric.cu:80-101 */
                             REAL y0 = bX * ooG00;
-                            REAL y1 = (bY - G10 * y0) * ooG11;
+                            REAL y1 = LG_FMA(-G10, y0, bY) * ooG11;
                             bY = y1 * ooG11;
-                            bX = (y0 - G10 * bY) * ooG00;
+                            bX = LG_FMA(-G10, bY, y0) * ooG00;
                         } else { /* metric.cu:132-143 */
-                            REAL x = L00 * bX + L10 * bY;
-                            bY = L10 * bX + L11 * bY;
+                            REAL x = LG_FMA(L00, bX, L10 * bY);
+                            bY = LG_FMA(L10, bX, L11 * bY);
                             bX = x;
                         }
                         Fm[ix + ri] = bX;
@@ -559,28 +566,28 @@ int FN(oracle_fluid_operator)(REAL *Fm, int inverse, const REAL *cosX, const REA
         for (long j = 0; j < ny; ++j)
             for (long k = 0; k < nz; ++k) {
                 const REAL wx = cosX[i], wy = cosY[j], wz = cosZ[k];
-                const REAL lambda = (REAL)(gamma + alpha * (double)(wx + wy + wz));
-                REAL l00 = (REAL)((double)lambda - beta * (double)wx);
-                REAL l11 = (REAL)((double)lambda - beta * (double)wy);
-                REAL l22 = (REAL)((double)lambda - beta * (double)wz);
+                const REAL lambda = (REAL)LG_FMAD(alpha, (double)(wx + wy + wz), gamma);
+                REAL l00 = (REAL)LG_FMAD(-beta, (double)wx, (double)lambda);
+                REAL l11 = (REAL)LG_FMAD(-beta, (double)wy, (double)lambda);
+                REAL l22 = (REAL)LG_FMAD(-beta, (double)wz, (double)lambda);
                 REAL l10 = (REAL)(beta * (double)sinX[i] * (double)sinY[j]);
                 REAL l20 = (REAL)(beta * (double)sinX[i] * (double)sinZ[k]);
                 REAL l21 = (REAL)(beta * (double)sinY[j] * (double)sinZ[k]);
-                REAL L00 = l00 * l00 + l10 * l10 + l20 * l20;
-                REAL L10 = l00 * l10 + l10 * l11 + l20 * l21;
-                REAL L11 = l10 * l10 + l11 * l11 + l21 * l21;
-                REAL L20 = l00 * l20 + l10 * l21 + l20 * l22;
-                REAL L21 = l10 * l20 + l11 * l21 + l21 * l22;
-                REAL L22 = l20 * l20 + l21 * l21 + l22 * l22;
+                REAL L00 = LG_FMA(l20, l20, LG_FMA(l00, l00, l10 * l10));
+                REAL L10 = LG_FMA(l20, l21, LG_FMA(l00, l10, l10 * l11));
+                REAL L11 = LG_FMA(l21, l21, LG_FMA(l10, l10, l11 * l11));
+                REAL L20 = LG_FMA(l20, l22, LG_FMA(l00, l20, l10 * l21));
+                REAL L21 = LG_FMA(l21, l22, LG_FMA(l10, l20, l11 * l21));
+                REAL L22 = LG_FMA(l22, l22, LG_FMA(l20, l20, l21 * l21));
                 REAL ooG00 = 0, G10 = 0, ooG11 = 0, G20 = 0, G21 = 0, ooG22 = 0;
                 if (inverse) { /* metric.cu:47-78 */
                     ooG00 = (REAL)(1. / (double)FN(lg_safe_sqrt)(L00));
                     G10 = L10 * ooG00;
                     G20 = L20 * ooG00;
-                    ooG11 = L11 - G10 * G10;
+                    ooG11 = LG_FMA(-G10, G10, L11);
                     ooG11 = (REAL)(1. / (double)FN(lg_safe_sqrt)(ooG11));
-                    G21 = (L21 - G20 * G10) * ooG11;
-                    ooG22 = L22 - G20 * G20 - G21 * G21;
+                    G21 = LG_FMA(-G20, G10, L21) * ooG11;
+                    ooG22 = LG_FMA(-G21, G21, LG_FMA(-G20, G20, L22));
                     ooG22 = (REAL)(1. / (double)FN(lg_safe_sqrt)(ooG22));
                 }
                 size_t ix = 2 * ((size_t)j + (size_t)i * ny) * nz + 2 * (size_t)k;
@@ -590,15 +597,15 @@ int FN(oracle_fluid_operator)(REAL *Fm, int inverse, const REAL *cosX, const REA
                         REAL bX = Fm[ix + ri], bY = Fm[iy + ri], bZ = Fm[iz + ri];
                         if (inverse) { /* metric.cu:103-130 */
                             REAL y0 = bX * ooG00;
-                            REAL y1 = (bY - G10 * y0) * ooG11;
-                            REAL y2 = (bZ - G20 * y0 - G21 * y1) * ooG22;
+                            REAL y1 = LG_FMA(-G10, y0, bY) * ooG11;
+                            REAL y2 = LG_FMA(-G21, y1, LG_FMA(-G20, y0, bZ)) * ooG22;
                             bZ = y2 * ooG22;
-                            bY = (y1 - G21 * bZ) * ooG11;
-                            bX = (y0 - G10 * bY - G20 * bZ) * ooG00;
+                            bY = LG_FMA(-G21, bZ, y1) * ooG11;
+                            bX = LG_FMA(-G20, bZ, LG_FMA(-G10, bY, y0)) * ooG00;
                         } else { /* metric.cu:145-160 */
-                            REAL x = L00 * bX + L10 * bY + L20 * bZ;
-                            REAL y = L10 * bX + L11 * bY + L21 * bZ;
-                            bZ = L20 * bX + L21 * bY + L22 * bZ;
+                            REAL x = LG_FMA(L20, bZ, LG_FMA(L00, bX, L10 * bY));
+                            REAL y = LG_FMA(L21, bZ, LG_FMA(L10, bX, L11 * bY));
+                            bZ = LG_FMA(L22, bZ, LG_FMA(L20, bX, L21 * bY));
                             bX = x;
                             bY = y;
                         }
@@ -636,15 +643,15 @@ int FN(oracle_affine_interp_forward)(REAL *out, const REAL *I, const REAL *A, co
                 for (long j = 0; j < ny; ++j) {
                     REAL fj = (REAL)j - oy;
                     if (dim == 2) {
-                        REAL hx = An[0] * fi + An[1] * fj + Tn[0] + ox;
-                        REAL hy = An[2] * fi + An[3] * fj + Tn[1] + oy;
+                        REAL hx = LG_FMA(An[0], fi, An[1] * fj) + Tn[0] + ox;
+                        REAL hy = LG_FMA(An[2], fi, An[3] * fj) + Tn[1] + oy;
                         oc[(size_t)i * ny + j] = FN(lg_bilerp)(Ic, hx, hy, nx, ny);
                     } else {
                         for (long k = 0; k < nz; ++k) {
                             REAL fk = (REAL)k - oz;
-                            REAL hx = An[0] * fi + An[1] * fj + An[2] * fk + Tn[0] + ox;
-                            REAL hy = An[3] * fi + An[4] * fj + An[5] * fk + Tn[1] + oy;
-                            REAL hz = An[6] * fi + An[7] * fj + An[8] * fk + Tn[2] + oz;
+                            REAL hx = LG_FMA(An[2], fk, LG_FMA(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+                            REAL hy = LG_FMA(An[5], fk, LG_FMA(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+                            REAL hz = LG_FMA(An[8], fk, LG_FMA(An[6], fi, An[7] * fj)) + Tn[2] + oz;
                             oc[((size_t)i * ny + j) * nz + k] = FN(lg_trilerp)(Ic, hx, hy, hz, nx, ny, nz);
                         }
                     }
@@ -678,17 +685,17 @@ int FN(oracle_affine_interp_forward_cpuref)(REAL *out, const REAL *I, const REAL
                 REAL fi = (REAL)i - ox;
                 if (dim == 2) {
                     size_t ix = (size_t)i * ny;
-                    REAL hx = An[0] * fi - An[1] * oy + Tn[0] + ox;
-                    REAL hy = An[2] * fi - An[3] * oy + Tn[1] + oy;
+                    REAL hx = LG_FMA(An[0], fi, -(An[1] * oy)) + Tn[0] + ox;
+                    REAL hy = LG_FMA(An[2], fi, -(An[3] * oy)) + Tn[1] + oy;
                     for (long j = 0; j < ny; ++j, ++ix, hx += An[1], hy += An[3])
                         outn[ix] = FN(lg_bilerp)(In, hx, hy, nx, ny);
                 } else {
                     for (long j = 0; j < ny; ++j) {
                         size_t ix = ((size_t)i * ny + j) * nz;
                         REAL fj = (REAL)j - oy;
-                        REAL hx = An[0] * fi + An[1] * fj - An[2] * oz + Tn[0] + ox;
-                        REAL hy = An[3] * fi + An[4] * fj - An[5] * oz + Tn[1] + oy;
-                        REAL hz = An[6] * fi + An[7] * fj - An[8] * oz + Tn[2] + oz;
+                        REAL hx = LG_FMA(-An[2], oz, LG_FMA(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+                        REAL hy = LG_FMA(-An[5], oz, LG_FMA(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+                        REAL hz = LG_FMA(-An[8], oz, LG_FMA(An[6], fi, An[7] * fj)) + Tn[2] + oz;
                         for (long k = 0; k < nz; ++k, ++ix, hx += An[2], hy += An[5], hz += An[8])
                             outn[ix] = FN(lg_trilerp)(In, hx, hy, hz, nx, ny, nz);
                     }
@@ -742,16 +749,16 @@ int FN(oracle_affine_interp_backward)(REAL *d_I, REAL *d_A, REAL *d_T, const REA
                                 REAL diff = gon[ix];
                                 REAL gx, gy, gz = 0, fk = 0;
                                 if (dim == 2) {
-                                    REAL hx = An[0] * fi + An[1] * fj + Tn[0] + ox;
-                                    REAL hy = An[2] * fi + An[3] * fj + Tn[1] + oy;
+                                    REAL hx = LG_FMA(An[0], fi, An[1] * fj) + Tn[0] + ox;
+                                    REAL hy = LG_FMA(An[2], fi, An[3] * fj) + Tn[1] + oy;
                                     if (need_I) FN(lg_splat2)(dIn, diff, hx, hy, nx, ny);
                                     if (!(need_A || need_T)) continue;
                                     FN(lg_bilerp_grad)(&gx, &gy, In, hx, hy, nx, ny);
                                 } else {
                                     fk = (REAL)k - oz;
-                                    REAL hx = An[0] * fi + An[1] * fj + An[2] * fk + Tn[0] + ox;
-                                    REAL hy = An[3] * fi + An[4] * fj + An[5] * fk + Tn[1] + oy;
-                                    REAL hz = An[6] * fi + An[7] * fj + An[8] * fk + Tn[2] + oz;
+                                    REAL hx = LG_FMA(An[2], fk, LG_FMA(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+                                    REAL hy = LG_FMA(An[5], fk, LG_FMA(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+                                    REAL hz = LG_FMA(An[8], fk, LG_FMA(An[6], fi, An[7] * fj)) + Tn[2] + oz;
                                     if (need_I) FN(lg_splat3)(dIn, diff, hx, hy, hz, nx, ny, nz);
                                     if (!(need_A || need_T)) continue;
                                     FN(lg_trilerp_grad)(&gx, &gy, &gz, In, hx, hy, hz, nx, ny, nz);
@@ -761,15 +768,15 @@ int FN(oracle_affine_interp_backward)(REAL *d_I, REAL *d_A, REAL *d_T, const REA
                                 gz *= diff;
                                 if (dim == 2) {
                                     if (need_A) {
-                                        p[0] += gx * fi; p[1] += gx * fj;
-                                        p[2] += gy * fi; p[3] += gy * fj;
+                                        p[0] = LG_FMA(gx, fi, p[0]); p[1] = LG_FMA(gx, fj, p[1]);
+                                        p[2] = LG_FMA(gy, fi, p[2]); p[3] = LG_FMA(gy, fj, p[3]);
                                     }
                                     if (need_T) { p[9] += gx; p[10] += gy; }
                                 } else {
                                     if (need_A) {
-                                        p[0] += gx * fi; p[1] += gx * fj; p[2] += gx * fk;
-                                        p[3] += gy * fi; p[4] += gy * fj; p[5] += gy * fk;
-                                        p[6] += gz * fi; p[7] += gz * fj; p[8] += gz * fk;
+                                        p[0] = LG_FMA(gx, fi, p[0]); p[1] = LG_FMA(gx, fj, p[1]); p[2] = LG_FMA(gx, fk, p[2]);
+                                        p[3] = LG_FMA(gy, fi, p[3]); p[4] = LG_FMA(gy, fj, p[4]); p[5] = LG_FMA(gy, fk, p[5]);
+                                        p[6] = LG_FMA(gz, fi, p[6]); p[7] = LG_FMA(gz, fj, p[7]); p[8] = LG_FMA(gz, fk, p[8]);
                                     }
                                     if (need_T) { p[9] += gx; p[10] += gy; p[11] += gz; }
                                 }
@@ -813,12 +820,12 @@ int FN(oracle_regrid_forward)(REAL *out, const REAL *I, int dim, long nn, long n
         REAL *on = out + (size_t)q * Nvox;
         for (long i = 0; i < Nx; ++i)
             for (long j = 0; j < Ny; ++j) {
-                REAL hx = ((REAL)i - ox) * Sx + Ox;
-                REAL hy = ((REAL)j - oy) * Sy + Oy;
+                REAL hx = LG_FMA((REAL)i - ox, Sx, Ox);
+                REAL hy = LG_FMA((REAL)j - oy, Sy, Oy);
                 if (dim == 2) {
                     on[(size_t)i * Ny + j] = FN(lg_bilerp)(In, hx, hy, nx, ny);
                 } else {
-                    REAL hz = Oz - oz * Sz;
+                    REAL hz = LG_FMA(-oz, Sz, Oz);
                     for (long k = 0; k < Nz; ++k) {
                         on[((size_t)i * Ny + j) * Nz + k] = FN(lg_trilerp)(In, hx, hy, hz, nx, ny, nz);
                         hz += Sz;
@@ -847,13 +854,13 @@ int FN(oracle_regrid_backward)(REAL *d_I, const REAL *go, int dim, long nn, long
         const REAL *gon = go + (size_t)q * Nvox;
         for (long i = 0; i < Nx; ++i)
             for (long j = 0; j < Ny; ++j) {
-                REAL hx = ((REAL)i - ox) * Sx + Ox;
-                REAL hy = ((REAL)j - oy) * Sy + Oy;
+                REAL hx = LG_FMA((REAL)i - ox, Sx, Ox);
+                REAL hy = LG_FMA((REAL)j - oy, Sy, Oy);
                 if (dim == 2) {
                     FN(lg_splat2)(dIn, gon[(size_t)i * Ny + j], hx, hy, nx, ny);
                 } else {
                     for (long k = 0; k < Nz; ++k) {
-                        REAL hz = ((REAL)k - oz) * Sz + Oz;
+                        REAL hz = LG_FMA((REAL)k - oz, Sz, Oz);
                         FN(lg_splat3)(dIn, gon[((size_t)i * Ny + j) * Nz + k], hx, hy, hz, nx, ny, nz);
                     }
                 }

@@ -51,10 +51,11 @@ def oracle_ext(monkeypatch):
     ext = OracleExt()
     mod = lagomorph_amd.lagomorph_ext
     for name in (
-        "interp_forward", "interp_backward", "interp_hessian_diagonal_image",
+        "interp_forward", "interp_backward", "interp_hessian_diagonal_image", "compose",
         "jacobian_times_vectorfield_forward", "jacobian_times_vectorfield_backward",
         "jacobian_times_vectorfield_adjoint_forward", "jacobian_times_vectorfield_adjoint_backward",
         "fluid_operator", "affine_interp_forward", "affine_interp_backward", "regrid_forward", "regrid_backward",
     ):
         monkeypatch.setattr(mod, name, getattr(ext, name))
+    monkeypatch.delattr(mod, "fluid_metric")  # the host mirror then takes its rfft / fluid_operator / irfft form
     return ext

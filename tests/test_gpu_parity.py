@@ -307,7 +307,7 @@ def test_empty_and_error_behaviour(ext):
     with pytest.raises(RuntimeError, match="must be contiguous"):
         ext.interp_forward(I, u.transpose(3, 4), 1.0)
     with pytest.raises(RuntimeError, match="Only two- and three-dimensional"):
-        ext.interp_forward(I[:, :, 0, 0], u[:, :, 0, 0], 1.0)
+        ext.interp_forward(I[:, :, 0, 0].contiguous(), u[:, :, 0, 0].contiguous(), 1.0)
     with pytest.raises(RuntimeError, match="thin"):
         ext.jacobian_times_vectorfield_forward(u[:, :, :, :, :1].contiguous(), u[:, :, :, :, :1].contiguous(), True, False)
     with pytest.raises(RuntimeError, match="Displacement mode only defined for vector fields"):
@@ -318,3 +318,46 @@ def test_empty_and_error_behaviour(ext):
         F = torch.zeros((1, 2, 4, 3, 2), device="cuda")
         l = [torch.zeros(4, device="cuda", dtype=torch.float64), torch.zeros(3, device="cuda", dtype=torch.float64)]
         ext.fluid_operator(F, True, l, l, 0.1, 0.0, 0.01)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(5, 6, 7), (8, 8, 8), (3, 4, 1), (7, 9), (2, 2)])
+def test_fused_compose_bit_exact(ext, dtype, sp):
+    """ds*u + dt*interp(v, u, ds) in one kernel == the unfused expression (three roundings kept)."""
+    rng = np.random.default_rng(hash(sp) % 2**31)
+    d = len(sp)
+    u = _disp(rng, 2, sp, dtype)
+    v = rnd(rng, (2, d) + sp, dtype)
+    for ds, dt in ((1.0, 1.0), (-0.1, 1.0), (0.7, -1.3)):
+        k = u.dtype.type
+        want = k(ds) * u + k(dt) * orc.interp_forward(v, u, ds)
+        assert_bits(ext.compose(dev(u), dev(v), ds, dt), want, f"compose ds={ds} dt={dt}")
+        # and equals the torch expression over this library's own interp
+        ud, vd = dev(u), dev(v)
+        assert torch.equal(ext.compose(ud, vd, ds, dt), ds * ud + dt * ext.interp_forward(vd, ud, ds))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(8, 6, 10), (7, 5, 9), (16, 16, 16), (12, 10), (9, 7)])
+@pytest.mark.parametrize("inverse", [True, False])
+def test_fused_fluid_metric_matches_three_call_form(ext, dtype, sp, inverse):
+    """hipFFT-direct sharp/flat vs rfftn(ortho) -> fluid_operator -> irfftn(ortho) and vs the oracle."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import metric as lmm
+
+    rng = np.random.default_rng(hash((sp, inverse)) % 2**31)
+    m = rnd(rng, (3, len(sp)) + sp, dtype)
+    md = dev(m)
+    keep = md.clone()
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    f = met.sharp if inverse else met.flat
+    fused = f(md)
+    assert torch.equal(md, keep), "fluid_metric modified its input"
+    lmm.USE_FUSED_FLUID = False
+    try:
+        plain = f(md)
+    finally:
+        lmm.USE_FUSED_FLUID = True
+    want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
+    assert_close(fused, want, dtype, "fused fluid metric vs oracle", mult=10.0)
+    assert_close(fused, host(plain), dtype, "fused vs three-call", mult=10.0)
