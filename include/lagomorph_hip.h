@@ -58,6 +58,8 @@ int lago_get_splat_mode(void);
  * whole rows when nz <= 192), window margins MX MY MZ, threads per workgroup
  * (256 / 512 / 1024).  Affects speed only, never results. */
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
+/* 1 (default): use the 16-byte vectorised 3D kernels when nz and alignment allow; 0: scalar kernels only. */
+void lago_set_vector_kernels(int on);
 
 #define LAGO_DECLARE(REAL, SUF)                                                                                      \
     /* interp_forward (extension.cpp:135-143 -> cuda/interp.cu:80-130):                                           \

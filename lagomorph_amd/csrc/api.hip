@@ -8,6 +8,7 @@ namespace lago {
 
 static int g_debug = 0;
 int g_splat_mode = 1;
+int g_interp_vec = 1;
 static thread_local char g_err[512] = "";
 
 int fail_invalid(const char *fmt, ...) {
@@ -45,4 +46,5 @@ const char *lago_version(void) { return "lagomorph_hip 0.1 (gfx950, HIP)"; }
 const char *lago_last_error(void) { return lago::g_err; }
 void lago_set_splat_mode(int mode) { lago::g_splat_mode = mode; }
 int lago_get_splat_mode(void) { return lago::g_splat_mode; }
+void lago_set_vector_kernels(int on) { lago::g_interp_vec = on ? 1 : 0; }
 }

@@ -28,6 +28,7 @@ int fail_invalid(const char *fmt, ...);
 int fail_hip(hipError_t e, const char *what);
 int finish_launch(hipStream_t s, const char *what);  // hipGetLastError (+ sync in debug mode)
 extern int g_splat_mode;
+extern int g_interp_vec;  // 1: use the vectorised 3D kernels when shapes allow (default)
 
 #define LAGO_HIP_TRY(expr)                                      \
     do {                                                        \
@@ -173,21 +174,25 @@ __device__ __forceinline__ double buf_load1<double>(BufRsrc r, uint32_t off) {
 // two adjacent elements with ONE load (element-aligned, not pair-aligned)
 template <typename R>
 __device__ __forceinline__ void buf_load2(BufRsrc r, uint32_t off, R &lo, R &hi);
+// hipcc 7.2 narrows a b64/b128 buffer load to its first dword when the vector elements are
+// extracted and only consumed through selects (observed miscompile; tools/probes/bufload_align.hip).
+// Going through a scalar integer of the full width avoids the pattern.
 template <>
 __device__ __forceinline__ void buf_load2<float>(BufRsrc r, uint32_t off, float &lo, float &hi) {
-    lg_u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-    // Opaque to the optimiser on purpose: hipcc 7.2 narrows a b64/b128 buffer load to its first
-    // dword when the elements are only consumed through selects (observed miscompile).
-    asm volatile("" : "+v"(p));
-    lo = __builtin_bit_cast(float, p.x);
-    hi = __builtin_bit_cast(float, p.y);
+    const lg_u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    const unsigned long long q = __builtin_bit_cast(unsigned long long, p);
+    lo = __builtin_bit_cast(float, (unsigned int)q);
+    hi = __builtin_bit_cast(float, (unsigned int)(q >> 32));
 }
+struct lg_u64x2 {
+    unsigned long long a, b;
+};
 template <>
 __device__ __forceinline__ void buf_load2<double>(BufRsrc r, uint32_t off, double &lo, double &hi) {
-    lg_u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-    asm volatile("" : "+v"(p));
-    lo = __builtin_bit_cast(double, lg_u32x2{p.x, p.y});
-    hi = __builtin_bit_cast(double, lg_u32x2{p.z, p.w});
+    const lg_u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    const lg_u64x2 q = __builtin_bit_cast(lg_u64x2, p);
+    lo = __builtin_bit_cast(double, q.a);
+    hi = __builtin_bit_cast(double, q.b);
 }
 
 // Trilinear stencil.  The 8 corners are 4 (x, y) rows times the z pair

@@ -36,6 +36,47 @@ __global__ __launch_bounds__(kBlock) void interp_fwd_kernel(R *__restrict__ out,
     }
 }
 
+// Vectorised 3D forward: each lane owns VPL consecutive-z voxels (one 16-byte load per
+// displacement component, one 16-byte store per channel) and issues the 4*VPL pair gathers of a
+// channel back to back.  The scalar kernel above is latency-bound (two dependent memory round
+// trips per wave with 256 bytes in flight); this one keeps VPL times more bytes in flight per
+// wave.  Requires nz % VPL == 0 and 16-byte aligned tensors; `gq` is the geometry of the
+// VPL-groups (nz / VPL along z).
+template <typename R, int N>
+struct alignas(sizeof(R) * N) VecN {
+    R e[N];
+};
+
+template <typename R, bool BC, int VPL>
+__global__ __launch_bounds__(kBlock) void interp_fwd3_vec_kernel(R *__restrict__ out, const R *__restrict__ I,
+                                                                 const R *__restrict__ u, double dt, int nc,
+                                                                 Geom gq) {
+    typedef VecN<R, VPL> V;
+    const Vox v = locate(gq);
+    if (!v.valid) return;
+    const int nz = gq.nz * VPL;
+    const size_t nv = (size_t)gq.nvox * VPL;
+    const size_t s = (size_t)v.s * VPL;
+    const R *un = u + (size_t)v.n * 3 * nv + s;
+    const R *In = BC ? I : I + (size_t)v.n * nc * nv;
+    R *on = out + (size_t)v.n * nc * nv + s;
+    const V ux = *reinterpret_cast<const V *>(un);
+    const V uy = *reinterpret_cast<const V *>(un + nv);
+    const V uz = *reinterpret_cast<const V *>(un + 2 * nv);
+    Lerp3<R> L[VPL];
+#pragma unroll
+    for (int e = 0; e < VPL; ++e)
+        L[e].setup(sample_pos<R>(v.i, dt, ux.e[e]), sample_pos<R>(v.j, dt, uy.e[e]),
+                   sample_pos<R>(v.k * VPL + e, dt, uz.e[e]), gq.nx, gq.ny, nz);
+    for (int c = 0; c < nc; ++c) {
+        const R *Ic = In + (size_t)c * nv;
+        V o;
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) o.e[e] = L[e].value(Ic);
+        *reinterpret_cast<V *>(on + (size_t)c * nv) = o;
+    }
+}
+
 // ------------------------------------------------------------------ backward, global atomics
 
 template <typename R, int DIM, bool BC, bool NEED_I, bool NEED_U>
@@ -146,6 +187,18 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
     if (g.nblocks == 0 || nc == 0) return LAGO_OK;  // empty batch / no channels: nothing to write
     if (!out || !I || !u) return fail_invalid("interp_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    constexpr int VPL = 16 / sizeof(R);
+    Geom gq;
+    if (dim == 3 && g_interp_vec && nz % VPL == 0 && nz >= 2 * VPL &&
+        (((uintptr_t)out | (uintptr_t)I | (uintptr_t)u) & 15) == 0 && make_geom(gq, 3, nn, nx, ny, nz / VPL)) {
+        if (bc)
+            hipLaunchKernelGGL((interp_fwd3_vec_kernel<R, true, VPL>), dim3(gq.nblocks), dim3(kBlock), 0, s, out, I, u,
+                               dt, (int)nc, gq);
+        else
+            hipLaunchKernelGGL((interp_fwd3_vec_kernel<R, false, VPL>), dim3(gq.nblocks), dim3(kBlock), 0, s, out, I,
+                               u, dt, (int)nc, gq);
+        return finish_launch(s, "interp_forward");
+    }
 #define LAUNCH(D, B) \
     hipLaunchKernelGGL((interp_fwd_kernel<R, D, B>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, u, dt, (int)nc, g)
     if (dim == 3) {
@@ -193,7 +246,7 @@ static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R
         if (need_u && nu) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
         return finish_launch(s, "interp_backward");
     }
-    if (dim == 3 && need_I && g_splat_mode == 1) {
+    if (dim == 3 && need_I && g_splat_mode >= 1) {
         int rc = interp_backward_lds<R>(d_I, d_u, go, I, u, dt, (int)nc, nn, g, bc != 0, need_u != 0, s);
         if (rc != 1) return rc;  // 1 = shape not supported by the tiled kernel, fall through
     }

@@ -7,12 +7,27 @@
 // so issuing the reference's 8 atomics per voxel-channel caps the kernel at a
 // fraction of the HBM roofline.  Here a workgroup owns a TX x TY x TZ tile of
 // *source* voxels and accumulates their 8 corner contributions in an LDS window
-// (ds_add_f32) that is positioned at tile origin + displacement at the tile
-// centre - margin.  Smooth displacement fields keep nearly every corner inside
-// the window; corners that fall outside take the global-atomic path, so any
-// displacement is handled correctly.  The window is then flushed with one
-// global atomic per *touched* cell, in 256-byte wavefront rows whose start is
-// 64-byte aligned (window z origin is a multiple of 16 floats).
+// positioned at tile origin + displacement probed at the tile centre - margin.
+// Smooth displacement fields keep
+// nearly every corner inside the window; corners that fall outside take the
+// global-atomic path, so any displacement is handled correctly.  The window is
+// then flushed with one global atomic per *touched* cell, in wavefront rows of
+// consecutive z whose start is 64-byte aligned (window z origin is a multiple of
+// 16 cells).
+//
+// The LDS window accumulates in float64 even for float32 fields: on gfx950
+// ds_add_f32 costs ~193 cycles per wave-instruction per CU while ds_add_f64 costs
+// ~9 (measured, tools/probes/lds_atomic_rate.hip), so an fp32 window is LDS-atomic
+// bound at ~0.7 ms for the 8 x 128^3 case.  Contributions are computed in the
+// field precision exactly as the reference does, summed in double inside a tile,
+// and rounded once at the flush.
+//
+// Each lane owns groups of VPL consecutive-z voxels of the tile (16-byte loads of u
+// and grad_out, 16-byte stores of d_u).  The kernel is latency-bound (dependent HBM
+// round trips per phase), so occupancy matters more than anything: this loop
+// structure compiles to 99 VGPRs; a variant that kept the sample positions live
+// across the barrier compiled to 217 and ran 1.7x slower.  VPL = 1 is the
+// general-shape fallback.
 //
 // d_u (the analytic gradient term, include/interp.h:207-327) is produced by the
 // same pass: the thread that owns a voxel owns its d_u entries, so the channel
@@ -24,31 +39,38 @@ namespace lago {
 
 struct TileGeom {
     int nx, ny, nz;
-    int TX, TY, TZ;     // source tile
+    int TX, TY, TZ;     // source tile (voxels)
     int WX, WY, WZ;     // LDS window (cells)
-    int MX, MY, MZ;     // margin below the displaced tile origin
+    int MX, MY, MZ;     // margin below the probed origin
     uint32_t ntx, nty, ntz, tiles_per_item, total;
-    uint32_t tile_vox, win_cells;
+    uint32_t tile_groups, win_cells;   // tile size in VPL-groups; window size in cells
+    int ablate;                        // profiling only (tools/ablate_splat.py): bit0 no LDS adds, bit1 no fallback
+                                       // atomics, bit2 no flush atomics; always 0 in production
     FastDiv d_tiles, d_tyz, d_tz;      // block id -> (n, bx, by, bz)
-    FastDiv d_TyTz, d_Tz;              // tile voxel id -> (a, b, c)
+    FastDiv d_TyTzq, d_Tzq;            // tile group id -> (a, b, cq)
     FastDiv d_WyWz, d_Wz;              // window cell id -> (lx, ly, lz)
 };
 
-static int g_tile_cfg[7] = {8, 8, 0, 2, 2, 16, 512};  // TX TY TZ(0=whole rows up to 192) MX MY MZ threads
+// TX TY TZ(0 = auto) window margins MX MY MZ around the probed origin, threads per workgroup
+static int g_tile_cfg[7] = {8, 8, 32, 1, 1, 4, 512};
+static int g_ablate = 0;
 
-__device__ __forceinline__ void lds_add(float *p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <typename R, bool BC, bool NEED_U, int NT>
+template <typename R, int N>
+struct alignas(sizeof(R) * N) SVec {
+    R e[N];
+};
+
+template <typename R, bool BC, bool NEED_U, int NT, int VPL>
 __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R *__restrict__ d_u,
                                                          const R *__restrict__ go, const R *__restrict__ I,
                                                          const R *__restrict__ u, double dt, int nc, TileGeom tg) {
+    typedef SVec<R, VPL> V;
     extern __shared__ __align__(16) unsigned char lago_smem[];
-    R *win = reinterpret_cast<R *>(lago_smem);
+    double *win = reinterpret_cast<double *>(lago_smem);  // f64 accumulators: see the header note
     const int nx = tg.nx, ny = tg.ny, nz = tg.nz;
     const size_t nv = (size_t)nx * ny * nz;
 
@@ -69,7 +91,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const R *gon = go + (size_t)n * nc * nv;
     R *dun = NEED_U ? d_u + (size_t)n * 3 * nv : nullptr;
 
-    // window origin from the displacement at the tile centre (placement only
+    // window origin: displacement probed at the tile centre minus a margin (placement only
     // affects speed, never the result)
     const size_t sc = ((size_t)(x0 + ex / 2) * ny + (y0 + ey / 2)) * nz + (z0 + ez / 2);
     const float fdt = (float)dt;
@@ -81,106 +103,123 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const int wy0 = max(0, min(y0 + offy - tg.MY, ny - wey));
     const int wz0 = max(0, min((z0 + offz - tg.MZ) & ~15, nz - wez));
     const int WY = tg.WY, WZ = tg.WZ;
+    const int TZq = tg.TZ / VPL;
 
     for (int c = 0; c < nc; ++c) {
-        for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0;
+        for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0.0;
         __syncthreads();
         const R *Ic = In + (size_t)c * nv;
         R *dIc = dIn + (size_t)c * nv;
         const R *gc = gon + (size_t)c * nv;
-        for (uint32_t t = threadIdx.x; t < tg.tile_vox; t += NT) {
-            const uint32_t a = tg.d_TyTz.div(t);
-            const uint32_t rr = t - a * (uint32_t)(tg.TY * tg.TZ);
-            const uint32_t b = tg.d_Tz.div(rr);
-            const uint32_t cc = rr - b * (uint32_t)tg.TZ;
-            if ((int)a >= ex || (int)b >= ey || (int)cc >= ez) continue;
-            const int i = x0 + a, j = y0 + b, k = z0 + cc;
-            const size_t s = ((size_t)i * ny + j) * nz + k;
-            const R hx = sample_pos<R>(i, dt, un[s]);
-            const R hy = sample_pos<R>(j, dt, un[s + nv]);
-            const R hz = sample_pos<R>(k, dt, un[s + 2 * nv]);
-            R diff = gc[s];
-            // include/interp.h:431-453: floor corner, sequentially flipped weights
-            const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
-            R dx = (R)1.f - (hx - (R)fx);
-            R dy = (R)1.f - (hy - (R)fy);
-            R dz = (R)1.f - (hz - (R)fz);
-            int gi[2] = {clamp1(fx, nx), clamp1(fx + 1, nx)};
-            int gj[2] = {clamp1(fy, ny), clamp1(fy + 1, ny)};
-            int gk[2] = {clamp1(fz, nz), clamp1(fz + 1, nz)};
+        for (uint32_t t = threadIdx.x; t < tg.tile_groups; t += NT) {
+            const uint32_t a = tg.d_TyTzq.div(t);
+            const uint32_t rr = t - a * (uint32_t)(tg.TY * TZq);
+            const uint32_t b = tg.d_Tzq.div(rr);
+            const uint32_t cq = rr - b * (uint32_t)TZq;
+            const int kk = (int)cq * VPL;
+            if ((int)a >= ex || (int)b >= ey || kk >= ez) continue;  // ez is a multiple of VPL
+            const int i = x0 + a, j = y0 + b, k0 = z0 + kk;
+            const size_t s = ((size_t)i * ny + j) * nz + k0;
+            const V ux = *reinterpret_cast<const V *>(un + s);
+            const V uy = *reinterpret_cast<const V *>(un + s + nv);
+            const V uz = *reinterpret_cast<const V *>(un + s + 2 * nv);
+            const V gv = *reinterpret_cast<const V *>(gc + s);
+            V dux, duy, duz;
+            if (NEED_U && c > 0) {
+                dux = *reinterpret_cast<const V *>(dun + s);
+                duy = *reinterpret_cast<const V *>(dun + s + nv);
+                duz = *reinterpret_cast<const V *>(dun + s + 2 * nv);
+            }
 #pragma unroll
-            for (int qa = 0; qa < 2; ++qa) {
-                const int lx = gi[qa] - wx0;
+            for (int e = 0; e < VPL; ++e) {
+                const R hx = sample_pos<R>(i, dt, ux.e[e]);
+                const R hy = sample_pos<R>(j, dt, uy.e[e]);
+                const R hz = sample_pos<R>(k0 + e, dt, uz.e[e]);
+                R diff = gv.e[e];
+                // include/interp.h:431-453: floor corner, sequentially flipped weights
+                const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+                R dx = (R)1.f - (hx - (R)fx);
+                R dy = (R)1.f - (hy - (R)fy);
+                R dz = (R)1.f - (hz - (R)fz);
+                const int gi[2] = {clamp1(fx, nx), clamp1(fx + 1, nx)};
+                const int gj[2] = {clamp1(fy, ny), clamp1(fy + 1, ny)};
+                const int gk[2] = {clamp1(fz, nz), clamp1(fz + 1, nz)};
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    const int ly = gj[qb] - wy0;
+                for (int qa = 0; qa < 2; ++qa) {
+                    const int lx = gi[qa] - wx0;
 #pragma unroll
-                    for (int qc = 0; qc < 2; ++qc) {
-                        const int lz = gk[qc] - wz0;
-                        const R val = (dx * dy * dz) * diff;
-                        const bool inside = (unsigned)lx < (unsigned)wex && (unsigned)ly < (unsigned)wey &&
-                                            (unsigned)lz < (unsigned)wez;
-                        if (inside)
-                            lds_add(&win[(lx * WY + ly) * WZ + lz], val);
-                        else
-                            atomic_add(dIc + ((size_t)gi[qa] * ny + gj[qb]) * nz + gk[qc], val);
-                        dz = (R)1.f - dz;
+                    for (int qb = 0; qb < 2; ++qb) {
+                        const int ly = gj[qb] - wy0;
+#pragma unroll
+                        for (int qc = 0; qc < 2; ++qc) {
+                            const int lz = gk[qc] - wz0;
+                            const R val = (dx * dy * dz) * diff;
+                            const bool inside = (unsigned)lx < (unsigned)wex && (unsigned)ly < (unsigned)wey &&
+                                                (unsigned)lz < (unsigned)wez;
+                            if (inside) {
+                                if (!(tg.ablate & 1)) lds_add(&win[(lx * WY + ly) * WZ + lz], (double)val);
+                            } else if (!(tg.ablate & 2)) {
+                                atomic_add(dIc + ((size_t)gi[qa] * ny + gj[qb]) * nz + gk[qc], val);
+                            }
+                            dz = (R)1.f - dz;
+                        }
+                        dy = (R)1.f - dy;
                     }
-                    dy = (R)1.f - dy;
+                    dx = (R)1.f - dx;
                 }
-                dx = (R)1.f - dx;
+                if (NEED_U) {
+                    Lerp3<R> Lq;
+                    Lq.setup(hx, hy, hz, nx, ny, nz);
+                    R gx, gy, gz;
+                    Lq.grad(Ic, gx, gy, gz);
+                    diff = (R)((double)diff * dt);  // cuda/interp.cu:230
+                    dux.e[e] = lg_fma(gx, diff, c == 0 ? (R)0 : dux.e[e]);
+                    duy.e[e] = lg_fma(gy, diff, c == 0 ? (R)0 : duy.e[e]);
+                    duz.e[e] = lg_fma(gz, diff, c == 0 ? (R)0 : duz.e[e]);
+                }
             }
             if (NEED_U) {
-                Lerp3<R> Lq;
-                Lq.setup(hx, hy, hz, nx, ny, nz);
-                R gx, gy, gz;
-                Lq.grad(Ic, gx, gy, gz);
-                diff = (R)((double)diff * dt);  // cuda/interp.cu:230
-                if (c == 0) {
-                    dun[s] = lg_fma(gx, diff, (R)0);
-                    dun[s + nv] = lg_fma(gy, diff, (R)0);
-                    dun[s + 2 * nv] = lg_fma(gz, diff, (R)0);
-                } else {
-                    dun[s] = lg_fma(gx, diff, dun[s]);
-                    dun[s + nv] = lg_fma(gy, diff, dun[s + nv]);
-                    dun[s + 2 * nv] = lg_fma(gz, diff, dun[s + 2 * nv]);
-                }
+                *reinterpret_cast<V *>(dun + s) = dux;
+                *reinterpret_cast<V *>(dun + s + nv) = duy;
+                *reinterpret_cast<V *>(dun + s + 2 * nv) = duz;
             }
         }
         __syncthreads();
         // flush touched cells: consecutive lanes -> consecutive z of one window row
         for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) {
-            const R val = win[f];
-            if (val != (R)0) {
+            const double acc = win[f];
+            if (acc != 0.0 && !(tg.ablate & 4)) {
                 const uint32_t lx = tg.d_WyWz.div(f);
-                const uint32_t rr = f - lx * (uint32_t)(WY * WZ);
-                const uint32_t ly = tg.d_Wz.div(rr);
-                const uint32_t lz = rr - ly * (uint32_t)WZ;
-                atomic_add(dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + (wz0 + lz), val);
+                const uint32_t r2 = f - lx * (uint32_t)(WY * WZ);
+                const uint32_t ly = tg.d_Wz.div(r2);
+                const uint32_t lz = r2 - ly * (uint32_t)WZ;
+                atomic_add(dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + (wz0 + lz), (R)acc);
             }
         }
         __syncthreads();
     }
 }
 
-static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, size_t elem, size_t &smem, int &nthreads) {
+static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, int vpl, size_t &smem, int &nthreads) {
     int TX = g_tile_cfg[0], TY = g_tile_cfg[1], TZ = g_tile_cfg[2];
-    const int MX = g_tile_cfg[3], MY = g_tile_cfg[4], MZ = g_tile_cfg[5];
-    nthreads = g_tile_cfg[6];
-    if (TX < 1 || TY < 1 || MX < 0 || MY < 0 || MZ < 0) return false;
-    if (TZ <= 0) TZ = g.nz <= 192 ? g.nz : 128;
+    const int EX = g_tile_cfg[3], EY = g_tile_cfg[4], EZ = g_tile_cfg[5];
+    nthreads = g_tile_cfg[6] >= 1024 ? 1024 : (g_tile_cfg[6] >= 512 ? 512 : 256);
+    if (TX < 1 || TY < 1 || EX < 0 || EY < 0 || EZ < 0) return false;
+    if (TZ <= 0) TZ = 32;
     TX = TX < g.nx ? TX : g.nx;
     TY = TY < g.ny ? TY : g.ny;
     TZ = TZ < g.nz ? TZ : g.nz;
+    TZ = ((TZ + vpl - 1) / vpl) * vpl;  // whole VPL-groups (vpl > 1 only when nz % vpl == 0)
     tg.nx = g.nx; tg.ny = g.ny; tg.nz = g.nz;
     tg.TX = TX; tg.TY = TY; tg.TZ = TZ;
-    tg.MX = MX; tg.MY = MY; tg.MZ = MZ;
-    tg.WX = TX + 1 + 2 * MX;
-    tg.WY = TY + 1 + 2 * MY;
-    tg.WZ = TZ >= g.nz ? g.nz : ((TZ + 1 + 2 * MZ + 15 + 15) / 16) * 16;  // +15: origin is aligned down
+    // window = tile extent + 1 (ceil corner) + a margin on both sides of the probed origin
+    tg.MX = EX; tg.MY = EY; tg.MZ = EZ;
+    tg.WX = TX + 1 + 2 * EX;
+    tg.WY = TY + 1 + 2 * EY;
+    tg.WZ = TZ >= g.nz ? g.nz : ((TZ + 1 + 2 * EZ + 15 + 15) / 16) * 16;  // +15: the z origin is aligned down
     if (tg.WZ > g.nz) tg.WZ = g.nz;
     tg.win_cells = (uint32_t)tg.WX * tg.WY * tg.WZ;
-    smem = (size_t)tg.win_cells * elem;
+    smem = (size_t)tg.win_cells * sizeof(double);
     if (smem > 160 * 1024) return false;
     tg.ntx = (g.nx + TX - 1) / TX;
     tg.nty = (g.ny + TY - 1) / TY;
@@ -189,21 +228,22 @@ static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, size_t elem, siz
     int64_t total = (int64_t)tg.tiles_per_item * nn;
     if (total >= (1ll << 31)) return false;
     tg.total = (uint32_t)total;
-    tg.tile_vox = (uint32_t)TX * TY * TZ;
+    tg.tile_groups = (uint32_t)TX * TY * (TZ / vpl);
+    tg.ablate = g_ablate;
     tg.d_tiles = FastDiv(tg.tiles_per_item);
     tg.d_tyz = FastDiv(tg.nty * tg.ntz);
     tg.d_tz = FastDiv(tg.ntz);
-    tg.d_TyTz = FastDiv((uint32_t)(TY * TZ));
-    tg.d_Tz = FastDiv((uint32_t)TZ);
+    tg.d_TyTzq = FastDiv((uint32_t)(TY * (TZ / vpl)));
+    tg.d_Tzq = FastDiv((uint32_t)(TZ / vpl));
     tg.d_WyWz = FastDiv((uint32_t)(tg.WY * tg.WZ));
     tg.d_Wz = FastDiv((uint32_t)tg.WZ);
     return true;
 }
 
-template <typename R, bool BC, bool NEED_U, int NT>
+template <typename R, bool BC, bool NEED_U, int NT, int VPL>
 static hipError_t launch_tiled(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc,
                                const TileGeom &tg, size_t smem, hipStream_t s) {
-    auto k = splat_tiled_kernel<R, BC, NEED_U, NT>;
+    auto k = splat_tiled_kernel<R, BC, NEED_U, NT, VPL>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -213,17 +253,10 @@ static hipError_t launch_tiled(R *d_I, R *d_u, const R *go, const R *I, const R 
     return hipSuccess;
 }
 
-// Returns LAGO_OK / error, or 1 when this shape/dtype is left to the plain kernel.
-// The caller has already zeroed d_I (and d_u when it is not needed).
-template <typename R>
-int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
-                        const Geom &g, bool bc, bool need_u, hipStream_t s) {
-    TileGeom tg;
-    size_t smem;
-    int nt;
-    if (!make_tiles(tg, g, nn, sizeof(R), smem, nt)) return 1;
-    hipError_t e = hipSuccess;
-#define GO(B, U, T) e = launch_tiled<R, B, U, T>(d_I, d_u, go, I, u, dt, nc, tg, smem, s)
+template <typename R, int VPL>
+static hipError_t dispatch_tiled(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc,
+                                 const TileGeom &tg, size_t smem, int nt, bool bc, bool need_u, hipStream_t s) {
+#define GO(B, U, T) return launch_tiled<R, B, U, T, VPL>(d_I, d_u, go, I, u, dt, nc, tg, smem, s)
 #define BY_NT(B, U)                          \
     do {                                     \
         if (nt >= 1024) GO(B, U, 1024);      \
@@ -237,6 +270,22 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     }
 #undef BY_NT
 #undef GO
+}
+
+// Returns LAGO_OK / error, or 1 when this shape is left to the plain kernel.
+// The caller has already zeroed d_I (and d_u when it is not needed).
+template <typename R>
+int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
+                        const Geom &g, bool bc, bool need_u, hipStream_t s) {
+    constexpr int VPLmax = 16 / sizeof(R);
+    const bool vec = g_interp_vec && g.nz % VPLmax == 0 &&
+                     (((uintptr_t)d_u | (uintptr_t)go | (uintptr_t)u) & 15) == 0;
+    TileGeom tg;
+    size_t smem;
+    int nt;
+    if (!make_tiles(tg, g, nn, vec ? VPLmax : 1, smem, nt)) return 1;
+    hipError_t e = vec ? dispatch_tiled<R, VPLmax>(d_I, d_u, go, I, u, dt, nc, tg, smem, nt, bc, need_u, s)
+                       : dispatch_tiled<R, 1>(d_I, d_u, go, I, u, dt, nc, tg, smem, nt, bc, need_u, s);
     if (e != hipSuccess) return fail_hip(e, "interp_backward (tiled splat)");
     return finish_launch(s, "interp_backward (tiled splat)");
 }
@@ -249,10 +298,12 @@ template int interp_backward_lds<double>(double *, double *, const double *, con
 }  // namespace lago
 
 extern "C" {
-// Tuning hook (bench / tests): tile TX, TY, TZ (0 = whole rows), margins MX, MY, MZ, threads per workgroup.
-void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
+// Tuning hook (bench / tests): tile TX, TY, TZ (0 = auto), window margins, threads per workgroup.
+// Affects speed only, never results.
+void lago_set_splat_tile(int tx, int ty, int tz, int ex, int ey, int ez, int nthreads) {
     lago::g_tile_cfg[0] = tx; lago::g_tile_cfg[1] = ty; lago::g_tile_cfg[2] = tz;
-    lago::g_tile_cfg[3] = mx; lago::g_tile_cfg[4] = my; lago::g_tile_cfg[5] = mz;
+    lago::g_tile_cfg[3] = ex; lago::g_tile_cfg[4] = ey; lago::g_tile_cfg[5] = ez;
     lago::g_tile_cfg[6] = nthreads;
 }
+void lago_debug_splat_ablate(int mask) { lago::g_ablate = mask; }  // profiling only; results are wrong when != 0
 }

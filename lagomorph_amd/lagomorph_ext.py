@@ -50,7 +50,7 @@ _SIGS = {
                                     _int, _int, _vp],
     "lago_regrid_forward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
-    "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _vp],
+    "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_fluid_metric": [_vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64, _i64,
                           _i64, _vp],
 }
@@ -135,6 +135,11 @@ def set_splat_mode(mode):
 
 def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
     _lib.lago_set_splat_tile(int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
+
+
+def set_vector_kernels(on):
+    """1 (default): 16-byte vectorised 3D kernels where shapes allow; 0: scalar kernels only."""
+    _lib.lago_set_vector_kernels(1 if on else 0)
 
 
 def version():

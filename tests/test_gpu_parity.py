@@ -54,7 +54,7 @@ def assert_close(got, want, dtype, what, scale=None, mult=1.0):
     assert err <= mult * RTOL[dtype] * max(ref, 1e-30), f"{what}: max err {err:.3e} vs scale {ref:.3e}"
 
 
-SHAPES3 = [(5, 6, 7), (8, 8, 8), (3, 4, 1), (2, 2, 2), (9, 5, 70)]
+SHAPES3 = [(5, 6, 7), (8, 8, 8), (3, 4, 1), (2, 2, 2), (9, 5, 70), (6, 5, 16), (3, 4, 128)]
 SHAPES2 = [(7, 9), (16, 16), (2, 2), (5, 1), (3, 130)]
 
 
@@ -112,13 +112,16 @@ def test_tiled_splat_any_tile_config(ext, dtype, tile):
     u = _disp(rng, 2, sp, dtype)
     go = rnd(rng, (2, 2) + sp, dtype)
     oI, ou = orc.interp_backward(go, I, u, 1.0, True, True)
-    ext.set_splat_tile(*tile)
-    try:
-        dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 1.0, True, True)
-    finally:
-        ext.set_splat_tile(8, 8, 0, 2, 2, 16, 512)
-    assert_bits(du, ou, "d_u")
-    assert_close(dI, oI, dtype, "d_I", mult=4.0)
+    for mode in (1,):
+        ext.set_splat_tile(*tile)
+        ext.set_splat_mode(mode)
+        try:
+            dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 1.0, True, True)
+        finally:
+            ext.set_splat_tile(8, 8, 32, 1, 1, 4, 512)
+            ext.set_splat_mode(1)
+        assert_bits(du, ou, f"d_u mode {mode}")
+        assert_close(dI, oI, dtype, f"d_I mode {mode}", mult=4.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -321,7 +324,7 @@ def test_empty_and_error_behaviour(ext):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("sp", [(5, 6, 7), (8, 8, 8), (3, 4, 1), (7, 9), (2, 2)])
+@pytest.mark.parametrize("sp", [(5, 6, 7), (8, 8, 8), (3, 4, 1), (7, 9), (2, 2), (4, 3, 64)])
 def test_fused_compose_bit_exact(ext, dtype, sp):
     """ds*u + dt*interp(v, u, ds) in one kernel == the unfused expression (three roundings kept)."""
     rng = np.random.default_rng(hash(sp) % 2**31)
@@ -361,3 +364,21 @@ def test_fused_fluid_metric_matches_three_call_form(ext, dtype, sp, inverse):
     want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
     assert_close(fused, want, dtype, "fused fluid metric vs oracle", mult=10.0)
     assert_close(fused, host(plain), dtype, "fused vs three-call", mult=10.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
+    """The 16-byte vectorised 3D kernels are a launch-shape choice only."""
+    rng = np.random.default_rng(77)
+    sp = (6, 7, 32)
+    I = rnd(rng, (2, 3) + sp, dtype)
+    u = _disp(rng, 2, sp, dtype)
+    v = rnd(rng, (2, 3) + sp, dtype)
+    a = ext.interp_forward(dev(I), dev(u), 0.9), ext.compose(dev(u), dev(v), -0.3, 1.0)
+    ext.set_vector_kernels(0)
+    try:
+        b = ext.interp_forward(dev(I), dev(u), 0.9), ext.compose(dev(u), dev(v), -0.3, 1.0)
+    finally:
+        ext.set_vector_kernels(1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert_bits(a[0], orc.interp_forward(I, u, 0.9), "vector interp vs oracle")
