@@ -201,7 +201,9 @@ __device__ __forceinline__ void buf_load2<double>(BufRsrc r, uint32_t off, doubl
 // border both members of the clamped pair coincide and are picked from the same
 // half.  Offsets are 32-bit byte offsets from a wave-uniform base pointer, so the
 // loads use the scalar-base addressing mode and need no 64-bit address math.
-template <typename R>
+// THIN_OK = false promises nz >= 2 at compile time (the vectorised kernels): without the
+// per-sample `thin` branch the compiler batches the pair loads of several samples.
+template <typename R, bool THIN_OK = true>
 struct Lerp3 {
     uint32_t rb[4];   // byte offsets of rows (fx,fy) (cx,fy) (cx,cy) (fx,cy) at z = zb: v0/v4 v1/v5 v2/v6 v3/v7
     R t, u, v;
@@ -216,7 +218,7 @@ struct Lerp3 {
         const int fx = clamp1(flx, sx), cx = clamp1(flx + 1, sx);
         const int fy = clamp1(fly, sy), cy = clamp1(fly + 1, sy);
         const int fz = clamp1(flz, sz), cz = clamp1(flz + 1, sz);
-        thin = sz < 2;
+        thin = THIN_OK && sz < 2;
         const int zb = thin ? 0 : min(fz, sz - 2);
         f_hi = fz != zb;
         c_lo = cz == zb;
@@ -235,7 +237,7 @@ struct Lerp3 {
     // descriptor held in SGPRs, the per-lane part is the 32-bit byte offset.
     __device__ __forceinline__ void fetch(const R *__restrict__ img, R (&c)[8]) const {
         const BufRsrc r = make_rsrc(img, bytes);
-        if (thin) {
+        if (THIN_OK && thin) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) c[q] = c[q + 4] = buf_load1<R>(r, rb[q]);
             return;

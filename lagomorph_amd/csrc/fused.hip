@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void compose3_vec_kernel(R *__restrict__ ou
     V uu[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) uu[d] = *reinterpret_cast<const V *>(un + (size_t)d * nv);
-    Lerp3<R> L[VPL];
+    Lerp3<R, false> L[VPL];
 #pragma unroll
     for (int e = 0; e < VPL; ++e)
         L[e].setup(sample_pos<R>(vx.i, ds, uu[0].e[e]), sample_pos<R>(vx.j, ds, uu[1].e[e]),

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void interp_fwd3_vec_kernel(R *__restrict__
     const V ux = *reinterpret_cast<const V *>(un);
     const V uy = *reinterpret_cast<const V *>(un + nv);
     const V uz = *reinterpret_cast<const V *>(un + 2 * nv);
-    Lerp3<R> L[VPL];
+    Lerp3<R, false> L[VPL];
 #pragma unroll
     for (int e = 0; e < VPL; ++e)
         L[e].setup(sample_pos<R>(v.i, dt, ux.e[e]), sample_pos<R>(v.j, dt, uy.e[e]),

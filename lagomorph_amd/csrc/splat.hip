@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                     dx = (R)1.f - dx;
                 }
                 if (NEED_U) {
-                    Lerp3<R> Lq;
+                    Lerp3<R, VPL == 1> Lq;
                     Lq.setup(hx, hy, hz, nx, ny, nz);
                     R gx, gy, gz;
                     Lq.grad(Ic, gx, gy, gz);
