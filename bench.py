@@ -288,9 +288,18 @@ def main():
         if k:
             bytes_per_launch = 36.0 * V  # 4*(C*V + 3*V + C*V), C = 3
             ach = bytes_per_launch / (k["mean_ms"] * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
+            # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath) and B == 32 and S == 128:
+                rec = json.load(open(tpath)).get("lago::interp_fwd3_vec_kernel<float, false, 4>")
+                if rec:
+                    traffic, tsrc = rec["traffic_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc, same workload)"
             result["roofline"] = {
                 "kernel": "interp_fwd3_vec_kernel<float,false,4> (C=3)", "bound": "hbm", "achieved": ach,
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": tsrc,
                 "bytes_per_launch": bytes_per_launch, "mean_launch_ms": k["mean_ms"], "launches": k["launches"],
             }
         total_ms = 1e3 * T

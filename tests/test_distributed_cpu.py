@@ -1,0 +1,95 @@
+"""CPU, world_size 2 over gloo: the batch-sharded atlas builder (lagomorph_amd.lddmm
+LDDMMAtlasBuilder; reference lddmm.py:108-375) gives the same atlas as a single process over the
+whole dataset -- shard ownership of momenta, the SUM all-reduce of the atlas gradient divided by
+image_iters * world_size (lddmm.py:292-297), the mean-image all-reduce (lddmm.py:196-198) and the
+loss reduction.  The CPU oracle stands in for lagomorph_ext inside the workers (tests only)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _patch_oracle():
+    import lagomorph_amd as lm
+    from oracle.lago_oracle import OracleExt
+
+    o = OracleExt()
+    for name in ("interp_forward", "interp_backward", "compose", "jacobian_times_vectorfield_forward",
+                 "jacobian_times_vectorfield_backward", "jacobian_times_vectorfield_adjoint_forward",
+                 "jacobian_times_vectorfield_adjoint_backward", "fluid_operator", "regrid_forward", "regrid_backward"):
+        setattr(lm.lagomorph_ext, name, getattr(o, name))
+    delattr(lm.lagomorph_ext, "fluid_metric")
+    return lm
+
+
+def _dataset(n, sp):
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn((1, 1) + sp, generator=g, dtype=torch.float64)
+    return base + 0.3 * torch.randn((n, 1) + sp, generator=g, dtype=torch.float64)
+
+
+def _run(rank, world, port, sp, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lm = _patch_oracle()
+        data = _dataset(4, sp)
+        per = data.shape[0] // world
+        shard = data[rank * per:(rank + 1) * per]
+        b = lm.LDDMMAtlasBuilder(shard, batch_size=2, lddmm_integration_steps=2, reg_weight=1e-1,
+                                 learning_rate_pose=1e-2, learning_rate_image=1e-1, world_size=world, rank=rank,
+                                 dataset_size=data.shape[0])
+        I = b.run(num_epochs=2)
+        res = {"I": I.numpy(), "loss": [float(x) for x in b.epoch_losses], "m0": b.ms[0].numpy()}
+        if rank == 0:
+            np.savez(out, I=res["I"], loss=np.array(res["loss"]), m0=res["m0"])
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("sp", [(6, 6, 6), (8, 8)])
+def test_two_rank_atlas_equals_sequential_emulation(tmp_path, oracle_ext, sp):
+    """Reference semantics being checked (lddmm.py:287-341, as coded): every rank runs lddmm_step on
+    its own minibatch against the same atlas, I.grad is SUM-all-reduced and divided by
+    image_iters * world_size, then one SGD step.  With image_update_freq = 0 that happens after
+    EVERY iteration (`image_iters < 0` is never true, lddmm.py:288-291), which is why a 2-rank run is
+    not the same computation as one process walking the 4 subjects in two minibatches.  The
+    emulation below does the per-rank steps sequentially in this process with plain tensor math."""
+    import lagomorph_amd as lm
+
+    data = _dataset(4, sp)
+    kw = dict(integration_steps=2, reg_weight=1e-1, learning_rate_pose=1e-2)
+    metric = lm.FluidMetric([0.1, 0, 0.01])
+    I = data.mean(0, keepdim=True).clone()
+    ms = [torch.zeros((2, len(sp)) + sp, dtype=data.dtype) for _ in range(2)]
+    losses = []
+    for _ in range(2):  # epochs; one iteration per rank per epoch
+        grads, tot = [], 0.0
+        for r in range(2):
+            Ir = I.clone().requires_grad_(True)
+            ms[r], loss, _reg = lm.lddmm_step(Ir, ms[r], data[2 * r:2 * r + 2], metric, 4, **kw)
+            grads.append(Ir.grad)
+            tot += float(loss)
+        I = I - 1e-1 * (grads[0] + grads[1]) / (1 * 2)
+        losses.append(tot)
+
+    out = str(tmp_path / "rank0.npz")
+    mp.spawn(_run, args=(2, _free_port(), sp, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert np.allclose(r["I"], I.numpy(), rtol=1e-10, atol=1e-12)  # up to the all-reduce's summation order
+    assert np.allclose(r["loss"], losses, rtol=1e-10)
+    assert np.allclose(r["m0"], ms[0].numpy(), rtol=1e-10, atol=1e-12)  # rank 0 owns the first minibatch
+    assert not np.allclose(r["I"], data.mean(0, keepdim=True).numpy())  # the atlas actually moved
