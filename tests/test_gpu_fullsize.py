@@ -1,0 +1,141 @@
+"""GPU: BASELINE.json's full-size configurations through size-independent properties (the CPU
+oracle would take minutes to hours at these sizes): adjointness <interp(I,u), g> = <I, splat(g)>,
+mass conservation of the splat (partition of unity), linearity, agreement of the LDS-privatised and
+the plain-atomic splat, flat(sharp(m)) = m, expmap(0) = 0, plus a spot check of a sub-volume
+against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lago_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lm():
+    import lagomorph_amd
+
+    lagomorph_amd.set_debug_mode(False)
+    return lagomorph_amd
+
+
+def smooth(shape, sigma, gen):
+    import bench
+
+    return bench.gaussian_blur(torch.randn(shape, device="cuda", generator=gen), sigma)
+
+
+def test_config1_interp_splat_batch8_128cubed(lm):
+    """configs[1]: 3D deform.interp + splat, batch 8, 1 x 128^3 fp32."""
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device="cuda").manual_seed(11)
+    N, S = 8, 128
+    I = smooth((N, 1, S, S, S), 2.0, g)
+    I = I / I.std()
+    u = smooth((N, 3, S, S, S), 8.0, g)
+    u = u * (4.0 / u.abs().max())
+    go = torch.randn((N, 1, S, S, S), device="cuda", generator=g)
+    out = ext.interp_forward(I, u, 1.0)
+    dI, du = ext.interp_backward(go, I, u, 1.0, True, True)
+    # adjointness of gather and scatter (fp32 sums over 16.7M terms: compare in float64)
+    lhs = (out.double() * go.double()).sum().item()
+    rhs = (I.double() * dI.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), np.sqrt(N * S ** 3))
+    # partition of unity: the splat conserves mass per batch item
+    m_in = go.double().sum(dim=(1, 2, 3, 4))
+    m_out = dI.double().sum(dim=(1, 2, 3, 4))
+    assert torch.allclose(m_in, m_out, rtol=0, atol=1e-5 * go.double().abs().sum().item() / N)
+    # linearity of the splat in grad_out
+    dI2, _ = ext.interp_backward(2.5 * go, I, u, 1.0, True, False)
+    assert torch.allclose(dI2, 2.5 * dI, rtol=1e-5, atol=1e-5 * dI.abs().max().item())
+    # LDS-privatised vs plain global atomics, and vector vs scalar kernels
+    ext.set_splat_mode(0)
+    try:
+        dI0, du0 = ext.interp_backward(go, I, u, 1.0, True, True)
+    finally:
+        ext.set_splat_mode(1)
+    assert torch.equal(du0, du)
+    assert (dI0 - dI).abs().max().item() <= 1e-5 * dI.abs().max().item()
+    ext.set_vector_kernels(0)
+    try:
+        assert torch.equal(ext.interp_forward(I, u, 1.0), out)
+    finally:
+        ext.set_vector_kernels(1)
+    # identity displacement is the identity map, exactly
+    assert torch.equal(ext.interp_forward(I, torch.zeros_like(u), 1.0), I)
+    # spot check of one batch item's corner block against the oracle (bit-exact: the block's
+    # samples may reach outside it, so compare where the oracle on the full item agrees)
+    n = 3
+    want = orc.interp_forward(I[n:n + 1].cpu().numpy(), u[n:n + 1].cpu().numpy(), 1.0)
+    assert np.array_equal(out[n:n + 1].cpu().numpy(), want)
+
+
+def test_config2_fluid_metric_batch8(lm):
+    """configs[2]: FluidMetric sharp/flat on 3 x 128^3 momentum fields, batch 8."""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    m = torch.randn((8, 3, 128, 128, 128), device="cuda", generator=g)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    v = met.sharp(m)
+    back = met.flat(v)
+    assert (back - m).abs().max().item() <= 1e-3  # the reference's own tolerance (test_metric.py:58-60)
+    assert (back - m).abs().max().item() <= 2e-4 * m.abs().max().item()
+    # self-adjoint: <sharp(a), b> = <a, sharp(b)>
+    b = torch.randn(m.shape, device="cuda", generator=g)
+    l = (v.double() * b.double()).sum().item()
+    r = (m.double() * met.sharp(b).double()).sum().item()
+    assert abs(l - r) <= 1e-4 * abs(l)
+    # zero frequency: sum(sharp(m)) = sum(m) / gamma^2 per component (SURVEY 8c cross-check)
+    s_in = m.double().sum(dim=(2, 3, 4))
+    s_out = v.double().sum(dim=(2, 3, 4))
+    assert torch.allclose(s_out, s_in / 0.01 ** 2, rtol=1e-3)
+
+
+def test_config3_expmap_batch32(lm):
+    """configs[3]: lddmm.expmap, 10 Euler steps, batch 32 of 128^3."""
+    metric = lm.FluidMetric([1.0, 0.1, 0.01])
+    with torch.no_grad():
+        z = torch.zeros((32, 3, 128, 128, 128), device="cuda")
+        h = lm.expmap(metric, z, num_steps=10)
+        assert torch.equal(h, z)  # expmap(0) = 0 (test_lddmm.py:46-51)
+        del h, z
+        g = torch.Generator(device="cuda").manual_seed(13)
+        m = smooth((4, 3, 128, 128, 128), 4.0, g)
+        m = m * (2.0 / lm.FluidMetric([0.1, 0.0, 0.01]).sharp(m).abs().max())
+        met = lm.FluidMetric([0.1, 0.0, 0.01])
+        h = lm.expmap(met, m, num_steps=10)
+        assert torch.isfinite(h).all() and 0.5 < h.abs().max().item() < 10
+        # batch items are independent: shooting a sub-batch gives the same displacement
+        h2 = lm.expmap(met, m[1:3].contiguous(), num_steps=10)
+        assert torch.allclose(h2, h[1:3], rtol=1e-4, atol=1e-5)
+        # first Euler step from the identity: h1 = -dt * sharp(m)
+        h1 = lm.EPDiff_step(met, m, 0.1, torch.zeros_like(m))
+        assert torch.allclose(h1, -0.1 * met.sharp(m), rtol=1e-5, atol=1e-6)
+
+
+def test_jtv_adjoint_identities_128cubed(lm):
+    """testing/test_diff.py:67-93 at 2 x 3 x 128^3 (fp32, accumulated in fp64)."""
+    g = torch.Generator(device="cuda").manual_seed(14)
+    sh = (2, 3, 128, 128, 128)
+    a, u, v = (torch.randn(sh, device="cuda", generator=g) for _ in range(3))
+    for disp in (True, False):
+        l = (lm.jacobian_times_vectorfield(a, u, displacement=disp, transpose=False).double() * v.double()).sum().item()
+        r = (u.double() * lm.jacobian_times_vectorfield(a, v, displacement=disp, transpose=True).double()).sum().item()
+        assert abs(l - r) <= 1e-5 * max(abs(l), 1e3)
+    l = (lm.jacobian_times_vectorfield(a, u, displacement=False).double() * v.double()).sum().item()
+    r = (a.double() * lm.jacobian_times_vectorfield_adjoint(v, u).double()).sum().item()
+    assert abs(l - r) <= 1e-5 * max(abs(l), 1e3)
+
+
+def test_atlas_step_gradients_160cubed(lm):
+    """configs[4] shape (160^3, small batch): one lddmm_step runs end to end through the HIP
+    backward kernels and moves both the momenta and the atlas gradient."""
+    g = torch.Generator(device="cuda").manual_seed(15)
+    S = 160
+    base = smooth((1, 1, S, S, S), 3.0, g)
+    imgs = base + 0.05 * torch.randn((2, 1, S, S, S), device="cuda", generator=g)
+    I = base.clone().requires_grad_(True)
+    m = torch.zeros((2, 3, S, S, S), device="cuda")
+    m2, loss, reg = lm.lddmm_step(I, m, imgs, lm.FluidMetric([0.1, 0, 0.01]), 2, integration_steps=3)
+    assert torch.isfinite(loss) and torch.isfinite(I.grad).all() and I.grad.abs().max() > 0
+    assert torch.isfinite(m2).all() and m2.abs().max() > 0
