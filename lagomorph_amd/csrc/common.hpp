@@ -146,9 +146,17 @@ __device__ __forceinline__ int clamp1(int r, int b) { return max(0, min(r, b - 1
 
 // Sample position x + dt*u: computed in double (dt is a double in the
 // reference, cuda/interp.cu:36-37,68-70) and narrowed to R.
+// Cost note: the double path is 4 half-rate instructions per coordinate.  For dt == +-1 (the
+// default of deform.interp) the double result is the exactly rounded sum i +- u, which a single
+// float add produces bit for bit (i < 2^24 is exact in float, one rounding either way), so that
+// case skips the conversions.  `dt` is wave-uniform: the branch is scalar.
 template <typename R>
 __device__ __forceinline__ R sample_pos(int i, double dt, R u) {
-    return (R)__builtin_fma(dt, (double)u, (double)(R)i);
+    if (sizeof(R) == 4) {
+        if (dt == 1.0) return (R)((float)i + (float)u);
+        if (dt == -1.0) return (R)((float)i - (float)u);
+    }
+    return (R)__builtin_fma(dt, (double)u, (double)i);
 }
 
 // Gathers go through buffer loads: a 128-bit descriptor in SGPRs (built from a
@@ -225,7 +233,11 @@ struct Lerp3 {
         const uint32_t rowB = (uint32_t)sz * (uint32_t)sizeof(R);   // uniform
         const uint32_t slabB = (uint32_t)sy * rowB;                  // uniform
         bytes = (uint32_t)sx * slabB;
-        const uint32_t ff = ((uint32_t)fx * (uint32_t)sy + (uint32_t)fy) * rowB + (uint32_t)zb * (uint32_t)sizeof(R);
+        // 24-bit multiplies are full rate, 32-bit ones quarter rate; slabB < 2^24 holds for every
+        // volume whose (y, z) plane is below 16 MiB, the branch is wave-uniform
+        const uint32_t ff = slabB < (1u << 24)
+                                ? __umul24((uint32_t)fx, slabB) + __umul24((uint32_t)fy, rowB) + (uint32_t)zb * (uint32_t)sizeof(R)
+                                : ((uint32_t)fx * (uint32_t)sy + (uint32_t)fy) * rowB + (uint32_t)zb * (uint32_t)sizeof(R);
         const uint32_t dX = cx != fx ? slabB : 0u;
         const uint32_t dY = cy != fy ? rowB : 0u;
         rb[0] = ff;

@@ -45,44 +45,65 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(R *__restrict__ out, co
     }
 }
 
-// 16-byte vectorised 3D variant (see interp_fwd3_vec_kernel in interp.hip): VPL consecutive-z
-// voxels per lane; `gq` is the geometry of the VPL-groups.
-template <typename R, int N>
-struct alignas(sizeof(R) * N) VecN {
-    R e[N];
-};
-
-template <typename R, int VPL>
-__global__ __launch_bounds__(kBlock) void compose3_vec_kernel(R *__restrict__ out, const R *__restrict__ u,
-                                                              const R *__restrict__ v, double ds, double dt, Geom gq) {
-    typedef VecN<R, VPL> V;
-    const Vox vx = locate(gq);
-    if (!vx.valid) return;
-    const int nz = gq.nz * VPL;
-    const size_t nv = (size_t)gq.nvox * VPL;
-    const size_t s = (size_t)vx.s * VPL;
-    const R *un = u + (size_t)vx.n * 3 * nv + s;
-    const R *vn = v + (size_t)vx.n * 3 * nv;
-    R *on = out + (size_t)vx.n * 3 * nv + s;
+// Unrolled 3D variant (see interp_fwd3_unroll_kernel in interp.hip): U slabs of 256 consecutive
+// voxels per workgroup, one voxel of each slab per lane.
+template <typename R, int U>
+__global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__ out, const R *__restrict__ u,
+                                                                 const R *__restrict__ v, double ds, double dt, Geom g,
+                                                                 uint32_t nbx_u, uint32_t nblocks_u) {
+    const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
+    const uint32_t n = Lb / nbx_u;
+    const uint32_t bx = Lb - n * nbx_u;
+    const size_t nv = g.nvox;
+    const R *un = u + (size_t)n * 3 * nv;
+    const R *vn = v + (size_t)n * 3 * nv;
+    R *on = out + (size_t)n * 3 * nv;
     const R dsr = (R)ds, dtr = (R)dt;
-    V uu[3];
+    uint32_t s[U];
+    bool ok[U];
+    R uu[3][U];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) uu[d] = *reinterpret_cast<const V *>(un + (size_t)d * nv);
-    Lerp3<R, false> L[VPL];
+    for (int e = 0; e < U; ++e) {
+        s[e] = (bx * U + e) * kBlock + threadIdx.x;
+        ok[e] = s[e] < g.nvox;
+        if (!ok[e]) s[e] = 0;
 #pragma unroll
-    for (int e = 0; e < VPL; ++e)
-        L[e].setup(sample_pos<R>(vx.i, ds, uu[0].e[e]), sample_pos<R>(vx.j, ds, uu[1].e[e]),
-                   sample_pos<R>(vx.k * VPL + e, ds, uu[2].e[e]), gq.nx, gq.ny, nz);
+        for (int d = 0; d < 3; ++d) uu[d][e] = un[(size_t)d * nv + s[e]];
+    }
+    Lerp3<R, false> L[U];  // nz >= 2 guaranteed by the host: no per-sample thin branch
+    uint32_t ci = 0, cj = 0, ck = 0;
+    const uint32_t qj = (uint32_t)kBlock / (uint32_t)g.nz, rk = (uint32_t)kBlock % (uint32_t)g.nz;  // uniform
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+        // (i, j, k) of slab e: one fast division for e = 0, then +256 voxels per slab as
+        // (+qj rows, +rk voxels) with at most one carry each (host guarantees qj + 1 < ny)
+        if (e == 0) {
+            ci = g.dyz.div(s[0]);
+            const uint32_t r = s[0] - ci * (uint32_t)(g.ny * g.nz);
+            cj = g.dz.div(r);
+            ck = r - cj * (uint32_t)g.nz;
+        } else {
+            ck += rk;
+            cj += qj;
+            if (ck >= (uint32_t)g.nz) { ck -= g.nz; ++cj; }
+            if (cj >= (uint32_t)g.ny) { cj -= g.ny; ++ci; }
+        }
+        const uint32_t i = ci, j = cj, k = ck;
+        L[e].setup(sample_pos<R>((int)i, ds, uu[0][e]), sample_pos<R>((int)j, ds, uu[1][e]),
+                   sample_pos<R>((int)k, ds, uu[2][e]), g.nx, g.ny, g.nz);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        V o;
+        R o[U];
 #pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-            const R a = dsr * uu[c].e[e];
+        for (int e = 0; e < U; ++e) {
+            const R a = dsr * uu[c][e];
             const R b = dtr * L[e].value(vn + (size_t)c * nv);
-            o.e[e] = a + b;
+            o[e] = a + b;
         }
-        *reinterpret_cast<V *>(on + (size_t)c * nv) = o;
+#pragma unroll
+        for (int e = 0; e < U; ++e)
+            if (ok[e]) on[(size_t)c * nv + s[e]] = o[e];
     }
 }
 
@@ -95,12 +116,15 @@ static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, in
     if (g.nblocks == 0) return LAGO_OK;
     if (!out || !u || !v) return fail_invalid("compose: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    constexpr int VPL = 16 / sizeof(R);
-    Geom gq;
-    if (dim == 3 && g_interp_vec && nz % VPL == 0 && nz >= 2 * VPL &&
-        (((uintptr_t)out | (uintptr_t)u | (uintptr_t)v) & 15) == 0 && make_geom(gq, 3, nn, nx, ny, nz / VPL)) {
-        hipLaunchKernelGGL((compose3_vec_kernel<R, VPL>), dim3(gq.nblocks), dim3(kBlock), 0, s, out, u, v, ds, dt, gq);
-        return finish_launch(s, "compose");
+    constexpr int U = 4;
+    if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
+        const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
+        const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
+        if (nb < (1ull << 31)) {
+            hipLaunchKernelGGL((compose3_unroll_kernel<R, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, u, v, ds, dt,
+                               g, nbx_u, (uint32_t)nb);
+            return finish_launch(s, "compose");
+        }
     }
     if (dim == 3)
         hipLaunchKernelGGL((compose_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, u, v, ds, dt, g);

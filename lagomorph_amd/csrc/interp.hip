@@ -9,6 +9,8 @@
 
 namespace lago {
 
+int g_dbg_variant = 0;  // profiling only (tools/): 0 = production
+
 // ------------------------------------------------------------------ forward
 
 template <typename R, int DIM, bool BC>
@@ -36,44 +38,70 @@ __global__ __launch_bounds__(kBlock) void interp_fwd_kernel(R *__restrict__ out,
     }
 }
 
-// Vectorised 3D forward: each lane owns VPL consecutive-z voxels (one 16-byte load per
-// displacement component, one 16-byte store per channel) and issues the 4*VPL pair gathers of a
-// channel back to back.  The scalar kernel above is latency-bound (two dependent memory round
-// trips per wave with 256 bytes in flight); this one keeps VPL times more bytes in flight per
-// wave.  Requires nz % VPL == 0 and 16-byte aligned tensors; `gq` is the geometry of the
-// VPL-groups (nz / VPL along z).
-template <typename R, int N>
-struct alignas(sizeof(R) * N) VecN {
-    R e[N];
-};
-
-template <typename R, bool BC, int VPL>
-__global__ __launch_bounds__(kBlock) void interp_fwd3_vec_kernel(R *__restrict__ out, const R *__restrict__ I,
-                                                                 const R *__restrict__ u, double dt, int nc,
-                                                                 Geom gq) {
-    typedef VecN<R, VPL> V;
-    const Vox v = locate(gq);
-    if (!v.valid) return;
-    const int nz = gq.nz * VPL;
-    const size_t nv = (size_t)gq.nvox * VPL;
-    const size_t s = (size_t)v.s * VPL;
-    const R *un = u + (size_t)v.n * 3 * nv + s;
-    const R *In = BC ? I : I + (size_t)v.n * nc * nv;
-    R *on = out + (size_t)v.n * nc * nv + s;
-    const V ux = *reinterpret_cast<const V *>(un);
-    const V uy = *reinterpret_cast<const V *>(un + nv);
-    const V uz = *reinterpret_cast<const V *>(un + 2 * nv);
-    Lerp3<R, false> L[VPL];
+// Unrolled 3D forward: a workgroup processes U slabs of 256 consecutive voxels, each lane one
+// voxel of every slab.  The scalar kernel above is latency-bound (two dependent memory round trips
+// per wave with 256 bytes in flight); giving each lane U *consecutive* voxels instead (16-byte
+// vectors) fixes that but spreads a wave's gather over 1 KiB, and PMC counters showed the kernel
+// then bound by L1 (TCP) line accesses: 652 per wave, one per clock per CU = the kernel time.
+// With slab-interleaved voxels every load and every gather of a wave covers ~256 contiguous bytes
+// (a few L1 lines), and the U * 4 pair gathers of a channel are still issued back to back.
+template <typename R, bool BC, int U>
+__global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restrict__ out, const R *__restrict__ I,
+                                                                    const R *__restrict__ u, double dt, int nc,
+                                                                    Geom g, uint32_t nbx_u, uint32_t nblocks_u, int dbg) {
+    const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
+    const uint32_t n = Lb / nbx_u;  // uniform: scalar division
+    const uint32_t bx = Lb - n * nbx_u;
+    const size_t nv = g.nvox;
+    const R *un = u + (size_t)n * 3 * nv;
+    const R *In = BC ? I : I + (size_t)n * nc * nv;
+    R *on = out + (size_t)n * nc * nv;
+    uint32_t s[U];
+    bool ok[U];
+    R ux[U], uy[U], uz[U];
 #pragma unroll
-    for (int e = 0; e < VPL; ++e)
-        L[e].setup(sample_pos<R>(v.i, dt, ux.e[e]), sample_pos<R>(v.j, dt, uy.e[e]),
-                   sample_pos<R>(v.k * VPL + e, dt, uz.e[e]), gq.nx, gq.ny, nz);
+    for (int e = 0; e < U; ++e) {
+        s[e] = (bx * U + e) * kBlock + threadIdx.x;
+        ok[e] = s[e] < g.nvox;
+        if (!ok[e]) s[e] = 0;
+        ux[e] = un[s[e]];
+        uy[e] = un[nv + s[e]];
+        uz[e] = un[2 * nv + s[e]];
+    }
+    Lerp3<R, false> L[U];  // nz >= 2 guaranteed by the host: no per-sample thin branch
+    uint32_t ci = 0, cj = 0, ck = 0;
+    const uint32_t qj = (uint32_t)kBlock / (uint32_t)g.nz, rk = (uint32_t)kBlock % (uint32_t)g.nz;  // uniform
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+        // (i, j, k) of slab e: one fast division for e = 0, then +256 voxels per slab as
+        // (+qj rows, +rk voxels) with at most one carry each (host guarantees qj + 1 < ny)
+        if (e == 0) {
+            ci = g.dyz.div(s[0]);
+            const uint32_t r = s[0] - ci * (uint32_t)(g.ny * g.nz);
+            cj = g.dz.div(r);
+            ck = r - cj * (uint32_t)g.nz;
+        } else {
+            ck += rk;
+            cj += qj;
+            if (ck >= (uint32_t)g.nz) { ck -= g.nz; ++cj; }
+            if (cj >= (uint32_t)g.ny) { cj -= g.ny; ++ci; }
+        }
+        const uint32_t i = ci, j = cj, k = ck;
+        L[e].setup(sample_pos<R>((int)i, dt, ux[e]), sample_pos<R>((int)j, dt, uy[e]), sample_pos<R>((int)k, dt, uz[e]),
+                   g.nx, g.ny, g.nz);
+    }
     for (int c = 0; c < nc; ++c) {
         const R *Ic = In + (size_t)c * nv;
-        V o;
+        R o[U];
 #pragma unroll
-        for (int e = 0; e < VPL; ++e) o.e[e] = L[e].value(Ic);
-        *reinterpret_cast<V *>(on + (size_t)c * nv) = o;
+        for (int e = 0; e < U; ++e) {
+            if (dbg == 0) o[e] = L[e].value(Ic);
+            else if (dbg == 1) o[e] = Ic[s[e]] * L[e].t;            // profiling: coalesced load instead of gathers
+            else o[e] = L[e].t + L[e].u + L[e].v;                  // profiling: no image access at all
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e)
+            if (ok[e]) on[(size_t)c * nv + s[e]] = o[e];
     }
 }
 
@@ -187,17 +215,19 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
     if (g.nblocks == 0 || nc == 0) return LAGO_OK;  // empty batch / no channels: nothing to write
     if (!out || !I || !u) return fail_invalid("interp_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    constexpr int VPL = 16 / sizeof(R);
-    Geom gq;
-    if (dim == 3 && g_interp_vec && nz % VPL == 0 && nz >= 2 * VPL &&
-        (((uintptr_t)out | (uintptr_t)I | (uintptr_t)u) & 15) == 0 && make_geom(gq, 3, nn, nx, ny, nz / VPL)) {
-        if (bc)
-            hipLaunchKernelGGL((interp_fwd3_vec_kernel<R, true, VPL>), dim3(gq.nblocks), dim3(kBlock), 0, s, out, I, u,
-                               dt, (int)nc, gq);
-        else
-            hipLaunchKernelGGL((interp_fwd3_vec_kernel<R, false, VPL>), dim3(gq.nblocks), dim3(kBlock), 0, s, out, I,
-                               u, dt, (int)nc, gq);
-        return finish_launch(s, "interp_forward");
+    constexpr int U = 4;
+    if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
+        const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
+        const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
+        if (nb < (1ull << 31)) {
+            if (bc)
+                hipLaunchKernelGGL((interp_fwd3_unroll_kernel<R, true, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out,
+                                   I, u, dt, (int)nc, g, nbx_u, (uint32_t)nb, g_dbg_variant);
+            else
+                hipLaunchKernelGGL((interp_fwd3_unroll_kernel<R, false, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out,
+                                   I, u, dt, (int)nc, g, nbx_u, (uint32_t)nb, g_dbg_variant);
+            return finish_launch(s, "interp_forward");
+        }
     }
 #define LAUNCH(D, B) \
     hipLaunchKernelGGL((interp_fwd_kernel<R, D, B>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, u, dt, (int)nc, g)
@@ -278,6 +308,7 @@ static int hessdiag_impl(R *out, const R *u, double dt, int64_t nI, int64_t nn, 
 }  // namespace lago
 
 extern "C" {
+void lago_debug_interp_variant(int v) { lago::g_dbg_variant = v; }  // profiling only
 #define LAGO_DEFINE(REAL, SUF)                                                                                     \
     int lago_interp_forward##SUF(REAL *out, const REAL *I, const REAL *u, double dt, int dim, int64_t nn,         \
                                  int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc, void *stream) {          \
