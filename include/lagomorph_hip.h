@@ -58,8 +58,10 @@ int lago_get_splat_mode(void);
  * whole rows when nz <= 192), window margins MX MY MZ, threads per workgroup
  * (256 / 512 / 1024).  Affects speed only, never results. */
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
-/* 1 (default): use the 16-byte vectorised 3D kernels when nz and alignment allow; 0: scalar kernels only. */
+/* 1 (default): use the 4x-unrolled 3D gather kernels when the shape allows; 0: one-voxel-per-lane kernels only. */
 void lago_set_vector_kernels(int on);
+/* 1 (default): lago_fluid_metric uses the fused x-axis pass (float32, 3D, nx in {64,128,256}); 0: plain 3D hipFFT. */
+void lago_set_fluid_xpass(int on);
 
 #define LAGO_DECLARE(REAL, SUF)                                                                                      \
     /* interp_forward (extension.cpp:135-143 -> cuda/interp.cu:80-130):                                           \

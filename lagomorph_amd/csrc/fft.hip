@@ -12,6 +12,8 @@
 // work memory once, the calls themselves allocate nothing.
 #include <hipfft/hipfft.h>
 
+#include <string.h>
+
 #include <mutex>
 #include <vector>
 
@@ -23,6 +25,26 @@ template <typename R>
 int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
                         const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim,
                         int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream, double scale);  // metric.hip
+
+// fftx.hip
+int fluid_coef_launch(float *tab, int inverse, const float *cosX, const float *sinX, const float *cosY,
+                      const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta,
+                      double gamma, int64_t nx, int64_t ny, int64_t nzc, hipStream_t s);
+bool fluid_xpass_supported(int64_t nx);
+int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int64_t nx, int64_t ny, int64_t nzc,
+                       double scale, hipStream_t s);
+int g_fluid_xpass = 1;  // 1: use the fused x-axis pass where supported
+
+// Operator coefficient tables (see fftx.hip), cached like the FFT plans: one device buffer per
+// (shape, parameters, direction, LUT identity), filled by a kernel on first use.
+struct CoefTab {
+    int64_t nx, ny, nzc;
+    int inverse, device;
+    double a, b, g;
+    const void *luts[6];
+    float *d;
+};
+static std::vector<CoefTab> g_tabs;
 
 struct FftPlan {
     int dim, n[3], batch, dbl, device;
@@ -59,6 +81,59 @@ static int get_plan(FftPlan &out, int dim, const int *n, int batch, int dbl) {
     return LAGO_OK;
 }
 
+static int get_coef(float *&tab, int inverse, const float *cosX, const float *sinX, const float *cosY,
+                    const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta, double gamma,
+                    int64_t nx, int64_t ny, int64_t nzc, hipStream_t s) {
+    int device = 0;
+    LAGO_HIP_TRY(hipGetDevice(&device));
+    const void *l[6] = {cosX, sinX, cosY, sinY, cosZ, sinZ};
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (const CoefTab &t : g_tabs)
+        if (t.nx == nx && t.ny == ny && t.nzc == nzc && t.inverse == inverse && t.device == device && t.a == alpha &&
+            t.b == beta && t.g == gamma && !memcmp(t.luts, l, sizeof(l))) {
+            tab = t.d;
+            return LAGO_OK;
+        }
+    CoefTab t{nx, ny, nzc, inverse, device, alpha, beta, gamma, {cosX, sinX, cosY, sinY, cosZ, sinZ}, nullptr};
+    LAGO_HIP_TRY(hipMalloc((void **)&t.d, (size_t)nx * ny * nzc * 6 * sizeof(float)));
+    int rc = fluid_coef_launch(t.d, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, s);
+    if (rc != LAGO_OK) return rc;
+    if (g_tabs.size() >= 16) {  // bounded cache
+        (void)hipFree(g_tabs.front().d);
+        g_tabs.erase(g_tabs.begin());
+    }
+    g_tabs.push_back(t);
+    tab = t.d;
+    return LAGO_OK;
+}
+
+// float32, 3D, power-of-two nx: rocFFT does the (y, z) transforms as a batched 2D real plan, the
+// x transform + operator + inverse x transform are one kernel (fftx.hip).
+static int fluid_metric_xpass(float *out, const float *m, float *work, int inverse, const float *cosX,
+                              const float *sinX, const float *cosY, const float *sinY, const float *cosZ,
+                              const float *sinZ, double alpha, double beta, double gamma, int64_t nn, int64_t nx,
+                              int64_t ny, int64_t nz, hipStream_t s) {
+    const int n2[3] = {(int)ny, (int)nz, 0};
+    FftPlan p;
+    int rc = get_plan(p, 2, n2, (int)(nn * 3 * nx), 0);
+    if (rc != LAGO_OK) return rc;
+    const int64_t nzc = nz / 2 + 1;
+    float *tab = nullptr;
+    rc = get_coef(tab, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, s);
+    if (rc != LAGO_OK) return rc;
+    hipfftResult r = hipfftSetStream(p.fwd, s);
+    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftSetStream");
+    r = hipfftSetStream(p.inv, s);
+    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftSetStream");
+    r = hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work);
+    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecR2C(2D)");
+    rc = fluid_xpass_launch(work, tab, inverse, nn, nx, ny, nzc, 1.0 / ((double)nx * (double)ny * (double)nz), s);
+    if (rc != LAGO_OK) return rc;
+    r = hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out);
+    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecC2R(2D)");
+    return finish_launch(s, "fluid_metric");
+}
+
 template <typename R>
 static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *cosX, const R *sinX, const R *cosY,
                              const R *sinY, const R *cosZ, const R *sinZ, double alpha, double beta, double gamma,
@@ -69,6 +144,10 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
         return fail_invalid("fluid_metric: bad extent");
     if (nn == 0) return LAGO_OK;
     if (!out || !m || !work) return fail_invalid("fluid_metric: null pointer");
+    if (sizeof(R) == 4 && dim == 3 && g_fluid_xpass && fluid_xpass_supported(nx) && nn * 3 * nx < (1ll << 31))
+        return fluid_metric_xpass((float *)out, (const float *)m, (float *)work, inverse, (const float *)cosX,
+                                  (const float *)sinX, (const float *)cosY, (const float *)sinY, (const float *)cosZ,
+                                  (const float *)sinZ, alpha, beta, gamma, nn, nx, ny, nz, (hipStream_t)stream);
     const int n[3] = {(int)nx, (int)ny, (int)nz};
     FftPlan p;
     int rc = get_plan(p, dim, n, (int)(nn * dim), sizeof(R) == 8);
@@ -100,6 +179,7 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
 }  // namespace lago
 
 extern "C" {
+void lago_set_fluid_xpass(int on) { lago::g_fluid_xpass = on ? 1 : 0; }
 #define LAGO_DEFINE(REAL, SUF)                                                                                     \
     int lago_fluid_metric##SUF(REAL *out, const REAL *m, REAL *work, int inverse, const REAL *cosX,               \
                                const REAL *sinX, const REAL *cosY, const REAL *sinY, const REAL *cosZ,            \

@@ -382,3 +382,28 @@ def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
         ext.set_vector_kernels(1)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert_bits(a[0], orc.interp_forward(I, u, 0.9), "vector interp vs oracle")
+
+
+@pytest.mark.parametrize("sp", [(64, 6, 10), (128, 5, 12), (64, 64, 64), (256, 4, 6), (128, 7, 130)])
+@pytest.mark.parametrize("inverse", [True, False])
+def test_fused_x_pass_fluid_metric(ext, sp, inverse):
+    """float32 3D, power-of-two nx: 2D rocFFT + fused (x-FFT, operator, inverse x-FFT) kernel vs the
+    plain hipFFT 3D path and vs the oracle (numpy FFT)."""
+    import ctypes
+    import lagomorph_amd as lm
+
+    ext._lib.lago_set_fluid_xpass.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(hash((sp, inverse)) % 2**31)
+    m = rnd(rng, (2, 3) + sp, torch.float32)
+    md = dev(m)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    f = met.sharp if inverse else met.flat
+    fused = f(md)
+    ext._lib.lago_set_fluid_xpass(0)
+    try:
+        plain = f(md)
+    finally:
+        ext._lib.lago_set_fluid_xpass(1)
+    want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
+    assert_close(fused, want, torch.float32, "x-pass fluid metric vs oracle", mult=10.0)
+    assert_close(fused, host(plain), torch.float32, "x-pass vs plain hipFFT", mult=10.0)
