@@ -293,11 +293,11 @@ def main():
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and B == 32 and S == 128:
-                rec = json.load(open(tpath)).get("lago::interp_fwd3_vec_kernel<float, false, 4>")
+                rec = json.load(open(tpath)).get("lago::interp_fwd3_unroll_kernel<float, false, 4>")
                 if rec:
                     traffic, tsrc = rec["traffic_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc, same workload)"
             result["roofline"] = {
-                "kernel": "interp_fwd3_vec_kernel<float,false,4> (C=3)", "bound": "hbm", "achieved": ach,
+                "kernel": "interp_fwd3_unroll_kernel<float,false,4> (C=3)", "bound": "hbm", "achieved": ach,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": tsrc,
                 "bytes_per_launch": bytes_per_launch, "mean_launch_ms": k["mean_ms"], "launches": k["launches"],

@@ -68,7 +68,6 @@ template <typename R, bool BC, bool NEED_U, int NT, int VPL>
 __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R *__restrict__ d_u,
                                                          const R *__restrict__ go, const R *__restrict__ I,
                                                          const R *__restrict__ u, double dt, int nc, TileGeom tg) {
-    typedef SVec<R, VPL> V;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     double *win = reinterpret_cast<double *>(lago_smem);  // f64 accumulators: see the header note
     const int nx = tg.nx, ny = tg.ny, nz = tg.nz;
@@ -103,7 +102,6 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const int wy0 = max(0, min(y0 + offy - tg.MY, ny - wey));
     const int wz0 = max(0, min((z0 + offz - tg.MZ) & ~15, nz - wez));
     const int WY = tg.WY, WZ = tg.WZ;
-    const int TZq = tg.TZ / VPL;
 
     for (int c = 0; c < nc; ++c) {
         for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0.0;
@@ -111,31 +109,41 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
         const R *Ic = In + (size_t)c * nv;
         R *dIc = dIn + (size_t)c * nv;
         const R *gc = gon + (size_t)c * nv;
-        for (uint32_t t = threadIdx.x; t < tg.tile_groups; t += NT) {
-            const uint32_t a = tg.d_TyTzq.div(t);
-            const uint32_t rr = t - a * (uint32_t)(tg.TY * TZq);
-            const uint32_t b = tg.d_Tzq.div(rr);
-            const uint32_t cq = rr - b * (uint32_t)TZq;
-            const int kk = (int)cq * VPL;
-            if ((int)a >= ex || (int)b >= ey || kk >= ez) continue;  // ez is a multiple of VPL
-            const int i = x0 + a, j = y0 + b, k0 = z0 + kk;
-            const size_t s = ((size_t)i * ny + j) * nz + k0;
-            const V ux = *reinterpret_cast<const V *>(un + s);
-            const V uy = *reinterpret_cast<const V *>(un + s + nv);
-            const V uz = *reinterpret_cast<const V *>(un + s + 2 * nv);
-            const V gv = *reinterpret_cast<const V *>(gc + s);
-            V dux, duy, duz;
-            if (NEED_U && c > 0) {
-                dux = *reinterpret_cast<const V *>(dun + s);
-                duy = *reinterpret_cast<const V *>(dun + s + nv);
-                duz = *reinterpret_cast<const V *>(dun + s + 2 * nv);
+        // VPL voxels per thread per pass, slab-interleaved: voxel e of thread t is tile voxel
+        // t + e*NT, so the lanes of a wave stay z-contiguous for every load, LDS atomic and gather
+        // (lane-consecutive voxels per thread made the LDS atomics 4-way bank conflicted).
+        for (uint32_t t0 = threadIdx.x; t0 < tg.tile_groups; t0 += NT * VPL) {
+            size_t sv[VPL];
+            int vi[VPL], vj[VPL], vk[VPL];
+            bool live[VPL];
+            R ux[VPL], uy[VPL], uz[VPL], gv[VPL], dux[VPL], duy[VPL], duz[VPL];
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) {
+                const uint32_t t = t0 + e * NT;
+                const uint32_t a = tg.d_TyTzq.div(t);
+                const uint32_t rr = t - a * (uint32_t)(tg.TY * tg.TZ);
+                const uint32_t b = tg.d_Tzq.div(rr);
+                const uint32_t cc = rr - b * (uint32_t)tg.TZ;
+                live[e] = t < tg.tile_groups && (int)a < ex && (int)b < ey && (int)cc < ez;
+                vi[e] = x0 + a; vj[e] = y0 + b; vk[e] = z0 + cc;
+                sv[e] = live[e] ? ((size_t)vi[e] * ny + vj[e]) * nz + vk[e] : 0;
+                ux[e] = un[sv[e]];
+                uy[e] = un[sv[e] + nv];
+                uz[e] = un[sv[e] + 2 * nv];
+                gv[e] = gc[sv[e]];
+                if (NEED_U && c > 0) {
+                    dux[e] = dun[sv[e]];
+                    duy[e] = dun[sv[e] + nv];
+                    duz[e] = dun[sv[e] + 2 * nv];
+                }
             }
 #pragma unroll
             for (int e = 0; e < VPL; ++e) {
-                const R hx = sample_pos<R>(i, dt, ux.e[e]);
-                const R hy = sample_pos<R>(j, dt, uy.e[e]);
-                const R hz = sample_pos<R>(k0 + e, dt, uz.e[e]);
-                R diff = gv.e[e];
+                if (!live[e]) continue;
+                const R hx = sample_pos<R>(vi[e], dt, ux[e]);
+                const R hy = sample_pos<R>(vj[e], dt, uy[e]);
+                const R hz = sample_pos<R>(vk[e], dt, uz[e]);
+                R diff = gv[e];
                 // include/interp.h:431-453: floor corner, sequentially flipped weights
                 const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
                 R dx = (R)1.f - (hx - (R)fx);
@@ -168,20 +176,15 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                     dx = (R)1.f - dx;
                 }
                 if (NEED_U) {
-                    Lerp3<R, VPL == 1> Lq;
+                    Lerp3<R> Lq;
                     Lq.setup(hx, hy, hz, nx, ny, nz);
                     R gx, gy, gz;
                     Lq.grad(Ic, gx, gy, gz);
                     diff = (R)((double)diff * dt);  // cuda/interp.cu:230
-                    dux.e[e] = lg_fma(gx, diff, c == 0 ? (R)0 : dux.e[e]);
-                    duy.e[e] = lg_fma(gy, diff, c == 0 ? (R)0 : duy.e[e]);
-                    duz.e[e] = lg_fma(gz, diff, c == 0 ? (R)0 : duz.e[e]);
+                    dun[sv[e]] = lg_fma(gx, diff, c == 0 ? (R)0 : dux[e]);
+                    dun[sv[e] + nv] = lg_fma(gy, diff, c == 0 ? (R)0 : duy[e]);
+                    dun[sv[e] + 2 * nv] = lg_fma(gz, diff, c == 0 ? (R)0 : duz[e]);
                 }
-            }
-            if (NEED_U) {
-                *reinterpret_cast<V *>(dun + s) = dux;
-                *reinterpret_cast<V *>(dun + s + nv) = duy;
-                *reinterpret_cast<V *>(dun + s + 2 * nv) = duz;
             }
         }
         __syncthreads();
@@ -209,7 +212,6 @@ static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, int vpl, size_t 
     TX = TX < g.nx ? TX : g.nx;
     TY = TY < g.ny ? TY : g.ny;
     TZ = TZ < g.nz ? TZ : g.nz;
-    TZ = ((TZ + vpl - 1) / vpl) * vpl;  // whole VPL-groups (vpl > 1 only when nz % vpl == 0)
     tg.nx = g.nx; tg.ny = g.ny; tg.nz = g.nz;
     tg.TX = TX; tg.TY = TY; tg.TZ = TZ;
     // window = tile extent + 1 (ceil corner) + a margin on both sides of the probed origin
@@ -228,13 +230,13 @@ static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, int vpl, size_t 
     int64_t total = (int64_t)tg.tiles_per_item * nn;
     if (total >= (1ll << 31)) return false;
     tg.total = (uint32_t)total;
-    tg.tile_groups = (uint32_t)TX * TY * (TZ / vpl);
+    tg.tile_groups = (uint32_t)TX * TY * TZ;  // voxels per tile
     tg.ablate = g_ablate;
     tg.d_tiles = FastDiv(tg.tiles_per_item);
     tg.d_tyz = FastDiv(tg.nty * tg.ntz);
     tg.d_tz = FastDiv(tg.ntz);
-    tg.d_TyTzq = FastDiv((uint32_t)(TY * (TZ / vpl)));
-    tg.d_Tzq = FastDiv((uint32_t)(TZ / vpl));
+    tg.d_TyTzq = FastDiv((uint32_t)(TY * TZ));
+    tg.d_Tzq = FastDiv((uint32_t)TZ);
     tg.d_WyWz = FastDiv((uint32_t)(tg.WY * tg.WZ));
     tg.d_Wz = FastDiv((uint32_t)tg.WZ);
     return true;
@@ -277,9 +279,8 @@ static hipError_t dispatch_tiled(R *d_I, R *d_u, const R *go, const R *I, const 
 template <typename R>
 int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
                         const Geom &g, bool bc, bool need_u, hipStream_t s) {
-    constexpr int VPLmax = 16 / sizeof(R);
-    const bool vec = g_interp_vec && g.nz % VPLmax == 0 &&
-                     (((uintptr_t)d_u | (uintptr_t)go | (uintptr_t)u) & 15) == 0;
+    constexpr int VPLmax = 4;
+    const bool vec = g_interp_vec != 0;
     TileGeom tg;
     size_t smem;
     int nt;

@@ -18,7 +18,7 @@ import itertools
 for mode in (1,):
   ext.set_splat_mode(mode)
   print("splat mode", mode)
-  for cfg in ((8, 8, 32, 1, 1, 4, 512), (8, 4, 32, 1, 1, 4, 256), (16, 8, 64, 1, 1, 4, 1024)):
+  for cfg in ((8, 8, 32, 1, 1, 4, 512), (8, 8, 32, 1, 1, 4, 256), (8, 4, 32, 1, 1, 4, 256), (16, 8, 64, 1, 1, 4, 1024), (8, 8, 64, 1, 1, 4, 512), (4, 4, 64, 1, 1, 4, 256), (4, 4, 128, 1, 1, 4, 512)):
     ext.set_splat_tile(*cfg)
     row = []
     for mask, name in ((0, "full"), (1, "-lds"), (2, "-fallback"), (4, "-flush"), (7, "-all")):
