@@ -118,7 +118,7 @@ def test_tiled_splat_any_tile_config(ext, dtype, tile):
         try:
             dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 1.0, True, True)
         finally:
-            ext.set_splat_tile(8, 8, 32, 1, 1, 4, 512)
+            ext.set_splat_tile(16, 8, 64, 1, 1, 4, 1024)
             ext.set_splat_mode(1)
         assert_bits(du, ou, f"d_u mode {mode}")
         assert_close(dI, oI, dtype, f"d_I mode {mode}", mult=4.0)
