@@ -155,6 +155,47 @@ def micro_fluid(lm, dev, size, batch=8):
     }
 
 
+def micro_ops(lm, dev, size, batch=8):
+    """Every other operator of the path at batch 8 x 3 x size^3 fp32 (smooth displacement): median ms and
+    algorithmic GB/s (each tensor counted once)."""
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device=dev).manual_seed(99)
+    sh = (batch, 3, size, size, size)
+    v, w, go = (torch.randn(sh, device=dev, generator=g) for _ in range(3))
+    u = gaussian_blur(torch.randn(sh, device=dev, generator=g), 8.0)
+    u = u * (4.0 / u.abs().max())
+    I1 = torch.randn((batch, 1, size, size, size), device=dev, generator=g)
+    A = (torch.eye(3, device=dev)[None] + 0.05 * torch.randn((batch, 3, 3), device=dev, generator=g)).contiguous()
+    T = torch.randn((batch, 3), device=dev, generator=g)
+    V = batch * size ** 3
+    half = [size // 2] * 3
+    origin = [(size - 1) * 0.5] * 3
+    spacing = [(size - 1) / (size // 2 - 1)] * 3
+    small = torch.randn((batch, 3, *half), device=dev, generator=g)
+    ops = {
+        "jtv_forward(disp)": (lambda: ext.jacobian_times_vectorfield_forward(v, w, True, False), 36),
+        "jtv_forward(transpose)": (lambda: ext.jacobian_times_vectorfield_forward(v, w, False, True), 36),
+        "jtv_backward": (lambda: ext.jacobian_times_vectorfield_backward(go, v, w, True, False, True, True), 60),
+        "jtv_adjoint_forward": (lambda: ext.jacobian_times_vectorfield_adjoint_forward(v, w), 36),
+        "jtv_adjoint_backward": (lambda: ext.jacobian_times_vectorfield_adjoint_backward(go, v, w, True, True), 60),
+        "interp_forward(C=3)": (lambda: ext.interp_forward(v, u, 1.0), 36),
+        "interp_backward(C=3)": (lambda: ext.interp_backward(go, v, u, 1.0, True, True), 60),
+        "compose": (lambda: ext.compose(u, v, -0.1, 1.0), 36),
+        "affine_interp_forward(C=1)": (lambda: ext.affine_interp_forward(I1, A, T), 8),
+        "affine_interp_backward(C=1)": (lambda: ext.affine_interp_backward(I1, I1, A, T, True, True, True), 12),
+        "regrid_forward(64^3->128^3,C=3)": (lambda: ext.regrid_forward(small, [size] * 3, [(size // 2 - 1) * 0.5] * 3,
+                                                                        [(size // 2 - 1) / (size - 1)] * 3), 12 + 1.5),
+        "regrid_backward(128^3->64^3,C=3)": (lambda: ext.regrid_backward(v, half, [size] * 3, [(size // 2 - 1) * 0.5] * 3,
+                                                                          [(size // 2 - 1) / (size - 1)] * 3), 12 + 1.5),
+    }
+    out = {"workload": f"batch {batch} x 3x{size}^3 fp32, median of 10", "ops": {}}
+    for name, (fn, bpv) in ops.items():
+        med, _ = time_op(fn, reps=10, warm=3)
+        out["ops"][name] = {"ms": med, "alg_bytes_per_voxel": bpv, "GBps": bpv * V / med / 1e6,
+                            "frac_of_hbm_peak": bpv * V / med / 1e6 / HBM_PEAK_GBPS}
+    return out
+
+
 def cpu_baseline(size, euler_steps, sample_batch=1):
     """Times the CPU oracle (test infrastructure, 1 thread) on a bounded sample of the headline
     workload: `sample_batch` volumes of size^3, one expmap of `euler_steps` steps.  The oracle
@@ -205,7 +246,7 @@ def main():
     ap.add_argument("--euler-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -309,6 +350,8 @@ def main():
             result["interp_splat"] = micro_interp_splat(ext, dev, S)
             torch.cuda.empty_cache()
             result["fluid"] = micro_fluid(lm, dev, S)
+            torch.cuda.empty_cache()
+            result["other_ops"] = micro_ops(lm, dev, S)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S, E, args.cpu_sample_batch)
         print(json.dumps(result))

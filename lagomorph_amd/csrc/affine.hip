@@ -15,6 +15,14 @@
 
 namespace lago {
 
+// splat.hip
+template <typename R>
+int affine_splat_lds(R *d_I, const R *go, const R *A, const R *T, int nc, int64_t nn, const Geom &g, bool bc,
+                     hipStream_t s);
+template <typename R>
+int regrid_splat_lds(R *d_I, const R *go, int64_t nplanes, const Geom &g, const Geom &gs, const double *O,
+                     const double *S, hipStream_t s);
+
 template <typename R>
 __device__ __forceinline__ R half_extent(int n) {  // `.5*static_cast<Real>(n-1)`, cuda/affine.cu:42-43
     return (R)(.5 * (double)(R)(n - 1));
@@ -69,11 +77,25 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I,
                                                             const R *__restrict__ T, int nc, Geom g) {
     constexpr int NP = DIM * DIM + DIM;
     __shared__ R red[kBlock / 64][NP];
-    const Vox v = locate(g);  // v.n is uniform per workgroup
     const size_t nv = g.nvox;
     R p[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) p[q] = 0;
+    // blockIdx.y = batch item; the x dimension strides over that item's 256-voxel chunks, so the
+    // 12 (6) dA/dT atomics per workgroup come from at most gridDim.x workgroups per item (every
+    // workgroup adding into the same few addresses is ~14x slower than spread atomics)
+    Vox v;
+    v.n = blockIdx.y;
+    for (uint32_t chunk = blockIdx.x; chunk < g.nbx; chunk += gridDim.x) {
+    v.s = chunk * kBlock + threadIdx.x;
+    v.valid = v.s < g.nvox;
+    {
+        const uint32_t sl = v.valid ? v.s : 0;
+        const uint32_t ii = g.dyz.div(sl);
+        const uint32_t rr = sl - ii * (uint32_t)(g.ny * g.nz);
+        const uint32_t jj = g.dz.div(rr);
+        v.i = (int)ii; v.j = (int)jj; v.k = (int)(rr - jj * (uint32_t)g.nz);
+    }
     if (v.valid) {
         const R *An = A + (size_t)v.n * DIM * DIM;
         const R *Tn = T + (size_t)v.n * DIM;
@@ -135,6 +157,7 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I,
             }
         }
     }
+    }  // chunk loop
     if (NEED_A || NEED_T) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -259,10 +282,14 @@ static int affine_forward_impl(R *out, const R *I, const R *A, const R *T, int d
 
 template <typename R, int DIM, bool BC>
 static void launch_affine_bwd(R *d_I, R *d_A, R *d_T, const R *go, const R *I, const R *A, const R *T, int nc,
-                              const Geom &g, bool nI, bool nA, bool nT, hipStream_t s) {
+                              const Geom &g, int64_t nn, bool nI, bool nA, bool nT, hipStream_t s) {
+    // ~4096 workgroups in total, at most one per 256-voxel chunk
+    uint32_t gx = (uint32_t)((4096 + nn - 1) / nn);
+    if (gx > g.nbx) gx = g.nbx;
+    if (gx < 1) gx = 1;
 #define LAUNCH(a, b, c)                                                                                             \
-    hipLaunchKernelGGL((affine_bwd_kernel<R, DIM, BC, a, b, c>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, d_A, d_T, \
-                       go, I, A, T, nc, g)
+    hipLaunchKernelGGL((affine_bwd_kernel<R, DIM, BC, a, b, c>), dim3(gx, (uint32_t)nn), dim3(kBlock), 0, s, d_I, d_A,  \
+                       d_T, go, I, A, T, nc, g)
     const int m = (nI ? 4 : 0) | (nA ? 2 : 0) | (nT ? 1 : 0);
     switch (m) {
         case 7: LAUNCH(true, true, true); break;
@@ -293,13 +320,20 @@ static int affine_backward_impl(R *d_I, R *d_A, R *d_T, const R *go, const R *I,
     if (need_I && nI) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
     if (need_A && nn) LAGO_HIP_TRY(hipMemsetAsync(d_A, 0, (size_t)nn * dim * dim * sizeof(R), s));
     if (need_T && nn) LAGO_HIP_TRY(hipMemsetAsync(d_T, 0, (size_t)nn * dim * sizeof(R), s));
+    if (nn > 65535) return fail_invalid("affine_interp_backward: batch size above 65535 is not supported");
+    if (g.nblocks && nc && need_I && dim == 3 && g_splat_mode >= 1) {
+        // the image splat goes through the LDS-privatised kernel; d_A / d_T keep the reduction kernel
+        const int rc = affine_splat_lds<R>(d_I, go, A, T, (int)nc, nn, g, bc != 0, s);
+        if (rc < 0) return rc;
+        if (rc == 0) need_I = 0;
+    }
     if (g.nblocks && nc && (need_I || need_A || need_T)) {
         if (dim == 3) {
-            if (bc) launch_affine_bwd<R, 3, true>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
-            else launch_affine_bwd<R, 3, false>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
+            if (bc) launch_affine_bwd<R, 3, true>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, nn, need_I, need_A, need_T, s);
+            else launch_affine_bwd<R, 3, false>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, nn, need_I, need_A, need_T, s);
         } else {
-            if (bc) launch_affine_bwd<R, 2, true>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
-            else launch_affine_bwd<R, 2, false>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, need_I, need_A, need_T, s);
+            if (bc) launch_affine_bwd<R, 2, true>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, nn, need_I, need_A, need_T, s);
+            else launch_affine_bwd<R, 2, false>(d_I, d_A, d_T, go, I, A, T, (int)nc, g, nn, need_I, need_A, need_T, s);
         }
     }
     return finish_launch(s, "affine_interp_backward");
@@ -359,6 +393,13 @@ static int regrid_backward_impl(R *d_I, const R *go, int dim, int64_t nn, int64_
     if ((nI && !d_I) || (nI && g.nblocks && !go)) return fail_invalid("regrid_backward: null pointer");
     if (nI) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
     if (g.nblocks && nn * nc) {
+        if (dim == 3 && g_splat_mode >= 1) {
+            Geom gt;
+            if (make_geom(gt, 3, 1, nx, ny, nz)) {
+                const int rc = regrid_splat_lds<R>(d_I, go, nn * nc, gt, g, rp.O, rp.S, s);
+                if (rc <= 0) return rc;  // done (or failed); 1 = shape left to the plain kernel
+            }
+        }
         if (dim == 3)
             hipLaunchKernelGGL((regrid_bwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, go, (int)(nn * nc), g, rp);
         else

@@ -51,6 +51,29 @@ struct Stencil {
         if (pos[d] == len[d] - 1) return (R)(.5) * lg_fma(a[0], b[0], a[-st] * b[-st]);
         return (R)(-.5) * lg_fma(a[st], b[st], -(a[-st] * b[-st]));
     }
+    // Same formula on values that are already in registers (x0 = centre, xp / xm = the clamped +1 / -1
+    // neighbours along axis d; the clamped side is never used at its border).  The kernels below load
+    // every needed neighbour once up front: all loads are then independent and in flight together,
+    // instead of up to six dependent-on-branch loads per (component, axis) pair.
+    template <typename R>
+    __device__ __forceinline__ R dTv(R a0, R ap, R am, R b0, R bp, R bm, int d) const {
+        if (pos[d] == 0) return (R)(-.5) * lg_fma(a0, b0, ap * bp);
+        if (pos[d] == len[d] - 1) return (R)(.5) * lg_fma(a0, b0, am * bm);
+        return (R)(-.5) * lg_fma(ap, bp, -(am * bm));
+    }
+};
+
+template <typename R, int DIM>
+struct Nb {  // centre and clamped +-1 neighbours along every axis
+    R c0, p[DIM], m[DIM];
+    __device__ __forceinline__ void load(const Stencil<DIM> &st, const R *__restrict__ f) {
+        c0 = f[0];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            p[d] = f[st.plus[d]];
+            m[d] = f[st.minus[d]];
+        }
+    }
 };
 
 template <typename R, int DIM>
@@ -123,17 +146,28 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
             if (DISP) gq[c] = gq[c] + (R)1.0;
             dwn[(size_t)c * nv] = (R)0 + dotw<R, DIM>(gq, gov);
         }
+        Nb<R, DIM> W[DIM], G[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            W[c].load(st, wn + (size_t)c * nv);
+            G[c].load(st, gon + (size_t)c * nv);
+        }
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             R acc = 0;
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) acc = acc + st.dT(wn + (size_t)c * nv, gon + (size_t)d * nv, d);
+            for (int d = 0; d < DIM; ++d)
+                acc = acc + st.dTv(W[c].c0, W[c].p[d], W[c].m[d], G[d].c0, G[d].p[d], G[d].m[d], d);
             dvn[(size_t)c * nv] = acc;
         }
     } else {
         R dw[DIM];
+        Nb<R, DIM> W[DIM];
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) dw[d] = 0;
+        for (int d = 0; d < DIM; ++d) {
+            dw[d] = 0;
+            W[d].load(st, wn + (size_t)d * nv);
+        }
         for (int c = 0; c < nc; ++c) {
             st.grad(vn + (size_t)c * nv, gq);
             if (DISP) {
@@ -144,9 +178,11 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
             const R goc = gon[(size_t)c * nv];
 #pragma unroll
             for (int d = 0; d < DIM; ++d) dw[d] = lg_fma(gq[d], goc, dw[d]);
+            Nb<R, DIM> G;
+            G.load(st, gon + (size_t)c * nv);
             R acc = 0;
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) acc = acc + st.dT(wn + (size_t)d * nv, gon + (size_t)c * nv, d);
+            for (int d = 0; d < DIM; ++d) acc = acc + st.dTv(W[d].c0, W[d].p[d], W[d].m[d], G.c0, G.p[d], G.m[d], d);
             dvn[(size_t)c * nv] = acc;
         }
 #pragma unroll
@@ -166,10 +202,15 @@ __global__ __launch_bounds__(kBlock) void jtv_adj_fwd_kernel(R *__restrict__ out
     const R *zn = z + (size_t)vx.n * nc * nv + vx.s;
     const R *wn = w + (size_t)vx.n * DIM * nv + vx.s;
     R *on = out + (size_t)vx.n * nc * nv + vx.s;
+    Nb<R, DIM> W[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) W[d].load(st, wn + (size_t)d * nv);
     for (int c = 0; c < nc; ++c) {
+        Nb<R, DIM> Z;
+        Z.load(st, zn + (size_t)c * nv);
         R acc = 0;
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) acc = acc + st.dT(wn + (size_t)d * nv, zn + (size_t)c * nv, d);
+        for (int d = 0; d < DIM; ++d) acc = acc + st.dTv(W[d].c0, W[d].p[d], W[d].m[d], Z.c0, Z.p[d], Z.m[d], d);
         on[(size_t)c * nv] = acc;
     }
 }

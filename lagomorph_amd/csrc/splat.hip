@@ -37,8 +37,18 @@
 
 namespace lago {
 
+// How a source voxel's sample position is obtained.
+enum { POS_DISP = 0,     // x + dt*u(x): interp_backward (cuda/interp.cu:185-244)
+       POS_AFFINE = 1,   // A(x - c) + T + c: affine_interp_backward's image splat (cuda/affine.cu:330-536)
+       POS_REGRID = 2 }; // (X - C)S + O: regrid_backward (cuda/affine.cu:767-800)
+struct PosArgs {
+    const void *u, *A, *T;
+    double dt, O[3], S[3];
+};
+
 struct TileGeom {
-    int nx, ny, nz;
+    int nx, ny, nz;      // target grid (d_I, LDS window)
+    int snx, sny, snz;   // source grid (grad_out, tiles); equals the target grid except for regrid
     int TX, TY, TZ;     // source tile (voxels)
     int WX, WY, WZ;     // LDS window (cells)
     int MX, MY, MZ;     // margin below the probed origin
@@ -64,14 +74,40 @@ struct alignas(sizeof(R) * N) SVec {
     R e[N];
 };
 
-template <typename R, bool BC, bool NEED_U, int NT, int VPL>
+template <typename R>
+__device__ __forceinline__ R splat_half_extent(int n) {  // `.5*static_cast<Real>(n-1)`, cuda/affine.cu:42-43
+    return (R)(.5 * (double)(R)(n - 1));
+}
+
+// Sample position of source voxel (i, j, k) for the analytic modes; arithmetic as in affine.hip.
+template <typename R, int MODE>
+__device__ __forceinline__ void analytic_pos(R &hx, R &hy, R &hz, int i, int j, int k, const R *An, const R *Tn,
+                                             const PosArgs &pa, const TileGeom &tg) {
+    if (MODE == POS_AFFINE) {
+        const R ox = splat_half_extent<R>(tg.nx), oy = splat_half_extent<R>(tg.ny), oz = splat_half_extent<R>(tg.nz);
+        const R fi = (R)i - ox, fj = (R)j - oy, fk = (R)k - oz;
+        hx = lg_fma(An[2], fk, lg_fma(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+        hy = lg_fma(An[5], fk, lg_fma(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+        hz = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
+    } else {
+        const R ox = splat_half_extent<R>(tg.snx), oy = splat_half_extent<R>(tg.sny), oz = splat_half_extent<R>(tg.snz);
+        hx = lg_fma((R)i - ox, (R)pa.S[0], (R)pa.O[0]);
+        hy = lg_fma((R)j - oy, (R)pa.S[1], (R)pa.O[1]);
+        hz = lg_fma((R)k - oz, (R)pa.S[2], (R)pa.O[2]);
+    }
+}
+
+template <typename R, int MODE, bool BC, bool NEED_U, int NT, int VPL>
 __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R *__restrict__ d_u,
                                                          const R *__restrict__ go, const R *__restrict__ I,
-                                                         const R *__restrict__ u, double dt, int nc, TileGeom tg) {
+                                                         PosArgs pa, int nc, TileGeom tg) {
     extern __shared__ __align__(16) unsigned char lago_smem[];
     double *win = reinterpret_cast<double *>(lago_smem);  // f64 accumulators: see the header note
     const int nx = tg.nx, ny = tg.ny, nz = tg.nz;
-    const size_t nv = (size_t)nx * ny * nz;
+    const int snx = tg.snx, sny = tg.sny, snz = tg.snz;
+    const size_t nv = (size_t)nx * ny * nz;       // target plane
+    const size_t snv = (size_t)snx * sny * snz;   // source plane
+    const double dt = pa.dt;
 
     // workgroup -> (batch item, tile)
     const uint32_t L = xcd_swizzle(blockIdx.x, tg.total);
@@ -82,25 +118,43 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const uint32_t by = tg.d_tz.div(r);
     const uint32_t bz = r - by * tg.ntz;
     const int x0 = bx * tg.TX, y0 = by * tg.TY, z0 = bz * tg.TZ;
-    const int ex = min(tg.TX, nx - x0), ey = min(tg.TY, ny - y0), ez = min(tg.TZ, nz - z0);
+    const int ex = min(tg.TX, snx - x0), ey = min(tg.TY, sny - y0), ez = min(tg.TZ, snz - z0);
 
-    const R *un = u + (size_t)n * 3 * nv;
+    const R *un = MODE == POS_DISP ? static_cast<const R *>(pa.u) + (size_t)n * 3 * snv : nullptr;
+    const R *An = MODE == POS_AFFINE ? static_cast<const R *>(pa.A) + (size_t)n * 9 : nullptr;
+    const R *Tn = MODE == POS_AFFINE ? static_cast<const R *>(pa.T) + (size_t)n * 3 : nullptr;
     const R *In = BC ? I : I + (size_t)n * nc * nv;
     R *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
-    const R *gon = go + (size_t)n * nc * nv;
+    const R *gon = go + (size_t)n * nc * snv;
     R *dun = NEED_U ? d_u + (size_t)n * 3 * nv : nullptr;
 
-    // window origin: displacement probed at the tile centre minus a margin (placement only
-    // affects speed, never the result)
-    const size_t sc = ((size_t)(x0 + ex / 2) * ny + (y0 + ey / 2)) * nz + (z0 + ez / 2);
-    const float fdt = (float)dt;
-    const int offx = (int)floorf(fdt * (float)un[sc]);
-    const int offy = (int)floorf(fdt * (float)un[sc + nv]);
-    const int offz = (int)floorf(fdt * (float)un[sc + 2 * nv]);
+    // window origin (placement only affects speed, never the result): for a displacement field,
+    // tile origin + displacement probed at the tile centre; for the analytic maps, the minimum over
+    // the images of the tile's 8 corner voxels (exact for affine maps) -- minus a margin
+    int bxo, byo, bzo;
+    if (MODE == POS_DISP) {
+        const size_t sc = ((size_t)(x0 + ex / 2) * ny + (y0 + ey / 2)) * nz + (z0 + ez / 2);
+        const float fdt = (float)dt;
+        bxo = x0 + (int)floorf(fdt * (float)un[sc]);
+        byo = y0 + (int)floorf(fdt * (float)un[sc + nv]);
+        bzo = z0 + (int)floorf(fdt * (float)un[sc + 2 * nv]);
+    } else {
+        R mnx = (R)1e30, mny = (R)1e30, mnz = (R)1e30;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            R hx, hy, hz;
+            analytic_pos<R, MODE>(hx, hy, hz, x0 + ((q & 4) ? ex - 1 : 0), y0 + ((q & 2) ? ey - 1 : 0),
+                                  z0 + ((q & 1) ? ez - 1 : 0), An, Tn, pa, tg);
+            mnx = hx < mnx ? hx : mnx;
+            mny = hy < mny ? hy : mny;
+            mnz = hz < mnz ? hz : mnz;
+        }
+        bxo = lg_floor(mnx); byo = lg_floor(mny); bzo = lg_floor(mnz);
+    }
     const int wex = min(tg.WX, nx), wey = min(tg.WY, ny), wez = min(tg.WZ, nz);
-    const int wx0 = max(0, min(x0 + offx - tg.MX, nx - wex));
-    const int wy0 = max(0, min(y0 + offy - tg.MY, ny - wey));
-    const int wz0 = max(0, min((z0 + offz - tg.MZ) & ~15, nz - wez));
+    const int wx0 = max(0, min(bxo - tg.MX, nx - wex));
+    const int wy0 = max(0, min(byo - tg.MY, ny - wey));
+    const int wz0 = max(0, min((bzo - tg.MZ) & ~15, nz - wez));
     const int WY = tg.WY, WZ = tg.WZ;
 
     for (int c = 0; c < nc; ++c) {
@@ -108,7 +162,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
         __syncthreads();
         const R *Ic = In + (size_t)c * nv;
         R *dIc = dIn + (size_t)c * nv;
-        const R *gc = gon + (size_t)c * nv;
+        const R *gc = gon + (size_t)c * snv;
         // VPL voxels per thread per pass, slab-interleaved: voxel e of thread t is tile voxel
         // t + e*NT, so the lanes of a wave stay z-contiguous for every load, LDS atomic and gather
         // (lane-consecutive voxels per thread made the LDS atomics 4-way bank conflicted).
@@ -126,10 +180,12 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                 const uint32_t cc = rr - b * (uint32_t)tg.TZ;
                 live[e] = t < tg.tile_groups && (int)a < ex && (int)b < ey && (int)cc < ez;
                 vi[e] = x0 + a; vj[e] = y0 + b; vk[e] = z0 + cc;
-                sv[e] = live[e] ? ((size_t)vi[e] * ny + vj[e]) * nz + vk[e] : 0;
-                ux[e] = un[sv[e]];
-                uy[e] = un[sv[e] + nv];
-                uz[e] = un[sv[e] + 2 * nv];
+                sv[e] = live[e] ? ((size_t)vi[e] * sny + vj[e]) * snz + vk[e] : 0;
+                if (MODE == POS_DISP) {
+                    ux[e] = un[sv[e]];
+                    uy[e] = un[sv[e] + nv];
+                    uz[e] = un[sv[e] + 2 * nv];
+                }
                 gv[e] = gc[sv[e]];
                 if (NEED_U && c > 0) {
                     dux[e] = dun[sv[e]];
@@ -140,9 +196,14 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
 #pragma unroll
             for (int e = 0; e < VPL; ++e) {
                 if (!live[e]) continue;
-                const R hx = sample_pos<R>(vi[e], dt, ux[e]);
-                const R hy = sample_pos<R>(vj[e], dt, uy[e]);
-                const R hz = sample_pos<R>(vk[e], dt, uz[e]);
+                R hx, hy, hz;
+                if (MODE == POS_DISP) {
+                    hx = sample_pos<R>(vi[e], dt, ux[e]);
+                    hy = sample_pos<R>(vj[e], dt, uy[e]);
+                    hz = sample_pos<R>(vk[e], dt, uz[e]);
+                } else {
+                    analytic_pos<R, MODE>(hx, hy, hz, vi[e], vj[e], vk[e], An, Tn, pa, tg);
+                }
                 R diff = gv[e];
                 // include/interp.h:431-453: floor corner, sequentially flipped weights
                 const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
@@ -203,34 +264,60 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     }
 }
 
-static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, int vpl, size_t &smem, int &nthreads) {
+// g: target grid; gs: source grid (tiles): the same grid for interp / affine.  sc[d] = how many
+// target cells one source step spans along axis d (1 for a displacement field); when given, the
+// tile is shrunk until its image fits the LDS window.
+static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, const double *sc, size_t &smem,
+                       int &nthreads) {
     int TX = g_tile_cfg[0], TY = g_tile_cfg[1], TZ = g_tile_cfg[2];
     const int EX = g_tile_cfg[3], EY = g_tile_cfg[4], EZ = g_tile_cfg[5];
     nthreads = g_tile_cfg[6] >= 1024 ? 1024 : (g_tile_cfg[6] >= 512 ? 512 : 256);
     if (TX < 1 || TY < 1 || EX < 0 || EY < 0 || EZ < 0) return false;
     if (TZ <= 0) TZ = 32;
-    TX = TX < g.nx ? TX : g.nx;
-    TY = TY < g.ny ? TY : g.ny;
-    TZ = TZ < g.nz ? TZ : g.nz;
+    TX = TX < gs.nx ? TX : gs.nx;
+    TY = TY < gs.ny ? TY : gs.ny;
+    TZ = TZ < gs.nz ? TZ : gs.nz;
     tg.nx = g.nx; tg.ny = g.ny; tg.nz = g.nz;
-    tg.TX = TX; tg.TY = TY; tg.TZ = TZ;
-    // window = tile extent + 1 (ceil corner) + a margin on both sides of the probed origin
+    tg.snx = gs.nx; tg.sny = gs.ny; tg.snz = gs.nz;
     tg.MX = EX; tg.MY = EY; tg.MZ = EZ;
-    tg.WX = TX + 1 + 2 * EX;
-    tg.WY = TY + 1 + 2 * EY;
-    tg.WZ = TZ >= g.nz ? g.nz : ((TZ + 1 + 2 * EZ + 15 + 15) / 16) * 16;  // +15: the z origin is aligned down
-    if (tg.WZ > g.nz) tg.WZ = g.nz;
+    auto span = [&](int T, int d) {  // target cells covered by T source voxels, + the ceil corner
+        if (!sc) return T + 1;
+        const double a = sc[d] < 0 ? -sc[d] : sc[d];
+        if (!(a < 1e6)) return 1 << 20;
+        return (int)((T - 1) * a) + 3;
+    };
+    for (;;) {
+        // window = image of the tile + a margin on both sides of the probed origin
+        tg.WX = span(TX, 0) + 2 * EX;
+        tg.WY = span(TY, 1) + 2 * EY;
+        tg.WZ = ((span(TZ, 2) + 2 * EZ + 15 + 15) / 16) * 16;  // +15: the z origin is aligned down
+        if (tg.WX > g.nx) tg.WX = g.nx;
+        if (tg.WY > g.ny) tg.WY = g.ny;
+        if (tg.WZ > g.nz) tg.WZ = g.nz;
+        const uint64_t cells = (uint64_t)tg.WX * tg.WY * tg.WZ;
+        if (cells * sizeof(double) <= 160 * 1024) break;
+        if (!sc) return false;
+        // halve the tile along the axis with the largest window extent
+        if (tg.WZ >= tg.WX && tg.WZ >= tg.WY && TZ > 1) TZ = (TZ + 1) / 2;
+        else if (tg.WX >= tg.WY && TX > 1) TX = (TX + 1) / 2;
+        else if (TY > 1) TY = (TY + 1) / 2;
+        else if (TX > 1) TX = (TX + 1) / 2;
+        else if (TZ > 1) TZ = (TZ + 1) / 2;
+        else return false;
+    }
+    if ((int64_t)TX * TY * TZ < 256 && (int64_t)gs.nx * gs.ny * gs.nz >= 256) return false;  // not worth a window
+    tg.TX = TX; tg.TY = TY; tg.TZ = TZ;
     tg.win_cells = (uint32_t)tg.WX * tg.WY * tg.WZ;
     smem = (size_t)tg.win_cells * sizeof(double);
-    if (smem > 160 * 1024) return false;
-    tg.ntx = (g.nx + TX - 1) / TX;
-    tg.nty = (g.ny + TY - 1) / TY;
-    tg.ntz = (g.nz + TZ - 1) / TZ;
+    tg.ntx = (gs.nx + TX - 1) / TX;
+    tg.nty = (gs.ny + TY - 1) / TY;
+    tg.ntz = (gs.nz + TZ - 1) / TZ;
     tg.tiles_per_item = tg.ntx * tg.nty * tg.ntz;
     int64_t total = (int64_t)tg.tiles_per_item * nn;
     if (total >= (1ll << 31)) return false;
     tg.total = (uint32_t)total;
     tg.tile_groups = (uint32_t)TX * TY * TZ;  // voxels per tile
+    while (nthreads > 256 && (uint32_t)nthreads > tg.tile_groups) nthreads >>= 1;
     tg.ablate = g_ablate;
     tg.d_tiles = FastDiv(tg.tiles_per_item);
     tg.d_tyz = FastDiv(tg.nty * tg.ntz);
@@ -242,36 +329,25 @@ static bool make_tiles(TileGeom &tg, const Geom &g, int64_t nn, int vpl, size_t 
     return true;
 }
 
-template <typename R, bool BC, bool NEED_U, int NT, int VPL>
-static hipError_t launch_tiled(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc,
+template <typename R, int MODE, bool BC, bool NEED_U, int NT, int VPL>
+static hipError_t launch_tiled(R *d_I, R *d_u, const R *go, const R *I, const PosArgs &pa, int nc,
                                const TileGeom &tg, size_t smem, hipStream_t s) {
-    auto k = splat_tiled_kernel<R, BC, NEED_U, NT, VPL>;
+    auto k = splat_tiled_kernel<R, MODE, BC, NEED_U, NT, VPL>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(tg.total), dim3(NT), smem, s, d_I, d_u, go, I, u, dt, nc, tg);
+    hipLaunchKernelGGL(k, dim3(tg.total), dim3(NT), smem, s, d_I, d_u, go, I, pa, nc, tg);
     return hipSuccess;
 }
 
-template <typename R, int VPL>
-static hipError_t dispatch_tiled(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc,
-                                 const TileGeom &tg, size_t smem, int nt, bool bc, bool need_u, hipStream_t s) {
-#define GO(B, U, T) return launch_tiled<R, B, U, T, VPL>(d_I, d_u, go, I, u, dt, nc, tg, smem, s)
-#define BY_NT(B, U)                          \
-    do {                                     \
-        if (nt >= 1024) GO(B, U, 1024);      \
-        else if (nt >= 512) GO(B, U, 512);   \
-        else GO(B, U, 256);                  \
-    } while (0)
-    if (bc) {
-        if (need_u) BY_NT(true, true); else BY_NT(true, false);
-    } else {
-        if (need_u) BY_NT(false, true); else BY_NT(false, false);
-    }
-#undef BY_NT
-#undef GO
+template <typename R, int MODE, bool BC, bool NEED_U, int VPL>
+static hipError_t by_threads(R *d_I, R *d_u, const R *go, const R *I, const PosArgs &pa, int nc, const TileGeom &tg,
+                             size_t smem, int nt, hipStream_t s) {
+    if (nt >= 1024) return launch_tiled<R, MODE, BC, NEED_U, 1024, VPL>(d_I, d_u, go, I, pa, nc, tg, smem, s);
+    if (nt >= 512) return launch_tiled<R, MODE, BC, NEED_U, 512, VPL>(d_I, d_u, go, I, pa, nc, tg, smem, s);
+    return launch_tiled<R, MODE, BC, NEED_U, 256, VPL>(d_I, d_u, go, I, pa, nc, tg, smem, s);
 }
 
 // Returns LAGO_OK / error, or 1 when this shape is left to the plain kernel.
@@ -279,23 +355,81 @@ static hipError_t dispatch_tiled(R *d_I, R *d_u, const R *go, const R *I, const 
 template <typename R>
 int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
                         const Geom &g, bool bc, bool need_u, hipStream_t s) {
-    constexpr int VPLmax = 4;
+    constexpr int V = 4;
     const bool vec = g_interp_vec != 0;
     TileGeom tg;
     size_t smem;
     int nt;
     if (g.nz < 2) return 1;  // thin volumes take the plain kernel
-    if (!make_tiles(tg, g, nn, vec ? VPLmax : 1, smem, nt)) return 1;
-    hipError_t e = vec ? dispatch_tiled<R, VPLmax>(d_I, d_u, go, I, u, dt, nc, tg, smem, nt, bc, need_u, s)
-                       : dispatch_tiled<R, 1>(d_I, d_u, go, I, u, dt, nc, tg, smem, nt, bc, need_u, s);
+    if (!make_tiles(tg, g, g, nn, nullptr, smem, nt)) return 1;
+    PosArgs pa{};
+    pa.u = u;
+    pa.dt = dt;
+    hipError_t e;
+#define GO(B, U) \
+    e = vec ? by_threads<R, POS_DISP, B, U, V>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s) \
+            : by_threads<R, POS_DISP, B, U, 1>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s)
+    if (bc) {
+        if (need_u) GO(true, true); else GO(true, false);
+    } else {
+        if (need_u) GO(false, true); else GO(false, false);
+    }
+#undef GO
     if (e != hipSuccess) return fail_hip(e, "interp_backward (tiled splat)");
     return finish_launch(s, "interp_backward (tiled splat)");
+}
+
+// Image splat of affine_interp_backward (cuda/affine.cu:330-536, the d_I part), 3D.
+// d_I already zeroed.  Same return convention as interp_backward_lds.
+template <typename R>
+int affine_splat_lds(R *d_I, const R *go, const R *A, const R *T, int nc, int64_t nn, const Geom &g, bool bc,
+                     hipStream_t s) {
+    TileGeom tg;
+    size_t smem;
+    int nt;
+    if (g.nz < 2) return 1;
+    if (!make_tiles(tg, g, g, nn, nullptr, smem, nt)) return 1;
+    PosArgs pa{};
+    pa.A = A;
+    pa.T = T;
+    hipError_t e = bc ? by_threads<R, POS_AFFINE, true, false, 4>(d_I, nullptr, go, nullptr, pa, nc, tg, smem, nt, s)
+                      : by_threads<R, POS_AFFINE, false, false, 4>(d_I, nullptr, go, nullptr, pa, nc, tg, smem, nt, s);
+    if (e != hipSuccess) return fail_hip(e, "affine_interp_backward (tiled splat)");
+    return finish_launch(s, "affine_interp_backward (tiled splat)");
+}
+
+// regrid_backward (cuda/affine.cu:767-855), 3D: every (n, c) plane of grad_out (source grid gs)
+// is one batch item with a single channel.  d_I (target grid g) already zeroed.
+template <typename R>
+int regrid_splat_lds(R *d_I, const R *go, int64_t nplanes, const Geom &g, const Geom &gs, const double *O,
+                     const double *S, hipStream_t s) {
+    TileGeom tg;
+    size_t smem;
+    int nt;
+    if (g.nz < 2 || gs.nz < 2) return 1;
+    if (!make_tiles(tg, g, gs, nplanes, S, smem, nt)) return 1;
+    PosArgs pa{};
+    for (int d = 0; d < 3; ++d) {
+        pa.O[d] = O[d];
+        pa.S[d] = S[d];
+    }
+    hipError_t e = by_threads<R, POS_REGRID, false, false, 4>(d_I, nullptr, go, nullptr, pa, 1, tg, smem, nt, s);
+    if (e != hipSuccess) return fail_hip(e, "regrid_backward (tiled splat)");
+    return finish_launch(s, "regrid_backward (tiled splat)");
 }
 
 template int interp_backward_lds<float>(float *, float *, const float *, const float *, const float *, double, int,
                                         int64_t, const Geom &, bool, bool, hipStream_t);
 template int interp_backward_lds<double>(double *, double *, const double *, const double *, const double *, double,
                                          int, int64_t, const Geom &, bool, bool, hipStream_t);
+template int affine_splat_lds<float>(float *, const float *, const float *, const float *, int, int64_t, const Geom &,
+                                     bool, hipStream_t);
+template int affine_splat_lds<double>(double *, const double *, const double *, const double *, int, int64_t,
+                                      const Geom &, bool, hipStream_t);
+template int regrid_splat_lds<float>(float *, const float *, int64_t, const Geom &, const Geom &, const double *,
+                                     const double *, hipStream_t);
+template int regrid_splat_lds<double>(double *, const double *, int64_t, const Geom &, const Geom &, const double *,
+                                      const double *, hipStream_t);
 
 }  // namespace lago
 

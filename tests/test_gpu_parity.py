@@ -407,3 +407,57 @@ def test_fused_x_pass_fluid_metric(ext, sp, inverse):
     want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
     assert_close(fused, want, torch.float32, "x-pass fluid metric vs oracle", mult=10.0)
     assert_close(fused, host(plain), torch.float32, "x-pass vs plain hipFFT", mult=10.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["near_identity", "rotation", "zoom", "flip"])
+@pytest.mark.parametrize("bc", [False, True])
+def test_affine_backward_tiled_splat(ext, dtype, kind, bc):
+    """affine_interp_backward's image splat through the LDS window, several tiles per volume,
+    with maps whose image leaves the window (rotation, zoom, flip fall back to global atomics)."""
+    rng = np.random.default_rng(77)
+    sp, nn, nc = (36, 20, 70), 2, 2
+    I = rnd(rng, ((1 if bc else nn), nc) + sp, dtype)
+    A = np.eye(3)[None].repeat(nn, 0)
+    if kind == "near_identity":
+        A = A + 0.02 * rng.standard_normal((nn, 3, 3))
+    elif kind == "rotation":
+        c, s = np.cos(0.6), np.sin(0.6)
+        A[0] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+        A[1] = [[1, 0, 0], [0, c, -s], [0, s, c]]
+    elif kind == "zoom":
+        A = A * np.array([2.5, 0.4])[:, None, None]
+    else:
+        A[0, 2, 2] = -1.0
+        A[1, 0, 0] = -1.0
+    A = A.astype(I.dtype)
+    T = (2.0 * rng.standard_normal((nn, 3))).astype(I.dtype)
+    go = rnd(rng, (nn, nc) + sp, dtype)
+    dI, dA, dT = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, True, True)
+    oI, oA, oT = orc.affine_interp_backward(go, I, A, T, True, True, True)
+    assert_close(dI, oI, dtype, "affine d_I (tiled)", mult=8.0)
+    ext.set_splat_mode(0)
+    try:
+        dI0, _, _ = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, False, False)
+    finally:
+        ext.set_splat_mode(1)
+    assert_close(dI0, oI, dtype, "affine d_I (global atomics)", mult=8.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp,out,scale", [((20, 12, 40), (40, 24, 80), 1.0), ((40, 24, 80), (20, 12, 40), 1.0),
+                                          ((33, 17, 65), (33, 17, 65), 1.0), ((16, 16, 16), (24, 20, 90), -0.8),
+                                          ((12, 10, 14), (30, 22, 66), 7.0)])
+def test_regrid_backward_tiled_splat(ext, dtype, sp, out, scale):
+    rng = np.random.default_rng(78)
+    origin = [(s - 1) * 0.5 - 0.2 for s in sp]
+    spacing = [scale * (a - 1) / (b - 1) for a, b in zip(sp, out)]
+    go = rnd(rng, (2, 3) + out, dtype)
+    want = orc.regrid_backward(go, sp, out, origin, spacing)
+    assert_close(ext.regrid_backward(dev(go), sp, out, origin, spacing), want, dtype, "regrid backward (tiled)", mult=8.0)
+    ext.set_splat_mode(0)
+    try:
+        got0 = ext.regrid_backward(dev(go), sp, out, origin, spacing)
+    finally:
+        ext.set_splat_mode(1)
+    assert_close(got0, want, dtype, "regrid backward (global atomics)", mult=8.0)
