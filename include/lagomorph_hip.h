@@ -60,8 +60,11 @@ int lago_get_splat_mode(void);
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
 /* 1 (default): use the 4x-unrolled 3D gather kernels when the shape allows; 0: one-voxel-per-lane kernels only. */
 void lago_set_vector_kernels(int on);
-/* 1 (default): lago_fluid_metric uses the fused x-axis pass (float32, 3D, nx in {64,128,256}); 0: plain 3D hipFFT. */
-void lago_set_fluid_xpass(int on);
+/* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
+ * (nx in {64,128,256}, ny in {32..256}, nz in {64..256}, powers of two, ny*nz <= 2^15); 1: rocFFT 2D (y, z)
+ * plan + fused x-axis pass (nx in {64,128,256}); 0: rocFFT 3D plan + operator kernel.  A mode falls back
+ * to the next lower one for shapes it does not support.  Results agree to rounding. */
+void lago_set_fluid_xpass(int mode);
 
 #define LAGO_DECLARE(REAL, SUF)                                                                                      \
     /* interp_forward (extension.cpp:135-143 -> cuda/interp.cu:80-130):                                           \

@@ -29,17 +29,24 @@ int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX, const 
 // fftx.hip
 int fluid_coef_launch(float *tab, int inverse, const float *cosX, const float *sinX, const float *cosY,
                       const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta,
-                      double gamma, int64_t nx, int64_t ny, int64_t nzc, hipStream_t s);
+                      double gamma, int64_t nx, int64_t ny, int64_t nzc, int split, hipStream_t s);
 bool fluid_xpass_supported(int64_t nx);
+// fft3.hip
+bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz);
+int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
+                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s);
 int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int64_t nx, int64_t ny, int64_t nzc,
                        double scale, hipStream_t s);
-int g_fluid_xpass = 1;  // 1: use the fused x-axis pass where supported
+// 0: rocFFT 3D plan + operator kernel; 1: rocFFT 2D (y, z) plan + fused x pass (fftx.hip);
+// 2: three LDS-tiled passes, no rocFFT (fft3.hip).  Each falls back to the previous one where the
+// shape is not supported.
+int g_fluid_xpass = 2;
 
 // Operator coefficient tables (see fftx.hip), cached like the FFT plans: one device buffer per
 // (shape, parameters, direction, LUT identity), filled by a kernel on first use.
 struct CoefTab {
     int64_t nx, ny, nzc;
-    int inverse, device;
+    int inverse, device, split;
     double a, b, g;
     const void *luts[6];
     float *d;
@@ -83,20 +90,21 @@ static int get_plan(FftPlan &out, int dim, const int *n, int batch, int dbl) {
 
 static int get_coef(float *&tab, int inverse, const float *cosX, const float *sinX, const float *cosY,
                     const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta, double gamma,
-                    int64_t nx, int64_t ny, int64_t nzc, hipStream_t s) {
+                    int64_t nx, int64_t ny, int64_t nzc, int split, hipStream_t s) {
     int device = 0;
     LAGO_HIP_TRY(hipGetDevice(&device));
     const void *l[6] = {cosX, sinX, cosY, sinY, cosZ, sinZ};
     std::lock_guard<std::mutex> lk(g_plan_mu);
     for (const CoefTab &t : g_tabs)
-        if (t.nx == nx && t.ny == ny && t.nzc == nzc && t.inverse == inverse && t.device == device && t.a == alpha &&
+        if (t.nx == nx && t.ny == ny && t.nzc == nzc && t.inverse == inverse && t.device == device && t.split == split &&
+            t.a == alpha &&
             t.b == beta && t.g == gamma && !memcmp(t.luts, l, sizeof(l))) {
             tab = t.d;
             return LAGO_OK;
         }
-    CoefTab t{nx, ny, nzc, inverse, device, alpha, beta, gamma, {cosX, sinX, cosY, sinY, cosZ, sinZ}, nullptr};
+    CoefTab t{nx, ny, nzc, inverse, device, split, alpha, beta, gamma, {cosX, sinX, cosY, sinY, cosZ, sinZ}, nullptr};
     LAGO_HIP_TRY(hipMalloc((void **)&t.d, (size_t)nx * ny * nzc * 6 * sizeof(float)));
-    int rc = fluid_coef_launch(t.d, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, s);
+    int rc = fluid_coef_launch(t.d, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, split, s);
     if (rc != LAGO_OK) return rc;
     if (g_tabs.size() >= 16) {  // bounded cache
         (void)hipFree(g_tabs.front().d);
@@ -119,7 +127,7 @@ static int fluid_metric_xpass(float *out, const float *m, float *work, int inver
     if (rc != LAGO_OK) return rc;
     const int64_t nzc = nz / 2 + 1;
     float *tab = nullptr;
-    rc = get_coef(tab, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, s);
+    rc = get_coef(tab, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, 0, s);
     if (rc != LAGO_OK) return rc;
     hipfftResult r = hipfftSetStream(p.fwd, s);
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftSetStream");
@@ -144,6 +152,16 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
         return fail_invalid("fluid_metric: bad extent");
     if (nn == 0) return LAGO_OK;
     if (!out || !m || !work) return fail_invalid("fluid_metric: null pointer");
+    if (sizeof(R) == 4 && dim == 3 && g_fluid_xpass >= 2 && fluid_native_supported(nx, ny, nz) &&
+        (((uintptr_t)out | (uintptr_t)m | (uintptr_t)work) & 15) == 0) {  // 16-byte vector accesses
+        float *tab = nullptr;
+        int rc = get_coef(tab, inverse, (const float *)cosX, (const float *)sinX, (const float *)cosY,
+                          (const float *)sinY, (const float *)cosZ, (const float *)sinZ, alpha, beta, gamma, nx, ny,
+                          nz / 2 + 1, 1, (hipStream_t)stream);
+        if (rc != LAGO_OK) return rc;
+        return fluid_metric_native((float *)out, (const float *)m, (float *)work, tab, inverse, nn, nx, ny, nz,
+                                   1.0 / ((double)nx * (double)ny * (double)nz), (hipStream_t)stream);
+    }
     if (sizeof(R) == 4 && dim == 3 && g_fluid_xpass && fluid_xpass_supported(nx) && nn * 3 * nx < (1ll << 31))
         return fluid_metric_xpass((float *)out, (const float *)m, (float *)work, inverse, (const float *)cosX,
                                   (const float *)sinX, (const float *)cosY, (const float *)sinY, (const float *)cosZ,
@@ -179,7 +197,7 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
 }  // namespace lago
 
 extern "C" {
-void lago_set_fluid_xpass(int on) { lago::g_fluid_xpass = on ? 1 : 0; }
+void lago_set_fluid_xpass(int mode) { lago::g_fluid_xpass = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 #define LAGO_DEFINE(REAL, SUF)                                                                                     \
     int lago_fluid_metric##SUF(REAL *out, const REAL *m, REAL *work, int inverse, const REAL *cosX,               \
                                const REAL *sinX, const REAL *cosY, const REAL *sinY, const REAL *cosZ,            \

@@ -1,0 +1,425 @@
+// LDS-resident FFT building blocks for the fluid metric (float32, power-of-two extents), gfx950.
+//
+// FluidMetricOperator.forward of the reference (/root/reference/lagomorph/metric.py:11-19) is
+// rfftn -> per-frequency 3x3 operator (cuda/metric.cu:163-305) -> irfftn.  Here it is three passes
+// over HBM, each one workgroup-per-tile with the tile held in LDS:
+//
+//   zy forward : one (n, c, x) plane of nz reals x ny rows  ->  real-to-complex FFT along z (as an
+//                nz/2-point complex FFT + split), complex FFT along y.  The two purely real
+//                columns kz = 0 and kz = nz/2 ride through the y transform packed as one complex
+//                column, so the plane is exactly ny x nz/2 complex = the size of the input.
+//   x pass     : all nx and the three vector components of 16 neighbouring frequencies -> FFT
+//                along x, operator, inverse FFT along x, in place.
+//   zy inverse : mirror image of zy forward.
+//
+// Layout of the spectrum between the passes (the caller's `work` buffer, nn*3*nx*ny*(nz/2+1)
+// complex): a "main" block [n][c][x][ky][kz < nz/2] followed by the Nyquist plane
+// [n][c][x][ky] (kz = nz/2).  Splitting the odd 65th column off keeps every row a multiple of
+// 128 bytes: measured on MI355X (tools/probes/seg_copy.hip), 128 B-aligned segments at a 64 KB
+// stride stream at the speed of contiguous memory, while the 520 B rows of the usual
+// nz/2+1 layout cost 3x on the write side (partial cache lines).
+//
+// All transforms are radix-2 decimation-in-frequency forward (natural -> bit-reversed order)
+// and decimation-in-time inverse (bit-reversed -> natural), three levels at a time in
+// registers; bit-reversed positions are undone for free when a tile is read from / written to LDS.
+//
+// Every phase between two workgroup barriers is a function of (phase, thread id) only, so the
+// same code runs on the host with a loop over thread ids (tests/native/fft_emul.hip): the
+// kernels are verified against a double-precision DFT without a GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lago {
+namespace fl {
+
+#define LAGO_HD __host__ __device__ __forceinline__
+
+LAGO_HD float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+LAGO_HD float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+LAGO_HD int brev(int v, int bits) { return (int)(__builtin_bitreverse32((uint32_t)v) >> (32 - bits)); }
+
+LAGO_HD float2 twiddle(int t, int m) {  // exp(-2 pi i t / m)
+#ifdef __HIP_DEVICE_COMPILE__
+    float sn, cs;
+    sincospif(-2.0f * (float)t / (float)m, &sn, &cs);
+    return make_float2(cs, sn);
+#else
+    const double a = -2.0 * 3.14159265358979323846 * (double)t / (double)m;
+    return make_float2((float)cos(a), (float)sin(a));
+#endif
+}
+
+// radix-2 levels are grouped three at a time, from the largest half down
+constexpr int stage_top(int logn, int g) {
+    int top = logn - 1;
+    for (int k = 0; k < g; ++k) top -= (top + 1 >= 3 ? 3 : top + 1);
+    return top;
+}
+constexpr int stage_s(int logn, int g) {
+    const int top = stage_top(logn, g);
+    return top < 0 ? 0 : (top + 1 >= 3 ? 3 : top + 1);
+}
+constexpr int stage_count(int logn) { return (logn + 2) / 3; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// A family of NB * 2^LOGNL transforms of 2^LOGN points in LDS: element i of transform (b, lane)
+// is buf[b*BS + i*ES + lane*LS].  tw[t] = exp(-2 pi i t / 2^LOGM), t < 2^(LOGM-1), LOGM >= LOGN.
+template <int LOGN_, int ES_, int LS_, int LOGNL_, int NB_, int BS_, int LOGM_, int NT_>
+struct Xf {
+    static constexpr int LOGN = LOGN_, ES = ES_, LS = LS_, LOGNL = LOGNL_, NB = NB_, BS = BS_, LOGM = LOGM_, NT = NT_;
+};
+
+// Stage G of transform family X: S = stage_s radix-2 levels (halves 2^TOP .. 2^(TOP-S+1)) on
+// 2^S elements spaced 2^(TOP-S+1) apart, in registers.  FWD: decimation in frequency; !FWD:
+// decimation in time with conjugated twiddles (same data flow backwards).
+template <class X, int G, bool FWD>
+LAGO_HD void radix_stage(float2 *buf, const float2 *tw, int tid) {
+    constexpr int TOP = stage_top(X::LOGN, G), S = stage_s(X::LOGN, G);
+    if constexpr (S > 0) {
+        constexpr int N = 1 << X::LOGN, R = 1 << S, LH = TOP - S + 1, H = 1 << LH, NL = 1 << X::LOGNL;
+        constexpr int PER = N / R, ITEMS = X::NB * PER * NL;
+        for (int w = tid; w < ITEMS; w += X::NT) {
+            const int lane = w & (NL - 1);
+            const int q = w >> X::LOGNL;
+            const int gidx = q & (PER - 1);
+            const int b = q / PER;
+            const int low = gidx & (H - 1);
+            const int i = ((gidx >> LH) << (LH + S)) | low;
+            float2 *p = buf + b * X::BS + i * X::ES + lane * X::LS;
+            float2 v[R];
+#pragma unroll
+            for (int m = 0; m < R; ++m) v[m] = p[m * H * X::ES];
+#pragma unroll
+            for (int ll = 0; ll < S; ++ll) {
+                const int l = FWD ? ll : S - 1 - ll;
+                const int hm = R >> (l + 1);
+                const int lhalf = LH + (S - 1 - l);
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                    if (m & hm) continue;
+                    const int jj = low + (m & (hm - 1)) * H;
+                    const float2 wv = tw[(jj << (X::LOGN - 1 - lhalf)) << (X::LOGM - X::LOGN)];
+                    const float2 a = v[m];
+                    if (FWD) {
+                        const float2 bb = v[m + hm];
+                        v[m] = make_float2(a.x + bb.x, a.y + bb.y);
+                        v[m + hm] = cmul(make_float2(a.x - bb.x, a.y - bb.y), wv);
+                    } else {
+                        const float2 bb = cmulc(v[m + hm], wv);
+                        v[m] = make_float2(a.x + bb.x, a.y + bb.y);
+                        v[m + hm] = make_float2(a.x - bb.x, a.y - bb.y);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < R; ++m) p[m * H * X::ES] = v[m];
+        }
+    }
+}
+
+// stage number `g` of the forward transform / of the inverse transform (which runs the groups in
+// reverse order); g is a constant after unrolling
+template <class X, bool FWD>
+LAGO_HD void run_stage(int g, float2 *buf, const float2 *tw, int tid) {
+    constexpr int G = stage_count(X::LOGN);
+    const int gg = FWD ? g : G - 1 - g;
+    if (gg == 0) radix_stage<X, 0, FWD>(buf, tw, tid);
+    else if (gg == 1) radix_stage<X, 1, FWD>(buf, tw, tid);
+    else radix_stage<X, 2, FWD>(buf, tw, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The per-frequency operator on one frequency bin (three complex components), coefficients as
+// tabulated by fluid_coef_kernel: cuda/metric.cu:103-130 (sharp: Cholesky solve with
+// ooG00 G10 ooG11 G20 G21 ooG22) and :145-160 (flat: L00 L10 L11 L20 L21 L22).  Same expressions
+// and roundings as fluid_kernel in metric.hip.
+template <bool INV>
+LAGO_HD void fluid_bin(const float *c, float2 &X, float2 &Y, float2 &Z, float scale) {
+    const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+    float bx[2] = {X.x, X.y}, by[2] = {Y.x, Y.y}, bz[2] = {Z.x, Z.y};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float bX = bx[q], bY = by[q], bZ = bz[q];
+        if (INV) {
+            const float y0 = bX * c0;
+            const float y1 = fmaf(-c1, y0, bY) * c2;
+            const float y2 = fmaf(-c4, y1, fmaf(-c3, y0, bZ)) * c5;
+            bZ = y2 * c5;
+            bY = fmaf(-c4, bZ, y1) * c2;
+            bX = fmaf(-c3, bZ, fmaf(-c1, bY, y0)) * c0;
+        } else {
+            const float x = fmaf(c3, bZ, fmaf(c0, bX, c1 * bY));
+            const float yy = fmaf(c4, bZ, fmaf(c1, bX, c2 * bY));
+            bZ = fmaf(c5, bZ, fmaf(c3, bX, c4 * bY));
+            bX = x;
+            bY = yy;
+        }
+        bx[q] = bX * scale; by[q] = bY * scale; bz[q] = bZ * scale;
+    }
+    X = make_float2(bx[0], bx[1]);
+    Y = make_float2(by[0], by[1]);
+    Z = make_float2(bz[0], bz[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// x pass.  Workgroup tile: 3 components x NX x 16 neighbouring bins (16 kz of one ky in the main
+// block, or 16 ky of the Nyquist plane); thread = (row group, bin lane).
+struct XArgs {
+    float2 *main_, *nyq;        // split spectrum (see the header comment)
+    const float *tabM, *tabN;   // coefficients [kx][ky][kz < nzh][6] and [kx][ky][6]
+    int ny, nzh, nch, items_per_n;
+    float scale;
+    uint32_t total;
+};
+
+template <int LOGNX, bool INV, int NT = 256>
+struct XPass {
+    static constexpr int NX = 1 << LOGNX, KL = 16, KCP = KL + 1;  // odd row pitch spreads rows over banks
+    using T = Xf<LOGNX, KCP, 1, 4, 3, NX * KCP, LOGNX, NT>;
+    static constexpr int G = stage_count(LOGNX);
+    static constexpr int NPH = 2 * G + 3;  // load | G forward stages | operator | G inverse stages | store
+    static constexpr int ROWS_IT = NT / 8, KLD = 3 * NX / ROWS_IT;  // float4 loads: 8 lanes per 16-bin row
+    static constexpr int RG = NT / KL, NOP = NX / RG;               // operator: NOP bins per thread
+    static constexpr size_t SMEM = (size_t)(3 * NX * KCP + NX / 2) * sizeof(float2);
+    static_assert(3 * NX % ROWS_IT == 0 && NX % RG == 0, "tile does not divide over the threads");
+
+    struct Block {  // workgroup-uniform
+        float2 *base;
+        size_t xs;        // x stride (complex elements); component stride = NX * xs
+        const float *tb;  // coefficient row of bin lane 0 at kx = 0
+        size_t tks;       // kx stride of the coefficient table (floats)
+    };
+    struct Regs { float coef[NOP][6]; };
+
+    LAGO_HD static Block locate(const XArgs &a, uint32_t blk) {
+        const uint32_t n = blk / (uint32_t)a.items_per_n, item = blk % (uint32_t)a.items_per_n;
+        const uint32_t nmain = (uint32_t)a.ny * a.nch;
+        Block b;
+        if (item < nmain) {
+            const uint32_t ky = item / (uint32_t)a.nch, ch = item % (uint32_t)a.nch;
+            b.xs = (size_t)a.ny * a.nzh;
+            b.base = a.main_ + (size_t)n * 3 * NX * b.xs + (size_t)ky * a.nzh + ch * KL;
+            b.tb = a.tabM + ((size_t)ky * a.nzh + ch * KL) * 6;
+            b.tks = b.xs * 6;
+        } else {
+            const uint32_t j = item - nmain;
+            b.xs = (size_t)a.ny;
+            b.base = a.nyq + (size_t)n * 3 * NX * b.xs + j * KL;
+            b.tb = a.tabN + (size_t)j * KL * 6;
+            b.tks = b.xs * 6;
+        }
+        return b;
+    }
+
+    LAGO_HD static void phase(int ph, int tid, Regs &r, const Block &b, float2 *buf, float2 *tw, float scale) {
+        if (ph == 0) {
+            for (int t = tid; t < NX / 2; t += NT) tw[t] = twiddle(t, NX);
+            const int rg = tid >> 3, l8 = tid & 7;
+            float4 v[KLD];
+#pragma unroll
+            for (int k = 0; k < KLD; ++k)
+                v[k] = *reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8);
+            // coefficient prefetch for the operator phase (consumed after the forward stages)
+            const int kc = tid & (KL - 1), row0 = tid / KL;
+#pragma unroll
+            for (int i = 0; i < NOP; ++i) {
+                const float *t = b.tb + (size_t)brev(row0 + i * RG, LOGNX) * b.tks + kc * 6;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const float2 c2 = *reinterpret_cast<const float2 *>(t + 2 * e);
+                    r.coef[i][2 * e] = c2.x;
+                    r.coef[i][2 * e + 1] = c2.y;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KLD; ++k) {
+                float2 *d = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
+                d[0] = make_float2(v[k].x, v[k].y);
+                d[1] = make_float2(v[k].z, v[k].w);
+            }
+        } else if (ph <= G) {
+            run_stage<T, true>(ph - 1, buf, tw, tid);
+        } else if (ph == G + 1) {
+            // position p of the x axis holds kx = bitrev(p) after the forward stages
+            const int kc = tid & (KL - 1), row0 = tid / KL;
+#pragma unroll
+            for (int i = 0; i < NOP; ++i) {
+                const int p = row0 + i * RG;
+                float2 *bx = buf + (0 * NX + p) * KCP + kc, *by = buf + (1 * NX + p) * KCP + kc,
+                       *bz = buf + (2 * NX + p) * KCP + kc;
+                float2 X = *bx, Y = *by, Z = *bz;
+                fluid_bin<INV>(r.coef[i], X, Y, Z, scale);
+                *bx = X; *by = Y; *bz = Z;
+            }
+        } else if (ph <= 2 * G + 1) {
+            run_stage<T, false>(ph - G - 2, buf, tw, tid);
+        } else {
+            const int rg = tid >> 3, l8 = tid & 7;
+#pragma unroll
+            for (int k = 0; k < KLD; ++k) {
+                const float2 *s = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
+                const float2 a = s[0], c = s[1];
+                *reinterpret_cast<float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8) =
+                    make_float4(a.x, a.y, c.x, c.y);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// zy passes.  LDS plane P[y][PZ], PZ = NZ/2 + 1 (odd pitch: column walks with lanes along y are
+// conflict-free; the spare column holds the Nyquist bins around the store / load).
+struct ZYArgs {
+    const float *in;   // forward: real planes (nn*3*nx planes of ny*nz); inverse: unused
+    float *out;        // inverse: real planes
+    float2 *main_, *nyq;
+    uint32_t total;
+};
+
+template <int LOGNY, int LOGNZ, int NT = 512>
+struct ZY {
+    static constexpr int NY = 1 << LOGNY, NZ = 1 << LOGNZ, LOGZH = LOGNZ - 1, NZH = 1 << LOGZH, PZ = NZH + 1;
+    static constexpr int LOGM = cmax(LOGNY, LOGNZ), M = 1 << LOGM;
+    using TZ = Xf<LOGZH, 1, PZ, LOGNY, 1, 0, LOGM, NT>;   // along z, lanes over y
+    using TY = Xf<LOGNY, PZ, 1, LOGZH, 1, 0, LOGM, NT>;   // along y, lanes over kz
+    static constexpr int GZ = stage_count(LOGZH), GY = stage_count(LOGNY);
+    static constexpr int NPH = GZ + GY + 4;  // load | stages | split | stages | unpack | store   (mirrored for the inverse)
+    static constexpr int KV = NY * NZH / 2 / NT;  // float4 (two complex) per thread per plane
+    static constexpr size_t SMEM = (size_t)(NY * PZ + M / 2) * sizeof(float2);
+    static_assert(KV >= 1 && (NY * NZH / 2) % NT == 0, "plane does not divide over the threads");
+
+    // -- forward: real plane -> main[ky][kz], nyq[ky]
+    LAGO_HD static void fwd_phase(int ph, int tid, const float *in, float2 *mainp, float2 *nyqp, float2 *P,
+                                  float2 *tw) {
+        if (ph == 0) {
+            for (int t = tid; t < M / 2; t += NT) tw[t] = twiddle(t, M);
+            // a row of NZ reals is NZH complex z[j] = (x[2j], x[2j+1]) as it lies in memory
+            float4 v[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) v[k] = reinterpret_cast<const float4 *>(in)[tid + k * NT];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int e = (tid + k * NT) * 2, y = e >> LOGZH, j = e & (NZH - 1);
+                P[y * PZ + j] = make_float2(v[k].x, v[k].y);
+                P[y * PZ + j + 1] = make_float2(v[k].z, v[k].w);
+            }
+        } else if (ph <= GZ) {
+            run_stage<TZ, true>(ph - 1, P, tw, tid);
+        } else if (ph == GZ + 1) {
+            // split the half-length transform Z into the real transform X (k = 0 .. NZH):
+            // X[k] = E + w^k O, conj X[NZH-k] = E - w^k O, E = (Z[k] + conj Z[NZH-k])/2,
+            // O = -i (Z[k] - conj Z[NZH-k])/2, w = exp(-2 pi i / NZ).  Z[k] sits at column bitrev(k).
+            // X[0] and X[NZH] are real: they share column 0 as (X[0], X[NZH]).
+            for (int w = tid; w < (NZH / 2 + 1) * NY; w += NT) {
+                const int y = w & (NY - 1), k = w >> LOGNY;
+                float2 *row = P + y * PZ;
+                if (k == 0) {
+                    const float2 z = row[0];
+                    row[0] = make_float2(z.x + z.y, z.x - z.y);
+                } else if (k == NZH / 2) {
+                    float2 *p = row + brev(k, LOGZH);
+                    *p = make_float2(p->x, -p->y);
+                } else {
+                    float2 *pk = row + brev(k, LOGZH), *pm = row + brev(NZH - k, LOGZH);
+                    const float2 zk = *pk, zm = *pm;
+                    const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                    const float2 D = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+                    const float2 wO = cmul(make_float2(D.y, -D.x), tw[k << (LOGM - LOGNZ)]);
+                    *pk = make_float2(E.x + wO.x, E.y + wO.y);
+                    *pm = make_float2(E.x - wO.x, -(E.y - wO.y));
+                }
+            }
+        } else if (ph <= GZ + 1 + GY) {
+            run_stage<TY, true>(ph - GZ - 2, P, tw, tid);
+        } else if (ph == GZ + GY + 2) {
+            // column 0 carried A + iB with A = X[0](y), B = X[NZH](y) both real: separate their
+            // transforms FA(ky) = (P(ky) + conj P(-ky))/2, FB(ky) = -i (P(ky) - conj P(-ky))/2.
+            // FA stays in column 0, FB goes to the spare column NZH.  Row ky sits at bitrev(ky).
+            for (int ky = tid; ky <= NY / 2; ky += NT) {
+                float2 *pk = P + brev(ky, LOGNY) * PZ, *pm = P + brev((NY - ky) & (NY - 1), LOGNY) * PZ;
+                const float2 a = pk[0], b = pm[0];
+                const float2 FA = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+                const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+                const float2 FB = make_float2(D.y, -D.x);
+                pk[0] = FA;
+                pk[NZH] = FB;
+                pm[0] = make_float2(FA.x, -FA.y);
+                pm[NZH] = make_float2(FB.x, -FB.y);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int e = (tid + k * NT) * 2, ky = e >> LOGZH, kz = e & (NZH - 1);
+                const float2 *row = P + brev(ky, LOGNY) * PZ;
+                const float2 a = row[brev(kz, LOGZH)], c = row[brev(kz + 1, LOGZH)];
+                reinterpret_cast<float4 *>(mainp)[tid + k * NT] = make_float4(a.x, a.y, c.x, c.y);
+            }
+            for (int ky = tid; ky < NY; ky += NT) nyqp[ky] = P[brev(ky, LOGNY) * PZ + NZH];
+        }
+    }
+
+    // -- inverse: main[ky][kz], nyq[ky] -> real plane (unnormalised: NY * NZ times the original)
+    LAGO_HD static void inv_phase(int ph, int tid, float *out, const float2 *mainp, const float2 *nyqp, float2 *P,
+                                  float2 *tw) {
+        if (ph == 0) {
+            for (int t = tid; t < M / 2; t += NT) tw[t] = twiddle(t, M);
+            float4 v[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int e = (tid + k * NT) * 2, ky = e >> LOGZH, kz = e & (NZH - 1);
+                float2 *row = P + brev(ky, LOGNY) * PZ;
+                float2 a = make_float2(v[k].x, v[k].y);
+                if (kz == 0) {  // pack FA + i FB: the inverse y transform then returns (X[0](y), X[NZH](y))
+                    const float2 fb = nyqp[ky];
+                    a = make_float2(a.x - fb.y, a.y + fb.x);
+                }
+                row[brev(kz, LOGZH)] = a;
+                row[brev(kz + 1, LOGZH)] = make_float2(v[k].z, v[k].w);
+            }
+        } else if (ph <= GY) {
+            run_stage<TY, false>(ph - 1, P, tw, tid);
+        } else if (ph == GY + 1) {
+            // merge X back into the half-length transform (twice it: the missing factor 2 of the
+            // real inverse): 2E = X[k] + conj X[NZH-k], 2O = (X[k] - conj X[NZH-k]) conj(w^k),
+            // Z[k] = 2E + i 2O, Z[NZH-k] = conj(2E) + i conj(2O)
+            for (int w = tid; w < (NZH / 2 + 1) * NY; w += NT) {
+                const int y = w & (NY - 1), k = w >> LOGNY;
+                float2 *row = P + y * PZ;
+                if (k == 0) {
+                    const float2 x = row[0];
+                    row[0] = make_float2(x.x + x.y, x.x - x.y);
+                } else if (k == NZH / 2) {
+                    float2 *p = row + brev(k, LOGZH);
+                    *p = make_float2(2.0f * p->x, -2.0f * p->y);
+                } else {
+                    float2 *pk = row + brev(k, LOGZH), *pm = row + brev(NZH - k, LOGZH);
+                    const float2 xk = *pk, xm = *pm;
+                    const float2 E = make_float2(xk.x + xm.x, xk.y - xm.y);
+                    const float2 O = cmulc(make_float2(xk.x - xm.x, xk.y + xm.y), tw[k << (LOGM - LOGNZ)]);
+                    *pk = make_float2(E.x - O.y, E.y + O.x);
+                    *pm = make_float2(E.x + O.y, O.x - E.y);
+                }
+            }
+        } else if (ph <= GY + 1 + GZ) {
+            run_stage<TZ, false>(ph - GY - 2, P, tw, tid);
+        } else if (ph == GY + GZ + 2) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int e = (tid + k * NT) * 2, y = e >> LOGZH, j = e & (NZH - 1);
+                const float2 a = P[y * PZ + j], c = P[y * PZ + j + 1];
+                reinterpret_cast<float4 *>(out)[tid + k * NT] = make_float4(a.x, a.y, c.x, c.y);
+            }
+        }
+    }
+    static constexpr int NPH_INV = GY + GZ + 3;
+};
+
+}  // namespace fl
+}  // namespace lago

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void fluid_coef_kernel(float *__restrict__ 
                                                             const float *__restrict__ sinX, const float *__restrict__ cosY,
                                                             const float *__restrict__ sinY, const float *__restrict__ cosZ,
                                                             const float *__restrict__ sinZ, double alpha, double beta,
-                                                            double gamma, Geom g) {
+                                                            double gamma, Geom g, int split) {
     const Vox v = locate(g);
     if (!v.valid) return;
     const float wx = cosX[v.i], wy = cosY[v.j], wz = cosZ[v.k];
@@ -52,7 +52,11 @@ __global__ __launch_bounds__(kBlock) void fluid_coef_kernel(float *__restrict__ 
     const float L20 = lg_fma(l20, l22, lg_fma(l00, l20, l10 * l21));
     const float L21 = lg_fma(l21, l22, lg_fma(l10, l20, l11 * l21));
     const float L22 = lg_fma(l22, l22, lg_fma(l20, l20, l21 * l21));
-    float *t = tab + (size_t)v.s * 6;
+    // split: [kx][ky][kz < nzc-1] followed by the Nyquist plane [kx][ky] (fft_lds.hpp)
+    const int nzh = g.nz - 1;
+    float *t = !split ? tab + (size_t)v.s * 6
+               : v.k < nzh ? tab + (((size_t)v.i * g.ny + v.j) * nzh + v.k) * 6
+                           : tab + ((size_t)g.nx * g.ny * nzh + (size_t)v.i * g.ny + v.j) * 6;
     if (INV) {  // cuda/metric.cu:47-78
         const float ooG00 = fx_recip(fx_safe_sqrt(L00));
         const float G10 = L10 * ooG00;
@@ -144,7 +148,7 @@ struct Levels<LOGN, -1, FWD> {
 template <int LOGN, bool INV>
 __global__ __launch_bounds__(256) void fluid_xpass_kernel(float2 *__restrict__ F, const float *__restrict__ tab,
                                                           int ny, int nzc, int KC, int nchunks, float scale,
-                                                          uint32_t total) {
+                                                          uint32_t total, int dbg) {
     constexpr int NX = 1 << LOGN;
     constexpr int KCP = kKCP;
     extern __shared__ __align__(16) unsigned char lago_smem[];
@@ -173,13 +177,13 @@ __global__ __launch_bounds__(256) void fluid_xpass_kernel(float2 *__restrict__ F
     for (int r = row0; r < 3 * NX; r += 16) buf[r * KCP + kc] = act ? Fn[(size_t)r * xs] : make_float2(0.f, 0.f);
     __syncthreads();
 
-    Levels<LOGN, LOGN - 1, true>::run(buf, tw, row0, kc);  // forward: natural -> bit-reversed
+    if (dbg != 1) Levels<LOGN, LOGN - 1, true>::run(buf, tw, row0, kc);  // forward: natural -> bit-reversed
 
     // per-frequency operator; position p holds kx = bitrev(p)
     for (int p = row0; p < NX; p += 16) {
-        if (act) {
+        if (act && dbg != 1 && dbg != 2) {
             const uint32_t kx = __brev((uint32_t)p) >> (32 - LOGN);
-            const float *t = tab + (((size_t)kx * ny + y) * nzc + k0 + kc) * 6;
+            const float *t = dbg == 3 ? tab + kc * 6 : tab + (((size_t)kx * ny + y) * nzc + k0 + kc) * 6;
             const float c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3], c4 = t[4], c5 = t[5];
             float2 X = buf[(0 * NX + p) * KCP + kc], Y = buf[(1 * NX + p) * KCP + kc], Z = buf[(2 * NX + p) * KCP + kc];
             float bx[2] = {X.x, X.y}, by[2] = {Y.x, Y.y}, bz[2] = {Z.x, Z.y};
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void fluid_xpass_kernel(float2 *__restrict__ F
     }
     __syncthreads();
 
-    Levels<LOGN, LOGN - 1, false>::run(buf, tw, row0, kc);  // inverse: bit-reversed -> natural, unnormalised
+    if (dbg != 1) Levels<LOGN, LOGN - 1, false>::run(buf, tw, row0, kc);  // inverse: bit-reversed -> natural, unnormalised
 
     for (int r = row0; r < 3 * NX; r += 16)
         if (act) Fn[(size_t)r * xs] = buf[r * KCP + kc];
@@ -219,18 +223,19 @@ __global__ __launch_bounds__(256) void fluid_xpass_kernel(float2 *__restrict__ F
 
 int fluid_coef_launch(float *tab, int inverse, const float *cosX, const float *sinX, const float *cosY,
                       const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta,
-                      double gamma, int64_t nx, int64_t ny, int64_t nzc, hipStream_t s) {
+                      double gamma, int64_t nx, int64_t ny, int64_t nzc, int split, hipStream_t s) {
     Geom g;
     if (!make_geom(g, 3, 1, nx, ny, nzc)) return fail_invalid("fluid_coef: bad extent");
     if (inverse)
         hipLaunchKernelGGL((fluid_coef_kernel<true>), dim3(g.nblocks), dim3(kBlock), 0, s, tab, cosX, sinX, cosY, sinY,
-                           cosZ, sinZ, alpha, beta, gamma, g);
+                           cosZ, sinZ, alpha, beta, gamma, g, split);
     else
         hipLaunchKernelGGL((fluid_coef_kernel<false>), dim3(g.nblocks), dim3(kBlock), 0, s, tab, cosX, sinX, cosY, sinY,
-                           cosZ, sinZ, alpha, beta, gamma, g);
+                           cosZ, sinZ, alpha, beta, gamma, g, split);
     return finish_launch(s, "fluid_coef");
 }
 
+int g_xpass_dbg = 0;  // profiling only (results are wrong when != 0)
 bool fluid_xpass_supported(int64_t nx) { return nx == 64 || nx == 128 || nx == 256; }
 
 template <int LOGN>
@@ -251,10 +256,10 @@ static hipError_t xpass_launch(float2 *F, const float *tab, int inverse, int64_t
     }
     if (inverse)
         hipLaunchKernelGGL(kinv, dim3((uint32_t)total), dim3(256), smem, s, F, tab, (int)ny, (int)nzc, KC, nchunks, scale,
-                           (uint32_t)total);
+                           (uint32_t)total, g_xpass_dbg);
     else
         hipLaunchKernelGGL(kfwd, dim3((uint32_t)total), dim3(256), smem, s, F, tab, (int)ny, (int)nzc, KC, nchunks, scale,
-                           (uint32_t)total);
+                           (uint32_t)total, g_xpass_dbg);
     return hipSuccess;
 }
 
@@ -271,3 +276,6 @@ int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int6
 }
 
 }  // namespace lago
+
+extern "C" void lago_debug_xpass_variant(int v) { lago::g_xpass_dbg = v; }
+

@@ -66,6 +66,8 @@ for _name, _args in _SIGS.items():
 _lib.lago_set_debug.argtypes = [_int]
 _lib.lago_set_splat_mode.argtypes = [_int]
 _lib.lago_set_splat_tile.argtypes = [_int] * 7
+_lib.lago_set_vector_kernels.argtypes = [_int]
+_lib.lago_set_fluid_xpass.argtypes = [_int]
 
 
 def _suffix(t):
@@ -140,6 +142,12 @@ def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
 def set_vector_kernels(on):
     """1 (default): 16-byte vectorised 3D kernels where shapes allow; 0: scalar kernels only."""
     _lib.lago_set_vector_kernels(1 if on else 0)
+
+
+def set_fluid_mode(mode):
+    """fluid_metric implementation: 2 (default) three LDS-tiled FFT passes where the shape allows,
+    1 rocFFT 2D plan + fused x pass, 0 rocFFT 3D plan + operator kernel."""
+    _lib.lago_set_fluid_xpass(int(mode))
 
 
 def version():

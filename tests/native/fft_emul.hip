@@ -1,0 +1,169 @@
+// Host emulation of the fluid-metric FFT passes (lagomorph_amd/csrc/fft_lds.hpp): every phase of
+// the three kernels is run for all thread ids in turn (barriers = phase boundaries) and the result
+// is compared with a double-precision separable DFT + the same per-frequency operator.
+// Built and run by tests/test_fft_emulation.py; needs no GPU.
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../lagomorph_amd/csrc/fft_lds.hpp"
+
+using namespace lago::fl;
+typedef std::complex<double> cd;
+
+static double frand() { return (double)rand() / RAND_MAX * 2.0 - 1.0; }
+
+// in-place DFT along one axis of a dense (d0, d1, d2) complex array, sign = -1 forward
+static void dft_axis(std::vector<cd> &a, int d0, int d1, int d2, int axis, int sign) {
+    const int dims[3] = {d0, d1, d2};
+    const int n = dims[axis];
+    const size_t strides[3] = {(size_t)d1 * d2, (size_t)d2, 1};
+    std::vector<cd> w(n), tmp(n);
+    for (int t = 0; t < n; ++t) w[t] = std::polar(1.0, sign * 2.0 * M_PI * t / n);
+    const int o1 = (axis + 1) % 3, o2 = (axis + 2) % 3;
+    for (int i = 0; i < dims[o1]; ++i)
+        for (int j = 0; j < dims[o2]; ++j) {
+            const size_t base = i * strides[o1] + j * strides[o2];
+            for (int k = 0; k < n; ++k) {
+                cd s = 0;
+                for (int t = 0; t < n; ++t) s += a[base + t * strides[axis]] * w[(size_t)k * t % n];
+                tmp[k] = s;
+            }
+            for (int k = 0; k < n; ++k) a[base + k * strides[axis]] = tmp[k];
+        }
+}
+
+template <bool INV>
+static void op_double(const float *c, cd &X, cd &Y, cd &Z) {
+    const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+    if (INV) {
+        const cd y0 = X * c0, y1 = (Y - c1 * y0) * c2, y2 = (Z - c3 * y0 - c4 * y1) * c5;
+        Z = y2 * c5;
+        Y = (y1 - c4 * Z) * c2;
+        X = (y0 - c1 * Y - c3 * Z) * c0;
+    } else {
+        const cd x = c0 * X + c1 * Y + c3 * Z, y = c1 * X + c2 * Y + c4 * Z, z = c3 * X + c4 * Y + c5 * Z;
+        X = x; Y = y; Z = z;
+    }
+}
+
+template <int LX, int LY, int LZ, bool INV>
+static int run_case() {
+    constexpr int NX = 1 << LX, NY = 1 << LY, NZ = 1 << LZ, NZH = NZ / 2, NZC = NZH + 1, NN = 2;
+    using Zy = ZY<LY, LZ, 512>;
+    using Xp = XPass<LX, INV, 256>;
+    const size_t plane = (size_t)NY * NZ, nplanes = (size_t)NN * 3 * NX;
+    std::vector<float> m(nplanes * plane), out(nplanes * plane, 0.f);
+    for (auto &v : m) v = (float)frand();
+    std::vector<float2> work(nplanes * NY * NZC);
+    float2 *mainb = work.data(), *nyqb = work.data() + nplanes * NY * NZH;
+    std::vector<float> tab((size_t)NX * NY * NZC * 6);
+    for (size_t b = 0; b < (size_t)NX * NY * NZC; ++b) {
+        float *c = &tab[b * 6];
+        for (int e = 0; e < 6; ++e) c[e] = (float)(0.3 * frand());
+        c[0] += 1.5f; c[2] += 1.5f; c[5] += 1.5f;
+    }
+    float *tabMw = tab.data(), *tabNw = tab.data() + (size_t)NX * NY * NZH * 6;
+    // a real field needs the same operator at k and -k; inside the half spectrum that constrains
+    // the planes kz = 0 and kz = NZH (the fluid operator's LUTs satisfy it by construction)
+    for (int kx = 0; kx < NX; ++kx)
+        for (int ky = 0; ky < NY; ++ky) {
+            const size_t a = (size_t)kx * NY + ky, bb = (size_t)((NX - kx) % NX) * NY + (NY - ky) % NY;
+            for (int e = 0; e < 6; ++e) {
+                tabMw[bb * NZH * 6 + e] = tabMw[a * NZH * 6 + e];
+                tabNw[bb * 6 + e] = tabNw[a * 6 + e];
+            }
+        }
+    const float *tabM = tabMw, *tabN = tabNw;
+    const float scale = 1.0f / ((float)NX * NY * NZ);
+
+    std::vector<float2> lds(Zy::SMEM / sizeof(float2) + Xp::SMEM / sizeof(float2));
+    // zy forward
+    for (size_t p = 0; p < nplanes; ++p) {
+        float2 *P = lds.data(), *tw = P + NY * Zy::PZ;
+        for (int ph = 0; ph < Zy::NPH; ++ph)
+            for (int tid = 0; tid < 512; ++tid)
+                Zy::fwd_phase(ph, tid, m.data() + p * plane, mainb + p * NY * NZH, nyqb + p * NY, P, tw);
+    }
+    // check the spectrum of plane-wise 2D transforms against the DFT (first batch item, component 1)
+    double err2d = 0, ref2d = 0;
+    {
+        std::vector<cd> a((size_t)NX * NY * NZ);
+        for (size_t i = 0; i < a.size(); ++i) a[i] = m[(size_t)1 * NX * plane + i];
+        dft_axis(a, NX, NY, NZ, 2, -1);
+        dft_axis(a, NX, NY, NZ, 1, -1);
+        for (int x = 0; x < NX; ++x)
+            for (int ky = 0; ky < NY; ++ky)
+                for (int kz = 0; kz <= NZH; ++kz) {
+                    const size_t pl = (size_t)1 * NX + x;
+                    const float2 g = kz < NZH ? mainb[(pl * NY + ky) * NZH + kz] : nyqb[pl * NY + ky];
+                    const cd r = a[((size_t)x * NY + ky) * NZ + kz];
+                    err2d = std::max(err2d, std::abs(cd(g.x, g.y) - r));
+                    ref2d = std::max(ref2d, std::abs(r));
+                }
+    }
+    // x pass
+    XArgs xa;
+    xa.main_ = mainb; xa.nyq = nyqb; xa.tabM = tabM; xa.tabN = tabN;
+    xa.ny = NY; xa.nzh = NZH; xa.nch = NZH / 16; xa.items_per_n = NY * xa.nch + NY / 16;
+    xa.scale = scale; xa.total = (uint32_t)(NN * xa.items_per_n);
+    std::vector<typename Xp::Regs> regs(256);
+    for (uint32_t blk = 0; blk < xa.total; ++blk) {
+        const auto b = Xp::locate(xa, blk);
+        float2 *buf = lds.data(), *tw = buf + 3 * NX * Xp::KCP;
+        for (int ph = 0; ph < Xp::NPH; ++ph)
+            for (int tid = 0; tid < 256; ++tid) Xp::phase(ph, tid, regs[tid], b, buf, tw, xa.scale);
+    }
+    // zy inverse
+    for (size_t p = 0; p < nplanes; ++p) {
+        float2 *P = lds.data(), *tw = P + NY * Zy::PZ;
+        for (int ph = 0; ph < Zy::NPH_INV; ++ph)
+            for (int tid = 0; tid < 512; ++tid)
+                Zy::inv_phase(ph, tid, out.data() + p * plane, mainb + p * NY * NZH, nyqb + p * NY, P, tw);
+    }
+    // reference: full complex 3D DFT in double, operator on every bin, inverse DFT
+    double err = 0, ref = 0;
+    for (int n = 0; n < NN; ++n) {
+        std::vector<cd> a[3];
+        for (int c = 0; c < 3; ++c) {
+            a[c].resize((size_t)NX * NY * NZ);
+            for (size_t i = 0; i < a[c].size(); ++i) a[c][i] = m[((size_t)n * 3 + c) * NX * plane + i];
+            for (int ax = 2; ax >= 0; --ax) dft_axis(a[c], NX, NY, NZ, ax, -1);
+        }
+        for (int kx = 0; kx < NX; ++kx)
+            for (int ky = 0; ky < NY; ++ky)
+                for (int kz = 0; kz < NZ; ++kz) {
+                    // the operator of bin (kx, ky, kz > NZH) is the conjugate-symmetric partner's: the
+                    // table covers the half spectrum, and the tabulated coefficients are real
+                    const int hx = kz <= NZH ? kx : (NX - kx) % NX, hy = kz <= NZH ? ky : (NY - ky) % NY,
+                              hz = kz <= NZH ? kz : NZ - kz;
+                    const float *c = hz < NZH ? tabM + (((size_t)hx * NY + hy) * NZH + hz) * 6
+                                              : tabN + ((size_t)hx * NY + hy) * 6;
+                    const size_t i = ((size_t)kx * NY + ky) * NZ + kz;
+                    op_double<INV>(c, a[0][i], a[1][i], a[2][i]);
+                }
+        for (int c = 0; c < 3; ++c) {
+            for (int ax = 0; ax < 3; ++ax) dft_axis(a[c], NX, NY, NZ, ax, +1);
+            for (size_t i = 0; i < a[c].size(); ++i) {
+                const double r = a[c][i].real() / ((double)NX * NY * NZ);
+                err = std::max(err, std::fabs(r - (double)out[((size_t)n * 3 + c) * NX * plane + i]));
+                ref = std::max(ref, std::fabs(r));
+            }
+        }
+    }
+    const bool ok = err2d <= 2e-5 * ref2d && err <= 2e-5 * ref;
+    printf("%s nx=%d ny=%d nz=%d inverse=%d: 2D spectrum err %.3e (scale %.3e), result err %.3e (scale %.3e)\n",
+           ok ? "ok  " : "FAIL", NX, NY, NZ, (int)INV, err2d, ref2d, err, ref);
+    return ok ? 0 : 1;
+}
+
+int main() {
+    int bad = 0;
+    bad += run_case<6, 5, 6, false>();
+    bad += run_case<6, 6, 7, true>();
+    bad += run_case<7, 5, 6, true>();
+    bad += run_case<6, 7, 6, false>();
+    printf(bad ? "FAILED\n" : "all ok\n");
+    return bad;
+}

@@ -384,29 +384,32 @@ def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
     assert_bits(a[0], orc.interp_forward(I, u, 0.9), "vector interp vs oracle")
 
 
-@pytest.mark.parametrize("sp", [(64, 6, 10), (128, 5, 12), (64, 64, 64), (256, 4, 6), (128, 7, 130)])
+@pytest.mark.parametrize("sp", [(64, 6, 10), (128, 5, 12), (64, 64, 64), (256, 4, 6), (128, 7, 130),
+                                (64, 32, 64), (128, 64, 128), (64, 128, 256), (256, 32, 64), (64, 256, 64)])
 @pytest.mark.parametrize("inverse", [True, False])
-def test_fused_x_pass_fluid_metric(ext, sp, inverse):
-    """float32 3D, power-of-two nx: 2D rocFFT + fused (x-FFT, operator, inverse x-FFT) kernel vs the
-    plain hipFFT 3D path and vs the oracle (numpy FFT)."""
-    import ctypes
+def test_fused_fluid_metric_paths(ext, sp, inverse):
+    """float32 3D: the three implementations of FluidMetric sharp/flat -- (2) three LDS-tiled FFT
+    passes without rocFFT (power-of-two extents), (1) 2D rocFFT + fused (x-FFT, operator, inverse
+    x-FFT) kernel (power-of-two nx), (0) plain 3D hipFFT + operator kernel -- against each other
+    and against the oracle (numpy FFT).  Shapes a mode does not support fall through to the next."""
     import lagomorph_amd as lm
 
-    ext._lib.lago_set_fluid_xpass.argtypes = [ctypes.c_int]
     rng = np.random.default_rng(hash((sp, inverse)) % 2**31)
     m = rnd(rng, (2, 3) + sp, torch.float32)
     md = dev(m)
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     f = met.sharp if inverse else met.flat
-    fused = f(md)
-    ext._lib.lago_set_fluid_xpass(0)
+    got = {}
     try:
-        plain = f(md)
+        for mode in (2, 1, 0):
+            ext.set_fluid_mode(mode)
+            got[mode] = f(md)
     finally:
-        ext._lib.lago_set_fluid_xpass(1)
+        ext.set_fluid_mode(2)
     want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
-    assert_close(fused, want, torch.float32, "x-pass fluid metric vs oracle", mult=10.0)
-    assert_close(fused, host(plain), torch.float32, "x-pass vs plain hipFFT", mult=10.0)
+    for mode in (2, 1, 0):
+        assert_close(got[mode], want, torch.float32, f"fluid metric mode {mode} vs oracle", mult=10.0)
+    assert_close(got[2], host(got[0]), torch.float32, "native passes vs plain hipFFT", mult=10.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
