@@ -133,16 +133,27 @@ __device__ __forceinline__ double lg_fma(double a, double b, double c) { return 
 
 // include/interp.h:64-70: (int)x, minus one for negative non-integers == floor(x).
 // Saturated to +-2^30 (as the oracle does) so that floor + 1 cannot overflow.
-template <typename R>
-__device__ __forceinline__ int lg_floor(R x) {
-    x = x > (R)1073741824.0 ? (R)1073741824.0 : x;
-    x = x < (R)-1073741824.0 ? (R)-1073741824.0 : x;
-    return (int)(sizeof(R) == 4 ? (R)__builtin_floorf((float)x) : (R)__builtin_floor((double)x));
+// float: one v_cvt_flr_i32_f32 (floor + convert, saturating at the int32 range) and one
+// v_med3_i32 -- the same value as saturating first, for every finite x.
+__device__ __forceinline__ int lg_med3(int x, int lo, int hi) {  // lo <= hi
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ int lg_floor(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return lg_med3(r, -1073741824, 1073741824);
+}
+__device__ __forceinline__ int lg_floor(double x) {
+    x = x > 1073741824.0 ? 1073741824.0 : x;
+    x = x < -1073741824.0 ? -1073741824.0 : x;
+    return (int)__builtin_floor(x);
 }
 
 // include/extrap.h:41-44 clamp(); clampBackground (extrap.h:46-57) on a
 // (floor, floor+1) pair is this clamp applied to both members.
-__device__ __forceinline__ int clamp1(int r, int b) { return max(0, min(r, b - 1)); }
+__device__ __forceinline__ int clamp1(int r, int b) { return lg_med3(r, 0, b - 1); }  // b >= 1
 
 // Sample position x + dt*u: computed in double (dt is a double in the
 // reference, cuda/interp.cu:36-37,68-70) and narrowed to R.
@@ -158,6 +169,16 @@ __device__ __forceinline__ R sample_pos(int i, double dt, R u) {
     }
     return (R)__builtin_fma(dt, (double)u, (double)i);
 }
+
+// Unrolled kernels hoist the dt == +-1 decision to a template parameter (float only): the
+// position is fma(+-1, u, i), one rounding of the exact sum, as above.
+template <typename R, bool UNIT>
+__device__ __forceinline__ R sample_pos_t(int i, double dt, R u) {
+    if (UNIT && sizeof(R) == 4) return (R)__builtin_fmaf((float)dt, (float)u, (float)i);
+    return (R)__builtin_fma(dt, (double)u, (double)i);
+}
+template <typename R>
+__host__ __device__ inline bool unit_dt(double dt) { return sizeof(R) == 4 && (dt == 1.0 || dt == -1.0); }
 
 // Gathers go through buffer loads: a 128-bit descriptor in SGPRs (built from a
 // wave-uniform plane pointer) plus a 32-bit per-lane byte offset -- no 64-bit

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(R *__restrict__ out, co
 
 // Unrolled 3D variant (see interp_fwd3_unroll_kernel in interp.hip): U slabs of 256 consecutive
 // voxels per workgroup, one voxel of each slab per lane.
-template <typename R, int U>
+template <typename R, int U, bool UNIT>
 __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__ out, const R *__restrict__ u,
                                                                  const R *__restrict__ v, double ds, double dt, Geom g,
                                                                  uint32_t nbx_u, uint32_t nblocks_u) {
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__
             if (cj >= (uint32_t)g.ny) { cj -= g.ny; ++ci; }
         }
         const uint32_t i = ci, j = cj, k = ck;
-        L[e].setup(sample_pos<R>((int)i, ds, uu[0][e]), sample_pos<R>((int)j, ds, uu[1][e]),
-                   sample_pos<R>((int)k, ds, uu[2][e]), g.nx, g.ny, g.nz);
+        L[e].setup(sample_pos_t<R, UNIT>((int)i, ds, uu[0][e]), sample_pos_t<R, UNIT>((int)j, ds, uu[1][e]),
+                   sample_pos_t<R, UNIT>((int)k, ds, uu[2][e]), g.nx, g.ny, g.nz);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -121,8 +121,12 @@ static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, in
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
         if (nb < (1ull << 31)) {
-            hipLaunchKernelGGL((compose3_unroll_kernel<R, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, u, v, ds, dt,
-                               g, nbx_u, (uint32_t)nb);
+            if (unit_dt<R>(ds))
+                hipLaunchKernelGGL((compose3_unroll_kernel<R, U, true>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, u, v,
+                                   ds, dt, g, nbx_u, (uint32_t)nb);
+            else
+                hipLaunchKernelGGL((compose3_unroll_kernel<R, U, false>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, u, v,
+                                   ds, dt, g, nbx_u, (uint32_t)nb);
             return finish_launch(s, "compose");
         }
     }

@@ -9,7 +9,6 @@
 
 namespace lago {
 
-int g_dbg_variant = 0;  // profiling only (tools/): 0 = production
 
 // ------------------------------------------------------------------ forward
 
@@ -45,10 +44,10 @@ __global__ __launch_bounds__(kBlock) void interp_fwd_kernel(R *__restrict__ out,
 // then bound by L1 (TCP) line accesses: 652 per wave, one per clock per CU = the kernel time.
 // With slab-interleaved voxels every load and every gather of a wave covers ~256 contiguous bytes
 // (a few L1 lines), and the U * 4 pair gathers of a channel are still issued back to back.
-template <typename R, bool BC, int U>
+template <typename R, bool BC, int U, bool UNIT>
 __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restrict__ out, const R *__restrict__ I,
                                                                     const R *__restrict__ u, double dt, int nc,
-                                                                    Geom g, uint32_t nbx_u, uint32_t nblocks_u, int dbg) {
+                                                                    Geom g, uint32_t nbx_u, uint32_t nblocks_u) {
     const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
     const uint32_t n = Lb / nbx_u;  // uniform: scalar division
     const uint32_t bx = Lb - n * nbx_u;
@@ -87,18 +86,14 @@ __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restric
             if (cj >= (uint32_t)g.ny) { cj -= g.ny; ++ci; }
         }
         const uint32_t i = ci, j = cj, k = ck;
-        L[e].setup(sample_pos<R>((int)i, dt, ux[e]), sample_pos<R>((int)j, dt, uy[e]), sample_pos<R>((int)k, dt, uz[e]),
-                   g.nx, g.ny, g.nz);
+        L[e].setup(sample_pos_t<R, UNIT>((int)i, dt, ux[e]), sample_pos_t<R, UNIT>((int)j, dt, uy[e]),
+                   sample_pos_t<R, UNIT>((int)k, dt, uz[e]), g.nx, g.ny, g.nz);
     }
     for (int c = 0; c < nc; ++c) {
         const R *Ic = In + (size_t)c * nv;
         R o[U];
 #pragma unroll
-        for (int e = 0; e < U; ++e) {
-            if (dbg == 0) o[e] = L[e].value(Ic);
-            else if (dbg == 1) o[e] = Ic[s[e]] * L[e].t;            // profiling: coalesced load instead of gathers
-            else o[e] = L[e].t + L[e].u + L[e].v;                  // profiling: no image access at all
-        }
+        for (int e = 0; e < U; ++e) o[e] = L[e].value(Ic);
 #pragma unroll
         for (int e = 0; e < U; ++e)
             if (ok[e]) on[(size_t)c * nv + s[e]] = o[e];
@@ -220,12 +215,16 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
         if (nb < (1ull << 31)) {
-            if (bc)
-                hipLaunchKernelGGL((interp_fwd3_unroll_kernel<R, true, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out,
-                                   I, u, dt, (int)nc, g, nbx_u, (uint32_t)nb, g_dbg_variant);
-            else
-                hipLaunchKernelGGL((interp_fwd3_unroll_kernel<R, false, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out,
-                                   I, u, dt, (int)nc, g, nbx_u, (uint32_t)nb, g_dbg_variant);
+#define LAUNCH_U(B, UN)                                                                                              \
+    hipLaunchKernelGGL((interp_fwd3_unroll_kernel<R, B, U, UN>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, I, u, dt, \
+                       (int)nc, g, nbx_u, (uint32_t)nb)
+            const bool unit = unit_dt<R>(dt);
+            if (bc) {
+                if (unit) LAUNCH_U(true, true); else LAUNCH_U(true, false);
+            } else {
+                if (unit) LAUNCH_U(false, true); else LAUNCH_U(false, false);
+            }
+#undef LAUNCH_U
             return finish_launch(s, "interp_forward");
         }
     }
@@ -308,7 +307,6 @@ static int hessdiag_impl(R *out, const R *u, double dt, int64_t nI, int64_t nn, 
 }  // namespace lago
 
 extern "C" {
-void lago_debug_interp_variant(int v) { lago::g_dbg_variant = v; }  // profiling only
 #define LAGO_DEFINE(REAL, SUF)                                                                                     \
     int lago_interp_forward##SUF(REAL *out, const REAL *I, const REAL *u, double dt, int dim, int64_t nn,         \
                                  int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc, void *stream) {          \

@@ -38,7 +38,8 @@
 namespace lago {
 
 // How a source voxel's sample position is obtained.
-enum { POS_DISP = 0,     // x + dt*u(x): interp_backward (cuda/interp.cu:185-244)
+enum { POS_DISP_UNIT = 3,  // POS_DISP with dt == +-1 in float: positions are one float fma (common.hpp)
+       POS_DISP = 0,     // x + dt*u(x): interp_backward (cuda/interp.cu:185-244)
        POS_AFFINE = 1,   // A(x - c) + T + c: affine_interp_backward's image splat (cuda/affine.cu:330-536)
        POS_REGRID = 2 }; // (X - C)S + O: regrid_backward (cuda/affine.cu:767-800)
 struct PosArgs {
@@ -54,16 +55,14 @@ struct TileGeom {
     int MX, MY, MZ;     // margin below the probed origin
     uint32_t ntx, nty, ntz, tiles_per_item, total;
     uint32_t tile_groups, win_cells;   // tile size in VPL-groups; window size in cells
-    int ablate;                        // profiling only (tools/ablate_splat.py): bit0 no LDS adds, bit1 no fallback
                                        // atomics, bit2 no flush atomics; always 0 in production
     FastDiv d_tiles, d_tyz, d_tz;      // block id -> (n, bx, by, bz)
     FastDiv d_TyTzq, d_Tzq;            // tile group id -> (a, b, cq)
-    FastDiv d_WyWz, d_Wz;              // window cell id -> (lx, ly, lz)
+    FastDiv d_wey;                     // window row id -> (lx, ly)
 };
 
 // TX TY TZ(0 = auto) window margins MX MY MZ around the probed origin, threads per workgroup
-static int g_tile_cfg[7] = {16, 8, 64, 1, 1, 4, 1024};
-static int g_ablate = 0;
+static int g_tile_cfg[7] = {0, 8, 0, 1, 1, 4, 512};
 
 __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -108,6 +107,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const size_t nv = (size_t)nx * ny * nz;       // target plane
     const size_t snv = (size_t)snx * sny * snz;   // source plane
     const double dt = pa.dt;
+    constexpr bool DISP = MODE == POS_DISP || MODE == POS_DISP_UNIT;
 
     // workgroup -> (batch item, tile)
     const uint32_t L = xcd_swizzle(blockIdx.x, tg.total);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const int x0 = bx * tg.TX, y0 = by * tg.TY, z0 = bz * tg.TZ;
     const int ex = min(tg.TX, snx - x0), ey = min(tg.TY, sny - y0), ez = min(tg.TZ, snz - z0);
 
-    const R *un = MODE == POS_DISP ? static_cast<const R *>(pa.u) + (size_t)n * 3 * snv : nullptr;
+    const R *un = DISP ? static_cast<const R *>(pa.u) + (size_t)n * 3 * snv : nullptr;
     const R *An = MODE == POS_AFFINE ? static_cast<const R *>(pa.A) + (size_t)n * 9 : nullptr;
     const R *Tn = MODE == POS_AFFINE ? static_cast<const R *>(pa.T) + (size_t)n * 3 : nullptr;
     const R *In = BC ? I : I + (size_t)n * nc * nv;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     // tile origin + displacement probed at the tile centre; for the analytic maps, the minimum over
     // the images of the tile's 8 corner voxels (exact for affine maps) -- minus a margin
     int bxo, byo, bzo;
-    if (MODE == POS_DISP) {
+    if (DISP) {
         const size_t sc = ((size_t)(x0 + ex / 2) * ny + (y0 + ey / 2)) * nz + (z0 + ez / 2);
         const float fdt = (float)dt;
         bxo = x0 + (int)floorf(fdt * (float)un[sc]);
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const int wy0 = max(0, min(byo - tg.MY, ny - wey));
     const int wz0 = max(0, min((bzo - tg.MZ) & ~15, nz - wez));
     const int WY = tg.WY, WZ = tg.WZ;
+    // floor corners whose whole footprint is unclamped and inside the window: lo <= f <= hi - 1
+    const int ilox = wx0, iloy = wy0, iloz = wz0;   // the window lies inside the grid
+    const int ispx = wex - 1, ispy = wey - 1, ispz = wez - 1;
+    const int wbase = -((wx0 * WY + wy0) * WZ + wz0);
 
     for (int c = 0; c < nc; ++c) {
         for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0.0;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                 live[e] = t < tg.tile_groups && (int)a < ex && (int)b < ey && (int)cc < ez;
                 vi[e] = x0 + a; vj[e] = y0 + b; vk[e] = z0 + cc;
                 sv[e] = live[e] ? ((size_t)vi[e] * sny + vj[e]) * snz + vk[e] : 0;
-                if (MODE == POS_DISP) {
+                if (DISP) {
                     ux[e] = un[sv[e]];
                     uy[e] = un[sv[e] + nv];
                     uz[e] = un[sv[e] + 2 * nv];
@@ -197,10 +201,10 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
             for (int e = 0; e < VPL; ++e) {
                 if (!live[e]) continue;
                 R hx, hy, hz;
-                if (MODE == POS_DISP) {
-                    hx = sample_pos<R>(vi[e], dt, ux[e]);
-                    hy = sample_pos<R>(vj[e], dt, uy[e]);
-                    hz = sample_pos<R>(vk[e], dt, uz[e]);
+                if (DISP) {
+                    hx = sample_pos_t<R, MODE == POS_DISP_UNIT>(vi[e], dt, ux[e]);
+                    hy = sample_pos_t<R, MODE == POS_DISP_UNIT>(vj[e], dt, uy[e]);
+                    hz = sample_pos_t<R, MODE == POS_DISP_UNIT>(vk[e], dt, uz[e]);
                 } else {
                     analytic_pos<R, MODE>(hx, hy, hz, vi[e], vj[e], vk[e], An, Tn, pa, tg);
                 }
@@ -210,31 +214,47 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                 R dx = (R)1.f - (hx - (R)fx);
                 R dy = (R)1.f - (hy - (R)fy);
                 R dz = (R)1.f - (hz - (R)fz);
-                const int gi[2] = {clamp1(fx, nx), clamp1(fx + 1, nx)};
-                const int gj[2] = {clamp1(fy, ny), clamp1(fy + 1, ny)};
-                const int gk[2] = {clamp1(fz, nz), clamp1(fz + 1, nz)};
+                // weights in the reference's order: dz flips after every corner, dy after every
+                // second, dx after the fourth (1 - (1 - d) is not always d, so the chain is kept)
+                R wgt[8];
+                {
+                    R ddx = dx, ddy = dy, ddz = dz;
 #pragma unroll
-                for (int qa = 0; qa < 2; ++qa) {
-                    const int lx = gi[qa] - wx0;
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) {
-                        const int ly = gj[qb] - wy0;
-#pragma unroll
-                        for (int qc = 0; qc < 2; ++qc) {
-                            const int lz = gk[qc] - wz0;
-                            const R val = (dx * dy * dz) * diff;
-                            const bool inside = (unsigned)lx < (unsigned)wex && (unsigned)ly < (unsigned)wey &&
-                                                (unsigned)lz < (unsigned)wez;
-                            if (inside) {
-                                if (!(tg.ablate & 1)) lds_add(&win[(lx * WY + ly) * WZ + lz], (double)val);
-                            } else if (!(tg.ablate & 2)) {
-                                atomic_add(dIc + ((size_t)gi[qa] * ny + gj[qb]) * nz + gk[qc], val);
-                            }
-                            dz = (R)1.f - dz;
-                        }
-                        dy = (R)1.f - dy;
+                    for (int q = 0; q < 8; ++q) {
+                        wgt[q] = (ddx * ddy * ddz) * diff;
+                        ddz = (R)1.f - ddz;
+                        if (q & 1) ddy = (R)1.f - ddy;
+                        if ((q & 3) == 3) ddx = (R)1.f - ddx;
                     }
-                    dx = (R)1.f - dx;
+                }
+                // fast path: the 2x2x2 footprint is unclamped and inside the window -> one address,
+                // eight LDS adds at fixed offsets
+                const bool interior = (unsigned)(fx - ilox) < (unsigned)ispx && (unsigned)(fy - iloy) < (unsigned)ispy &&
+                                      (unsigned)(fz - iloz) < (unsigned)ispz;
+                if (interior) {
+                    double *w0 = win + ((fx * WY + fy) * WZ + fz + wbase);
+                    double *w1 = w0 + WZ, *w2 = w0 + WY * WZ, *w3 = w2 + WZ;
+                    lds_add(w0, (double)wgt[0]);
+                    lds_add(w0 + 1, (double)wgt[1]);
+                    lds_add(w1, (double)wgt[2]);
+                    lds_add(w1 + 1, (double)wgt[3]);
+                    lds_add(w2, (double)wgt[4]);
+                    lds_add(w2 + 1, (double)wgt[5]);
+                    lds_add(w3, (double)wgt[6]);
+                    lds_add(w3 + 1, (double)wgt[7]);
+                } else {
+                    const int gi[2] = {clamp1(fx, nx), clamp1(fx + 1, nx)};
+                    const int gj[2] = {clamp1(fy, ny), clamp1(fy + 1, ny)};
+                    const int gk[2] = {clamp1(fz, nz), clamp1(fz + 1, nz)};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int cx = gi[q >> 2], cy = gj[(q >> 1) & 1], cz = gk[q & 1];
+                        const int lx = cx - wx0, ly = cy - wy0, lz = cz - wz0;
+                        const bool inside = (unsigned)lx < (unsigned)wex && (unsigned)ly < (unsigned)wey &&
+                                            (unsigned)lz < (unsigned)wez;
+                        if (inside) lds_add(&win[(lx * WY + ly) * WZ + lz], (double)wgt[q]);
+                        else atomic_add(dIc + ((size_t)cx * ny + cy) * nz + cz, wgt[q]);
+                    }
                 }
                 if (NEED_U) {
                     Lerp3<R, false> Lq;  // nz >= 2 guaranteed by the host: lets the compiler batch the gathers
@@ -249,15 +269,20 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
             }
         }
         __syncthreads();
-        // flush touched cells: consecutive lanes -> consecutive z of one window row
-        for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) {
-            const double acc = win[f];
-            if (acc != 0.0 && !(tg.ablate & 4)) {
-                const uint32_t lx = tg.d_WyWz.div(f);
-                const uint32_t r2 = f - lx * (uint32_t)(WY * WZ);
-                const uint32_t ly = tg.d_Wz.div(r2);
-                const uint32_t lz = r2 - ly * (uint32_t)WZ;
-                atomic_add(dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + (wz0 + lz), (R)acc);
+        // flush touched cells: one wave per window row (lx, ly) -- the row decode and both base
+        // addresses are wave-uniform (scalar), the lanes run along z
+        {
+            const int lane = threadIdx.x & 63;
+            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const uint32_t nrows = (uint32_t)(wex * wey);
+            for (uint32_t row = wv; row < nrows; row += NT / 64) {
+                const uint32_t lx = tg.d_wey.div(row), ly = row - lx * (uint32_t)wey;
+                const double *wrow = win + (lx * (uint32_t)WY + ly) * (uint32_t)WZ;
+                R *grow = dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + wz0;
+                for (int lz = lane; lz < wez; lz += 64) {
+                    const double acc = wrow[lz];
+                    if (acc != 0.0) atomic_add(grow + lz, (R)acc);
+                }
             }
         }
         __syncthreads();
@@ -268,12 +293,20 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
 // target cells one source step spans along axis d (1 for a displacement field); when given, the
 // tile is shrunk until its image fits the LDS window.
 static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, const double *sc, size_t &smem,
-                       int &nthreads) {
-    int TX = g_tile_cfg[0], TY = g_tile_cfg[1], TZ = g_tile_cfg[2];
-    const int EX = g_tile_cfg[3], EY = g_tile_cfg[4], EZ = g_tile_cfg[5];
-    nthreads = g_tile_cfg[6] >= 1024 ? 1024 : (g_tile_cfg[6] >= 512 ? 512 : 256);
-    if (TX < 1 || TY < 1 || EX < 0 || EY < 0 || EZ < 0) return false;
-    if (TZ <= 0) TZ = 32;
+                       int &nthreads, const int *cfg = g_tile_cfg) {
+    int TX = cfg[0], TY = cfg[1], TZ = cfg[2];
+    const int EX = cfg[3], EY = cfg[4], EZ = cfg[5];
+    nthreads = cfg[6] >= 1024 ? 1024 : (cfg[6] >= 512 ? 512 : 256);
+    if (TY < 1 || EX < 0 || EY < 0 || EZ < 0) return false;
+    if (TZ <= 0) {  // auto: whole z rows, split evenly when they are longer than 160 voxels
+        const int parts = (gs.nz + 159) / 160;
+        TZ = (((gs.nz + parts - 1) / parts + 15) / 16) * 16;
+    }
+    if (TX <= 0) {  // auto: about 4096 voxels per tile (measured optimum at 128^3: 4 x 8 x 128, 512 threads)
+        const int per = TY * (TZ < gs.nz ? TZ : gs.nz);
+        TX = (4096 + per - 1) / per;
+        if (TX < 4) TX = 4;
+    }
     TX = TX < gs.nx ? TX : gs.nx;
     TY = TY < gs.ny ? TY : gs.ny;
     TZ = TZ < gs.nz ? TZ : gs.nz;
@@ -318,14 +351,12 @@ static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, 
     tg.total = (uint32_t)total;
     tg.tile_groups = (uint32_t)TX * TY * TZ;  // voxels per tile
     while (nthreads > 256 && (uint32_t)nthreads > tg.tile_groups) nthreads >>= 1;
-    tg.ablate = g_ablate;
     tg.d_tiles = FastDiv(tg.tiles_per_item);
     tg.d_tyz = FastDiv(tg.nty * tg.ntz);
     tg.d_tz = FastDiv(tg.ntz);
     tg.d_TyTzq = FastDiv((uint32_t)(TY * TZ));
     tg.d_Tzq = FastDiv((uint32_t)TZ);
-    tg.d_WyWz = FastDiv((uint32_t)(tg.WY * tg.WZ));
-    tg.d_Wz = FastDiv((uint32_t)tg.WZ);
+    tg.d_wey = FastDiv((uint32_t)(tg.WY < g.ny ? tg.WY : g.ny));
     return true;
 }
 
@@ -366,9 +397,11 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     pa.u = u;
     pa.dt = dt;
     hipError_t e;
+    const bool unit = unit_dt<R>(dt);
 #define GO(B, U) \
-    e = vec ? by_threads<R, POS_DISP, B, U, V>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s) \
-            : by_threads<R, POS_DISP, B, U, 1>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s)
+    e = !vec   ? by_threads<R, POS_DISP, B, U, 1>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s)          \
+        : unit ? by_threads<R, POS_DISP_UNIT, B, U, V>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s)     \
+               : by_threads<R, POS_DISP, B, U, V>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s)
     if (bc) {
         if (need_u) GO(true, true); else GO(true, false);
     } else {
@@ -388,7 +421,10 @@ int affine_splat_lds(R *d_I, const R *go, const R *A, const R *T, int nc, int64_
     size_t smem;
     int nt;
     if (g.nz < 2) return 1;
-    if (!make_tiles(tg, g, g, nn, nullptr, smem, nt)) return 1;
+    // a sheared / rotated tile spreads along every axis: compact tiles keep its image inside the
+    // window (the thin 4 x 8 x nz default of the displacement mode does not)
+    static const int affine_cfg[7] = {16, 8, 64, 1, 1, 4, 1024};
+    if (!make_tiles(tg, g, g, nn, nullptr, smem, nt, affine_cfg)) return 1;
     PosArgs pa{};
     pa.A = A;
     pa.T = T;
@@ -441,5 +477,4 @@ void lago_set_splat_tile(int tx, int ty, int tz, int ex, int ey, int ez, int nth
     lago::g_tile_cfg[3] = ex; lago::g_tile_cfg[4] = ey; lago::g_tile_cfg[5] = ez;
     lago::g_tile_cfg[6] = nthreads;
 }
-void lago_debug_splat_ablate(int mask) { lago::g_ablate = mask; }  // profiling only; results are wrong when != 0
 }

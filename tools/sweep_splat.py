@@ -16,11 +16,11 @@ go = torch.randn((B, 1, S, S, S), device=dev, generator=g)
 V = B * S ** 3
 ref = None
 cfgs = []
-for (tx, ty) in ((4, 4), (8, 8), (8, 4), (16, 8), (2, 2), (16, 16)):
-    for tz in (0, 64, 32):
-        for (mx, mz) in ((1, 4), (2, 8), (3, 8)):
-            for nt in (256, 512, 1024):
-                cfgs.append((tx, ty, tz, mx, mx, mz, nt))
+for (tx, ty, tz) in ((16, 8, 64), (8, 8, 128), (16, 4, 128), (12, 8, 128), (8, 4, 128), (4, 8, 128), (8, 8, 64), (16, 8, 32),
+                     (16, 16, 32), (32, 8, 32), (8, 8, 32), (4, 4, 128), (16, 16, 16), (32, 16, 16)):
+    for (mx, mz) in ((1, 4), (1, 0), (0, 0), (2, 4)):
+        for nt in (256, 512, 1024):
+            cfgs.append((tx, ty, tz, mx, mx, mz, nt))
 res = []
 for cfg in cfgs:
     ext.set_splat_tile(*cfg)
