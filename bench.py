@@ -181,6 +181,7 @@ def micro_ops(lm, dev, size, batch=8):
         "interp_forward(C=3)": (lambda: ext.interp_forward(v, u, 1.0), 36),
         "interp_backward(C=3)": (lambda: ext.interp_backward(go, v, u, 1.0, True, True), 60),
         "compose": (lambda: ext.compose(u, v, -0.1, 1.0), 36),
+        "ad_star(fused interp+jtv)": (lambda: ext.ad_star(u, w), 36),
         "affine_interp_forward(C=1)": (lambda: ext.affine_interp_forward(I1, A, T), 8),
         "affine_interp_backward(C=1)": (lambda: ext.affine_interp_backward(I1, I1, A, T, True, True, True), 12),
         "regrid_forward(64^3->128^3,C=3)": (lambda: ext.regrid_forward(small, [size] * 3, [(size // 2 - 1) * 0.5] * 3,
@@ -210,9 +211,12 @@ def cpu_baseline(size, euler_steps, sample_batch=1):
     o = OracleExt()
     names = ["interp_forward", "jacobian_times_vectorfield_forward", "fluid_operator", "compose"]
     saved = {n: getattr(lm.lagomorph_ext, n) for n in names}
-    fused_flag = lmm.USE_FUSED_FLUID
+    from lagomorph_amd import adjrep as lma
+
+    fused_flag, fused_ad = lmm.USE_FUSED_FLUID, lma.USE_FUSED_AD_STAR
     try:
         lmm.USE_FUSED_FLUID = False  # the oracle has the reference's three-call form only
+        lma.USE_FUSED_AD_STAR = False  # ... and Ad_star as interp + jacobian_times_vectorfield
         for n in names:
             setattr(lm.lagomorph_ext, n, getattr(o, n))
         rng = np.random.default_rng(7)
@@ -225,6 +229,7 @@ def cpu_baseline(size, euler_steps, sample_batch=1):
         dt = time.perf_counter() - t0
     finally:
         lmm.USE_FUSED_FLUID = fused_flag
+        lma.USE_FUSED_AD_STAR = fused_ad
         for n, f in saved.items():
             setattr(lm.lagomorph_ext, n, f)
     vox = sample_batch * size ** 3 * euler_steps
@@ -275,7 +280,8 @@ def main():
         def step():
             return lm.expmap(metric, m, num_steps=E)
 
-        names = ["interp_forward", "jacobian_times_vectorfield_forward", "fluid_operator", "fluid_metric", "compose"]
+        names = ["interp_forward", "jacobian_times_vectorfield_forward", "fluid_operator", "fluid_metric", "compose",
+                 "ad_star"]
         with KernelTimer(ext, names) as kt:
             for _ in range(args.warmup):
                 step()
@@ -325,23 +331,37 @@ def main():
         },
     }
     if rank == 0:
-        k = ksum.get("interp_forward")
-        if k:
-            bytes_per_launch = 36.0 * V  # 4*(C*V + 3*V + C*V), C = 3
+        # the dominant single kernel of the timed region (fluid_metric is three kernels and is reported
+        # separately): all four candidates move 36 algorithmic bytes per voxel at C = 3
+        cands = {
+            "ad_star": ("ad_star3_unroll_kernel<float,4>", "lago::ad_star3_unroll_kernel<float"),
+            "compose": ("compose3_unroll_kernel<float,4>", "lago::compose3_unroll_kernel<float"),
+            "interp_forward": ("interp_fwd3_unroll_kernel<float,false,4> (C=3)", "lago::interp_fwd3_unroll_kernel<float"),
+            "jacobian_times_vectorfield_forward": ("jtv_fwd_kernel<float,3,true,false>", "lago::jtv_fwd_kernel<float, 3, true"),
+        }
+        present = {n: ksum[n] for n in cands if n in ksum and ksum[n]["launches"]}
+        if present:
+            op = max(present, key=lambda n: present[n]["total_ms"])
+            k, (kname, prefix) = present[op], cands[op]
+            bytes_per_launch = 36.0 * V  # 4*(3 + 3 + 3) bytes per voxel
             ach = bytes_per_launch / (k["mean_ms"] * 1e-3) / 1e9
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
             # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and B == 32 and S == 128:
-                rec = json.load(open(tpath)).get("lago::interp_fwd3_unroll_kernel<float, false, 4>")
-                if rec:
-                    traffic, tsrc = rec["traffic_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc, same workload)"
+                for name, rec in json.load(open(tpath)).items():
+                    if name.startswith(prefix):
+                        traffic, tsrc = rec["traffic_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc, same workload)"
+                        break
             result["roofline"] = {
-                "kernel": "interp_fwd3_unroll_kernel<float,false,4> (C=3)", "bound": "hbm", "achieved": ach,
+                "kernel": kname, "op": op, "bound": "hbm", "achieved": ach,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": tsrc,
                 "bytes_per_launch": bytes_per_launch, "mean_launch_ms": k["mean_ms"], "launches": k["launches"],
+                "others": {n: {"mean_launch_ms": present[n]["mean_ms"],
+                               "frac": 36.0 * V / (present[n]["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                           for n in present if n != op},
             }
         total_ms = 1e3 * T
         result["breakdown_ms_per_step"] = {n: s["total_ms"] / args.steps for n, s in ksum.items()}

@@ -2,8 +2,34 @@ r"""Adjoint representation of Diff(R^d) on velocities and momenta.
 
 Host-side mirror of ``/root/reference/lagomorph/adjrep.py`` (same formulas).
 """
+import torch
+
+from . import lagomorph_ext
 from .deform import interp
 from .diff import jacobian_times_vectorfield, jacobian_times_vectorfield_adjoint
+
+USE_FUSED_AD_STAR = True
+
+
+class AdStarFunction(torch.autograd.Function):
+    """(D phiinv + I) (m o (id + phiinv)) as ONE kernel (csrc/fused.hip), bit-identical to the
+    two-call sequence of adjrep.py:86-97.  The backward recomputes the resampled momentum and is the
+    chain of the two reference backward kernels."""
+
+    @staticmethod
+    def forward(ctx, phiinv, m):
+        ctx.save_for_backward(phiinv, m)
+        return lagomorph_ext.ad_star(phiinv.contiguous(), m.contiguous())
+
+    @staticmethod
+    def backward(ctx, gradout):
+        phiinv, m = ctx.saved_tensors
+        phiinv, m, gradout = phiinv.contiguous(), m.contiguous(), gradout.contiguous()
+        need_phi, need_m = ctx.needs_input_grad
+        mphiinv = lagomorph_ext.interp_forward(m, phiinv, 1.0)
+        d_v, d_w = lagomorph_ext.jacobian_times_vectorfield_backward(gradout, phiinv, mphiinv, True, False, need_phi, True)
+        d_m, d_u = lagomorph_ext.interp_backward(d_w, m, phiinv, 1.0, need_m, need_phi)
+        return (d_v + d_u) if need_phi else None, d_m if need_m else None
 
 
 def ad(v, w):
@@ -27,6 +53,9 @@ def ad_star(v, m):
 
 def Ad_star(phiinv, m):
     r"""Ad^*(phi, m)(x) = (D phi(x)) m(phi(x)); note the non-transposed product (adjrep.py:86-97)"""
+    if (USE_FUSED_AD_STAR and hasattr(lagomorph_ext, "ad_star") and phiinv.shape == m.shape
+            and m.size(1) == m.dim() - 2 and phiinv.dtype == m.dtype):
+        return AdStarFunction.apply(phiinv, m)
     mphiinv = interp(m, phiinv)
     return jacobian_times_vectorfield(phiinv, mphiinv, displacement=True)
 

@@ -137,6 +137,193 @@ static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, in
     return finish_launch(s, "compose");
 }
 
+// ------------------------------------------------------------------ Ad^*(phi, m) in one pass
+//
+// ad_star: out = (D phiinv + I) (m o (id + phiinv)), i.e. adjrep.Ad_star of the reference
+// (/root/reference/lagomorph/adjrep.py:86-97): interp(m, phiinv) followed by
+// jacobian_times_vectorfield(phiinv, ., displacement=True).  Unfused, the resampled momentum makes a
+// round trip through HBM (12 + 12 bytes per voxel of 72); here it stays in registers.  The
+// interpolated components are rounded to R exactly where the unfused sequence stores them, and the
+// Jacobian product is the expression of jtv_fwd_kernel (diff.hip), so the result is bit-identical.
+
+// 0.5 (f[+1] - f[-1]) with the neighbour offsets clamped at the borders (include/diff.h:55-76)
+template <typename R>
+__device__ __forceinline__ R cdiff(const R *__restrict__ f, int plus, int minus) {
+    return (R)0.5f * (f[plus] - f[minus]);
+}
+
+template <typename R, int DIM>
+__global__ __launch_bounds__(kBlock) void ad_star_kernel(R *__restrict__ out, const R *__restrict__ phi,
+                                                         const R *__restrict__ m, Geom g) {
+    const Vox vx = locate(g);
+    if (!vx.valid) return;
+    const size_t nv = g.nvox;
+    const R *pn = phi + (size_t)vx.n * DIM * nv + vx.s;
+    const R *mn = m + (size_t)vx.n * DIM * nv;
+    R *on = out + (size_t)vx.n * DIM * nv + vx.s;
+    R pv[DIM], wv[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) pv[d] = pn[(size_t)d * nv];
+    int plus[DIM], minus[DIM];
+    if (DIM == 3) {
+        Lerp3<R> L;
+        L.setup(sample_pos<R>(vx.i, 1.0, pv[0]), sample_pos<R>(vx.j, 1.0, pv[1]), sample_pos<R>(vx.k, 1.0, pv[2]),
+                g.nx, g.ny, g.nz);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wv[d] = L.value(mn + (size_t)d * nv);
+        const int P[3] = {vx.i, vx.j, vx.k}, Ln[3] = {g.nx, g.ny, g.nz}, St[3] = {g.ny * g.nz, g.nz, 1};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            plus[d] = P[d] + 1 < Ln[d] ? St[d] : 0;
+            minus[d] = P[d] > 0 ? -St[d] : 0;
+        }
+    } else {
+        Lerp2<R> L;
+        L.setup(sample_pos<R>(vx.j, 1.0, pv[0]), sample_pos<R>(vx.k, 1.0, pv[1]), g.ny, g.nz);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) wv[d] = L.value(mn + (size_t)d * nv);
+        const int P[2] = {vx.j, vx.k}, Ln[2] = {g.ny, g.nz}, St[2] = {g.nz, 1};
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            plus[d] = P[d] + 1 < Ln[d] ? St[d] : 0;
+            minus[d] = P[d] > 0 ? -St[d] : 0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+        R gq[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            gq[d] = cdiff(pn + (size_t)c * nv, plus[d], minus[d]);
+            if (c == d) gq[d] = gq[d] + (R)1.0;
+        }
+        R sacc = lg_fma(gq[0], wv[0], gq[1] * wv[1]);  // dotw of diff.hip
+        if (DIM == 3) sacc = lg_fma(gq[2], wv[2], sacc);
+        on[(size_t)c * nv] = sacc;
+    }
+}
+
+// Unrolled 3D variant: U slabs of 256 consecutive voxels per workgroup, one voxel of each per lane.
+template <typename R, int U>
+__global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__ out, const R *__restrict__ phi,
+                                                                 const R *__restrict__ m, Geom g, uint32_t nbx_u,
+                                                                 uint32_t nblocks_u) {
+    const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
+    const uint32_t n = Lb / nbx_u;  // uniform: scalar division
+    const uint32_t bx = Lb - n * nbx_u;
+    const size_t nv = g.nvox;
+    const R *pn = phi + (size_t)n * 3 * nv;
+    const R *mn = m + (size_t)n * 3 * nv;
+    R *on = out + (size_t)n * 3 * nv;
+    uint32_t s[U];
+    bool ok[U];
+    R pv[3][U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+        s[e] = (bx * U + e) * kBlock + threadIdx.x;
+        ok[e] = s[e] < g.nvox;
+        if (!ok[e]) s[e] = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pv[d][e] = pn[(size_t)d * nv + s[e]];
+    }
+    Lerp3<R, false> L[U];  // nz >= 2 guaranteed by the host
+    int plus[3][U], minus[3][U];
+    uint32_t ci = 0, cj = 0, ck = 0;
+    const uint32_t qj = (uint32_t)kBlock / (uint32_t)g.nz, rk = (uint32_t)kBlock % (uint32_t)g.nz;  // uniform
+    const int syz = g.ny * g.nz;
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+        if (e == 0) {
+            ci = g.dyz.div(s[0]);
+            const uint32_t r = s[0] - ci * (uint32_t)(g.ny * g.nz);
+            cj = g.dz.div(r);
+            ck = r - cj * (uint32_t)g.nz;
+        } else {
+            ck += rk;
+            cj += qj;
+            if (ck >= (uint32_t)g.nz) { ck -= g.nz; ++cj; }
+            if (cj >= (uint32_t)g.ny) { cj -= g.ny; ++ci; }
+        }
+        // past-the-end lanes were redirected to voxel 0 for their loads; give them its coordinates
+        const int i = ok[e] ? (int)ci : 0, j = ok[e] ? (int)cj : 0, k = ok[e] ? (int)ck : 0;
+        L[e].setup(sample_pos_t<R, true>(i, 1.0, pv[0][e]), sample_pos_t<R, true>(j, 1.0, pv[1][e]),
+                   sample_pos_t<R, true>(k, 1.0, pv[2][e]), g.nx, g.ny, g.nz);
+        plus[0][e] = i + 1 < g.nx ? syz : 0;
+        minus[0][e] = i > 0 ? -syz : 0;
+        plus[1][e] = j + 1 < g.ny ? g.nz : 0;
+        minus[1][e] = j > 0 ? -g.nz : 0;
+        plus[2][e] = k + 1 < g.nz ? 1 : 0;
+        minus[2][e] = k > 0 ? -1 : 0;
+    }
+    R wv[3][U];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d) __builtin_amdgcn_sched_barrier(0);  // 16 pair loads in flight at a time, as in interp / compose
+#pragma unroll
+        for (int e = 0; e < U; ++e) wv[d][e] = L[e].value(mn + (size_t)d * nv);
+    }
+    // keep the gather phase and the three stencil phases apart: hoisting the 72 stencil loads above
+    // the lerps doubled the register count (201 VGPRs, 2 waves/SIMD) for no gain in overlap
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c) __builtin_amdgcn_sched_barrier(0);
+        // neighbours through a buffer descriptor on the component plane: 32-bit byte offsets,
+        // no 64-bit address pair per load
+        const BufRsrc pc = make_rsrc(pn + (size_t)c * nv, (uint32_t)(nv * sizeof(R)));
+        R fp[3][U], fm[3][U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const uint32_t sb = s[e] * (uint32_t)sizeof(R);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                fp[d][e] = buf_load1<R>(pc, sb + (uint32_t)(plus[d][e] * (int)sizeof(R)));
+                fm[d][e] = buf_load1<R>(pc, sb + (uint32_t)(minus[d][e] * (int)sizeof(R)));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            R gq[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                gq[d] = (R)0.5f * (fp[d][e] - fm[d][e]);
+                if (c == d) gq[d] = gq[d] + (R)1.0;
+            }
+            const R sacc = lg_fma(gq[2], wv[2][e], lg_fma(gq[0], wv[0][e], gq[1] * wv[1][e]));
+            if (ok[e]) on[(size_t)c * nv + s[e]] = sacc;
+        }
+    }
+}
+
+template <typename R>
+static int ad_star_impl(R *out, const R *phi, const R *m, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz,
+                        void *stream) {
+    if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional fields are supported");
+    Geom g;
+    if (!make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("ad_star: bad extent");
+    if (g.nblocks == 0) return LAGO_OK;
+    if (!out || !phi || !m) return fail_invalid("ad_star: null pointer");
+    if (out == phi || out == m) return fail_invalid("ad_star: out may not alias an input");
+    if (nx <= 1 || ny <= 1 || (dim == 3 && nz <= 1))
+        return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int U = 2;
+    if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
+        const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
+        const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
+        if (nb < (1ull << 31)) {
+            hipLaunchKernelGGL((ad_star3_unroll_kernel<R, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, phi, m, g,
+                               nbx_u, (uint32_t)nb);
+            return finish_launch(s, "ad_star");
+        }
+    }
+    if (dim == 3)
+        hipLaunchKernelGGL((ad_star_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, phi, m, g);
+    else
+        hipLaunchKernelGGL((ad_star_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, out, phi, m, g);
+    return finish_launch(s, "ad_star");
+}
+
 }  // namespace lago
 
 extern "C" {
@@ -147,5 +334,13 @@ int lago_compose_f32(float *out, const float *u, const float *v, double ds, doub
 int lago_compose_f64(double *out, const double *u, const double *v, double ds, double dt, int dim, int64_t nn,
                      int64_t nx, int64_t ny, int64_t nz, void *stream) {
     return lago::compose_impl<double>(out, u, v, ds, dt, dim, nn, nx, ny, nz, stream);
+}
+int lago_ad_star_f32(float *out, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+                     int64_t nz, void *stream) {
+    return lago::ad_star_impl<float>(out, phiinv, m, dim, nn, nx, ny, nz, stream);
+}
+int lago_ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+                     int64_t nz, void *stream) {
+    return lago::ad_star_impl<double>(out, phiinv, m, dim, nn, nx, ny, nz, stream);
 }
 }

@@ -464,3 +464,67 @@ def test_regrid_backward_tiled_splat(ext, dtype, sp, out, scale):
     finally:
         ext.set_splat_mode(1)
     assert_close(got0, want, dtype, "regrid backward (global atomics)", mult=8.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(5, 6, 7), (8, 8, 8), (7, 9), (2, 2), (4, 3, 64), (9, 5, 70), (20, 12, 40), (2, 6, 5)])
+def test_fused_ad_star_bit_exact(ext, dtype, sp):
+    """Ad_star in one kernel == interp_forward followed by jacobian_times_vectorfield_forward
+    (displacement=True), bit for bit, against the oracle and against this library's own two calls
+    (unrolled and scalar kernels)."""
+    rng = np.random.default_rng(hash(sp) % 2**31)
+    d = len(sp)
+    phi = _disp(rng, 2, sp, dtype)
+    m = rnd(rng, (2, d) + sp, dtype)
+    want = orc.jacobian_times_vectorfield_forward(phi, orc.interp_forward(m, phi, 1.0), True, False)
+    pd, md = dev(phi), dev(m)
+    for vec in (1, 0):
+        ext.set_vector_kernels(vec)
+        try:
+            got = ext.ad_star(pd, md)
+            two = ext.jacobian_times_vectorfield_forward(pd, ext.interp_forward(md, pd, 1.0), True, False)
+        finally:
+            ext.set_vector_kernels(1)
+        assert_bits(got, want, f"ad_star (vector kernels {vec})")
+        assert torch.equal(got, two)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(6, 5, 8), (7, 9)])
+def test_fused_ad_star_backward_matches_unfused(ext, dtype, sp):
+    """AdStarFunction.backward (recompute + the two reference backward kernels) == autograd through the
+    unfused pair."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import adjrep
+
+    rng = np.random.default_rng(5)
+    d = len(sp)
+    phi = dev(0.7 * rnd(rng, (2, d) + sp, dtype))
+    m = dev(rnd(rng, (2, d) + sp, dtype))
+    go = dev(rnd(rng, (2, d) + sp, dtype))
+    grads = {}
+    for fused in (True, False):
+        adjrep.USE_FUSED_AD_STAR = fused
+        try:
+            p, q = phi.clone().requires_grad_(True), m.clone().requires_grad_(True)
+            out = lm.Ad_star(p, q)
+            out.backward(go)
+            grads[fused] = (out.detach(), p.grad, q.grad)
+        finally:
+            adjrep.USE_FUSED_AD_STAR = True
+    assert torch.equal(grads[True][0], grads[False][0])
+    assert_close(grads[True][1], host(grads[False][1]), dtype, "d_phiinv", mult=4.0)
+    assert_close(grads[True][2], host(grads[False][2]), dtype, "d_m", mult=4.0)
+
+
+def test_ad_star_rejects_bad_arguments(ext):
+    a = torch.zeros((1, 3, 4, 4, 4), device="cuda")
+    with pytest.raises(RuntimeError):
+        ext.ad_star(a, torch.zeros((1, 2, 4, 4, 4), device="cuda"))
+    with pytest.raises(RuntimeError):
+        ext.ad_star(a.cpu(), a.cpu())
+    with pytest.raises(RuntimeError):
+        ext.ad_star(a, a.double())
+    thin = torch.zeros((1, 3, 4, 4, 1), device="cuda")
+    with pytest.raises(RuntimeError, match="thin"):
+        ext.ad_star(thin, thin)
