@@ -334,9 +334,9 @@ def main():
         # the dominant single kernel of the timed region (fluid_metric is three kernels and is reported
         # separately): all four candidates move 36 algorithmic bytes per voxel at C = 3
         cands = {
-            "ad_star": ("ad_star3_unroll_kernel<float,4>", "lago::ad_star3_unroll_kernel<float"),
-            "compose": ("compose3_unroll_kernel<float,4>", "lago::compose3_unroll_kernel<float"),
-            "interp_forward": ("interp_fwd3_unroll_kernel<float,false,4> (C=3)", "lago::interp_fwd3_unroll_kernel<float"),
+            "ad_star": ("ad_star3_unroll_kernel<float,2>", "lago::ad_star3_unroll_kernel<float"),
+            "compose": ("compose3_unroll_kernel<float,2,false>", "lago::compose3_unroll_kernel<float"),
+            "interp_forward": ("interp_fwd3_unroll_kernel<float,false,2,true> (C=3)", "lago::interp_fwd3_unroll_kernel<float"),
             "jacobian_times_vectorfield_forward": ("jtv_fwd_kernel<float,3,true,false>", "lago::jtv_fwd_kernel<float, 3, true"),
         }
         present = {n: ksum[n] for n in cands if n in ksum and ksum[n]["launches"]}

@@ -116,7 +116,7 @@ static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, in
     if (g.nblocks == 0) return LAGO_OK;
     if (!out || !u || !v) return fail_invalid("compose: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    constexpr int U = 4;
+    constexpr int U = 2;
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;

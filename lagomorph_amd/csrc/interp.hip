@@ -210,7 +210,7 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
     if (g.nblocks == 0 || nc == 0) return LAGO_OK;  // empty batch / no channels: nothing to write
     if (!out || !I || !u) return fail_invalid("interp_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    constexpr int U = 4;
+    constexpr int U = 2;
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
