@@ -197,6 +197,28 @@ def micro_ops(lm, dev, size, batch=8):
     return out
 
 
+def micro_atlas_step(lm, dev, size, batch=8):
+    """One matching step of the atlas builder (lddmm.py:300-325: expmap 5 steps -> interp -> loss ->
+    backward through every operator -> momentum update) at batch 8 x size^3, momenta that shoot to
+    ~3 voxels of displacement, learning rate 0 so that every timed step sees the same state."""
+    metric = lm.FluidMetric([0.1, 0.0, 0.01])
+    g = torch.Generator(device=dev).manual_seed(4321)
+    I = gaussian_blur(torch.randn((1, 1, size, size, size), device=dev, generator=g), 3.0)
+    I = (I / I.std()).requires_grad_(True)
+    img = gaussian_blur(torch.randn((batch, 1, size, size, size), device=dev, generator=g), 3.0)
+    img = img / img.std()
+    with torch.no_grad():
+        m = gaussian_blur(torch.randn((batch, 3, size, size, size), device=dev, generator=g), 4.0)
+        m *= 3.0 / metric.sharp(m).abs().max()
+
+    def step():
+        lm.lddmm_step(I, m, img, metric, dataset_size=batch, integration_steps=5, learning_rate_pose=0.0)
+
+    med, _ = time_op(step, reps=5, warm=2)
+    return {"workload": f"lddmm_step (fwd + bwd + update) batch {batch} x {size}^3 fp32, 5 integration steps",
+            "ms": med, "Gvoxel_per_s": batch * size ** 3 / med / 1e6}
+
+
 def cpu_baseline(size, euler_steps, sample_batch=1):
     """Times the CPU oracle (test infrastructure, 1 thread) on a bounded sample of the headline
     workload: `sample_batch` volumes of size^3, one expmap of `euler_steps` steps.  The oracle
@@ -372,6 +394,8 @@ def main():
             result["fluid"] = micro_fluid(lm, dev, S)
             torch.cuda.empty_cache()
             result["other_ops"] = micro_ops(lm, dev, S)
+            torch.cuda.empty_cache()
+            result["atlas_step"] = micro_atlas_step(lm, dev, S)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S, E, args.cpu_sample_batch)
         print(json.dumps(result))
