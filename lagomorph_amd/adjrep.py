@@ -29,7 +29,7 @@ class AdStarFunction(torch.autograd.Function):
         mphiinv = lagomorph_ext.interp_forward(m, phiinv, 1.0)
         d_v, d_w = lagomorph_ext.jacobian_times_vectorfield_backward(gradout, phiinv, mphiinv, True, False, need_phi, True)
         d_m, d_u = lagomorph_ext.interp_backward(d_w, m, phiinv, 1.0, need_m, need_phi)
-        return (d_v + d_u) if need_phi else None, d_m if need_m else None
+        return d_v.add_(d_u) if need_phi else None, d_m if need_m else None
 
 
 def ad(v, w):

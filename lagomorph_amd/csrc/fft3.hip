@@ -13,9 +13,12 @@
 
 namespace lago {
 
+// threads per plane: 1024 once a plane has at least 2048 float4 (two per thread)
+constexpr int zy_threads(int logny, int lognz) { return logny + lognz >= 13 ? 1024 : 512; }
+
 template <int LOGNY, int LOGNZ>
-__global__ __launch_bounds__(512) void zy_forward_kernel(fl::ZYArgs a) {
-    using K = fl::ZY<LOGNY, LOGNZ, 512>;
+__global__ __launch_bounds__(zy_threads(LOGNY, LOGNZ)) void zy_forward_kernel(fl::ZYArgs a) {
+    using K = fl::ZY<LOGNY, LOGNZ, zy_threads(LOGNY, LOGNZ)>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
     const size_t p = blockIdx.x;
@@ -29,8 +32,8 @@ __global__ __launch_bounds__(512) void zy_forward_kernel(fl::ZYArgs a) {
 }
 
 template <int LOGNY, int LOGNZ>
-__global__ __launch_bounds__(512) void zy_inverse_kernel(fl::ZYArgs a) {
-    using K = fl::ZY<LOGNY, LOGNZ, 512>;
+__global__ __launch_bounds__(zy_threads(LOGNY, LOGNZ)) void zy_inverse_kernel(fl::ZYArgs a) {
+    using K = fl::ZY<LOGNY, LOGNZ, zy_threads(LOGNY, LOGNZ)>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
     const size_t p = blockIdx.x;
@@ -79,17 +82,18 @@ static hipError_t allow_smem(Kern k, size_t smem) {
 
 template <int LY, int LZ>
 static hipError_t zy_launch(const fl::ZYArgs &a, bool inverse, hipStream_t s) {
-    using K = fl::ZY<LY, LZ, 512>;
+    constexpr int NT = zy_threads(LY, LZ);
+    using K = fl::ZY<LY, LZ, NT>;
     if (inverse) {
         auto k = zy_inverse_kernel<LY, LZ>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(512), K::SMEM, s, a);
+        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
     } else {
         auto k = zy_forward_kernel<LY, LZ>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(512), K::SMEM, s, a);
+        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
     }
     return hipSuccess;
 }

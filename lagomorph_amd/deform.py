@@ -61,11 +61,12 @@ class ComposeFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gradout):
         u, v = ctx.saved_tensors
-        gi = (ctx.dt * gradout).contiguous()  # gradient reaching the interp output
+        gradout = gradout.contiguous()
+        gi = gradout if ctx.dt == 1.0 else ctx.dt * gradout  # gradient reaching the interp output
         d_v, d_u = lagomorph_ext.interp_backward(gi, v.contiguous(), u.contiguous(), ctx.ds,
                                                  ctx.needs_input_grad[1], ctx.needs_input_grad[0])
         if ctx.needs_input_grad[0]:
-            d_u = ctx.ds * gradout + d_u
+            d_u.add_(gradout, alpha=ctx.ds)  # d_u is a fresh tensor owned by this call
         return d_u, d_v, None, None
 
 
