@@ -119,7 +119,9 @@ def micro_interp_splat(ext, dev, size, batch=8):
         r = {"fwd_ms": fwd_med, "fwd_GBps": 20.0 * V / fwd_med / 1e6}
         for mode in (1, 0):
             ext.set_splat_mode(mode)
-            bwd_med, _ = time_op(lambda: ext.interp_backward(go, I, uu, 1.0, True, True))
+            # the global-atomics leg is only a comparison figure: few repetitions
+            bwd_med, _ = time_op(lambda: ext.interp_backward(go, I, uu, 1.0, True, True),
+                                 reps=20 if mode == 1 else 4, warm=5 if mode == 1 else 1)
             tag = "lds" if mode == 1 else "atomics"
             r[f"bwd_{tag}_ms"] = bwd_med
             r[f"bwd_{tag}_GBps"] = 36.0 * V / bwd_med / 1e6
