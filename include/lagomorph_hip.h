@@ -150,9 +150,9 @@ int lago_compose_f64(double *out, const double *u, const double *v, double ds, d
  * followed by jacobian_times_vectorfield_forward(displacement = true).  phiinv, m, out:
  * (nn, dim, sp); out may not alias an input.  Bit-identical to the two-call sequence (the
  * resampled momentum is rounded where that sequence stores it). */
-int lago_ad_star_f32(float *out, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+int lago_Ad_star_f32(float *out, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
                      int64_t nz, void *stream);
-int lago_ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx,
+int lago_Ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx,
                      int64_t ny, int64_t nz, void *stream);
 
 /* fluid_metric: the whole FluidMetricOperator.forward of the reference

@@ -19,7 +19,7 @@ class AdStarFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, phiinv, m):
         ctx.save_for_backward(phiinv, m)
-        return lagomorph_ext.ad_star(phiinv.contiguous(), m.contiguous())
+        return lagomorph_ext.Ad_star(phiinv.contiguous(), m.contiguous())
 
     @staticmethod
     def backward(ctx, gradout):
@@ -53,7 +53,7 @@ def ad_star(v, m):
 
 def Ad_star(phiinv, m):
     r"""Ad^*(phi, m)(x) = (D phi(x)) m(phi(x)); note the non-transposed product (adjrep.py:86-97)"""
-    if (USE_FUSED_AD_STAR and hasattr(lagomorph_ext, "ad_star") and phiinv.shape == m.shape
+    if (USE_FUSED_AD_STAR and hasattr(lagomorph_ext, "Ad_star") and phiinv.shape == m.shape
             and m.size(1) == m.dim() - 2 and phiinv.dtype == m.dtype):
         return AdStarFunction.apply(phiinv, m)
     mphiinv = interp(m, phiinv)

@@ -347,11 +347,11 @@ int lago_compose_f64(double *out, const double *u, const double *v, double ds, d
                      int64_t nx, int64_t ny, int64_t nz, void *stream) {
     return lago::compose_impl<double>(out, u, v, ds, dt, dim, nn, nx, ny, nz, stream);
 }
-int lago_ad_star_f32(float *out, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+int lago_Ad_star_f32(float *out, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
                      int64_t nz, void *stream) {
     return lago::ad_star_impl<float>(out, phiinv, m, dim, nn, nx, ny, nz, stream);
 }
-int lago_ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+int lago_Ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx, int64_t ny,
                      int64_t nz, void *stream) {
     return lago::ad_star_impl<double>(out, phiinv, m, dim, nn, nx, ny, nz, stream);
 }

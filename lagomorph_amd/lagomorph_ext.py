@@ -51,7 +51,7 @@ _SIGS = {
     "lago_regrid_forward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
-    "lago_ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
+    "lago_Ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_fluid_metric": [_vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64, _i64,
                           _i64, _vp],
 }
@@ -414,7 +414,7 @@ def compose(u, v, ds=1.0, dt=1.0):
     return out
 
 
-def ad_star(phiinv, m):
+def Ad_star(phiinv, m):
     """Fused adjrep.Ad_star (adjrep.py:86-97): jacobian_times_vectorfield(phiinv, interp(m, phiinv),
     displacement=True) in one kernel.  Not part of the reference's extension surface."""
     _check_input(phiinv, "phiinv")
@@ -424,9 +424,9 @@ def ad_star(phiinv, m):
     if dim not in (2, 3):
         raise RuntimeError("Only two- and three-dimensional fields are supported")
     if phiinv.shape != m.shape or m.size(1) != dim:
-        raise RuntimeError("ad_star: phiinv and m must be vector fields of the same shape")
+        raise RuntimeError("Ad_star: phiinv and m must be vector fields of the same shape")
     out = torch.empty_like(m)
-    _call("lago_ad_star", m, _ptr(out), _ptr(phiinv), _ptr(m), dim, m.size(0), nx, ny, nz)
+    _call("lago_Ad_star", m, _ptr(out), _ptr(phiinv), _ptr(m), dim, m.size(0), nx, ny, nz)
     return out
 
 

@@ -481,7 +481,7 @@ def test_fused_ad_star_bit_exact(ext, dtype, sp):
     for vec in (1, 0):
         ext.set_vector_kernels(vec)
         try:
-            got = ext.ad_star(pd, md)
+            got = ext.Ad_star(pd, md)
             two = ext.jacobian_times_vectorfield_forward(pd, ext.interp_forward(md, pd, 1.0), True, False)
         finally:
             ext.set_vector_kernels(1)
@@ -520,14 +520,14 @@ def test_fused_ad_star_backward_matches_unfused(ext, dtype, sp):
 def test_ad_star_rejects_bad_arguments(ext):
     a = torch.zeros((1, 3, 4, 4, 4), device="cuda")
     with pytest.raises(RuntimeError):
-        ext.ad_star(a, torch.zeros((1, 2, 4, 4, 4), device="cuda"))
+        ext.Ad_star(a, torch.zeros((1, 2, 4, 4, 4), device="cuda"))
     with pytest.raises(RuntimeError):
-        ext.ad_star(a.cpu(), a.cpu())
+        ext.Ad_star(a.cpu(), a.cpu())
     with pytest.raises(RuntimeError):
-        ext.ad_star(a, a.double())
+        ext.Ad_star(a, a.double())
     thin = torch.zeros((1, 3, 4, 4, 1), device="cuda")
     with pytest.raises(RuntimeError, match="thin"):
-        ext.ad_star(thin, thin)
+        ext.Ad_star(thin, thin)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -564,7 +564,7 @@ def test_lds_staged_gathers_bit_exact(ext, dtype, sp, kind):
             assert_bits(ext.interp_forward(Id, ud, 0.9), want["interp"], f"interp {cfg}")
             assert_bits(ext.interp_forward(I1d, ud, 1.0), want["interp_bc"], f"interp broadcast {cfg}")
             assert_bits(ext.compose(ud, vd, -0.1, 1.0), want["compose"], f"compose {cfg}")
-            assert_bits(ext.ad_star(ud, vd), want["ad_star"], f"ad_star {cfg}")
+            assert_bits(ext.Ad_star(ud, vd), want["ad_star"], f"ad_star {cfg}")
     finally:
         ext.set_gather_mode(0)
         ext.set_gather_tile(8, 8, 64, 1, 1, 1, 1024)

@@ -18,7 +18,7 @@ I1 = torch.randn((B, 1, S, S, S), device=dev, generator=g)
 
 def row(tag):
     a, _ = time_op(lambda: ext.compose(u, v, -0.1, 1.0), reps=10, warm=3)
-    b, _ = time_op(lambda: ext.ad_star(u, w), reps=10, warm=3)
+    b, _ = time_op(lambda: ext.Ad_star(u, w), reps=10, warm=3)
     c, _ = time_op(lambda: ext.interp_forward(I1, u, 1.0), reps=10, warm=3)
     print(f"{tag:40s} compose(ds=-0.1) {a*1e3:7.1f}  ad_star {b*1e3:7.1f}  interp C=1 {c*1e3:7.1f} us", flush=True)
 
