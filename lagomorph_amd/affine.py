@@ -2,7 +2,8 @@
 
 Host-side mirror of the operator part of ``/root/reference/lagomorph/affine.py``
 (``AffineInterpFunction`` :11-36, helpers :49-148, ``RegridFunction`` / ``regrid``
-:151-285).  The HDF5-driven ``affine_atlas`` driver is outside this build's scope.
+:151-285) and of the compute loop of ``affine_atlas`` / ``StandardizedDataset`` (:288-438) on
+device-resident tensors (the DataLoader / HDF5 plumbing around it is outside this build's scope).
 Kernels: ``csrc/affine.hip``.
 """
 import torch
@@ -160,3 +161,139 @@ class RegridModule(torch.nn.Module):
 
     def forward(self, I):
         return regrid(I, self.shape, self.origin, self.spacing)
+
+
+# --------------------------------------------------------------------------- affine atlas
+
+
+def batch_average(images, batch_size=50):
+    """Mean over the first axis, accumulated minibatch by minibatch (utils.batch_average of the
+    reference as used at affine.py:328-333), on the device the images live on."""
+    acc = torch.zeros_like(images[:1])
+    for b in range(0, images.size(0), batch_size):
+        acc += images[b:b + batch_size].sum(dim=0, keepdim=True)
+    return acc / max(images.size(0), 1)
+
+
+def affine_atlas(images, As, Ts, I=None, num_epochs=1000, batch_size=50, image_update_freq=0, affine_steps=1,
+                 reg_weightA=0e1, reg_weightT=0e1, learning_rate_A=1e-3, learning_rate_T=1e-2, learning_rate_I=1e5,
+                 world_size=1, rank=0, dataset_size=None):
+    """Affine atlas building on device-resident data: the compute loop of ``affine_atlas``
+    (affine.py:288-415) without its DataLoader / HDF5 plumbing.
+
+    images: (N, 1, *spatial) -- this rank's contiguous shard of the subjects (the reference shards
+    with a DistributedSampler); As (N, d, d) and Ts (N, d): the matching shard of the affine
+    parameters, stored as in the reference as the deviation from the identity (the map applied is
+    A + eye, T).  They are updated in place and returned.  ``dataset_size`` is the total number of
+    subjects over all ranks (default N * world_size).
+
+    Same update rules as the reference: per minibatch ``affine_steps`` gradient steps on (A, T) with
+    the image gradient accumulated on the last one; the image takes an SGD step every
+    ``image_update_freq`` minibatches (0: once per epoch) on the gradient averaged over minibatches
+    and ranks -- ONE all-reduce of the (1, 1, *spatial) gradient per image update.  Differences: the
+    losses stay on the device until the end (no per-iteration host synchronisation) and the epoch
+    loss is all-reduced once per epoch.
+
+    Returns (I, As, Ts, epoch_losses, iter_losses) like the reference."""
+    import torch.distributed as dist
+
+    N = images.size(0)
+    if dataset_size is None:
+        dataset_size = N * world_size
+    dev, dt = images.device, As.dtype
+    sp = tuple(images.shape[2:])
+    dim = len(sp)
+    nvox = 1
+    for s in sp:
+        nvox *= s
+    if I is None:
+        with torch.no_grad():
+            I = batch_average(images.to(dt), batch_size)
+            if world_size > 1:
+                dist.all_reduce(I)
+                I /= world_size
+    else:
+        I = I.clone().to(dev)
+    I = I.to(dt).view(1, 1, *sp).contiguous()
+    eye = torch.eye(dim, dtype=dt, device=dev).view(1, dim, dim)
+    epoch_losses, iter_losses = [], []
+    grad_I = torch.zeros_like(I)
+
+    def image_step(image_iters):
+        # affine.py:389-396, 404-409: average over accumulated minibatches and ranks, plain SGD
+        if world_size > 1:
+            dist.all_reduce(grad_I)
+        I.sub_(grad_I, alpha=learning_rate_I / (image_iters * world_size))
+
+    for epoch in range(num_epochs):
+        epoch_loss = torch.zeros((), dtype=dt, device=dev)
+        if image_update_freq == 0 or epoch == 0:
+            grad_I.zero_()
+        image_iters = 0
+        for b in range(0, N, batch_size):
+            img = images[b:b + batch_size].to(dt)
+            A = As[b:b + batch_size].detach().clone().contiguous()
+            T = Ts[b:b + batch_size].detach().clone().contiguous()
+            nb = img.size(0)
+            for affit in range(affine_steps):
+                A.requires_grad_(True)
+                T.requires_grad_(True)
+                A.grad = None
+                T.grad = None
+                last = affit == affine_steps - 1
+                Iv = I.detach().requires_grad_(last)  # the image gradient is accumulated on the last affine step only
+                Idef = affine_interp(Iv, A + eye, T)
+                regloss = 0.0
+                if reg_weightA > 0:
+                    regloss = regloss + 0.5 * reg_weightA * (A * A).sum()
+                if reg_weightT > 0:
+                    regloss = regloss + 0.5 * reg_weightT * (T * T).sum()
+                loss = (((Idef - img) ** 2).sum() * (1.0 / nvox) + regloss) / nb
+                loss.backward()
+                with torch.no_grad():
+                    li = loss.detach() * (nb / dataset_size)
+                    iter_losses.append(li)
+                    A.sub_(A.grad, alpha=learning_rate_A)
+                    T.sub_(T.grad, alpha=learning_rate_T)
+                    if last:
+                        grad_I.add_(Iv.grad)
+            image_iters += 1
+            with torch.no_grad():
+                if image_iters == image_update_freq:
+                    image_step(image_iters)
+                    grad_I.zero_()
+                    image_iters = 0
+                epoch_loss = epoch_loss + li
+                As[b:b + batch_size] = A.detach()
+                Ts[b:b + batch_size] = T.detach()
+        with torch.no_grad():
+            if image_iters > 0:
+                image_step(image_iters)
+            if world_size > 1:
+                dist.all_reduce(epoch_loss)
+        epoch_losses.append(epoch_loss)
+    epoch_losses = [float(x) for x in epoch_losses]
+    iter_losses = [float(x) for x in iter_losses]
+    return I.detach(), As.detach(), Ts.detach(), epoch_losses, iter_losses
+
+
+class StandardizedDataset:
+    """Subjects resampled into atlas space by the inverse of their fitted affine map
+    (affine.py:418-438); ``dataset[idx]`` is one (C, *spatial) image."""
+
+    def __init__(self, dataset, As, Ts, device="cuda"):
+        self.dataset, self.As, self.Ts, self.device = dataset, As, Ts, device
+        dim = Ts.shape[1]
+        self.eye = torch.eye(dim, dtype=As.dtype, device=device).view(1, dim, dim)
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, idx):
+        J = self.dataset[idx].to(self.device).unsqueeze(0)
+        A = self.As[[idx], ...].to(self.device)
+        T = self.Ts[[idx], ...].to(self.device)
+        Ainv, Tinv = affine_inverse(A + self.eye, T)
+        if J.dtype not in (torch.float32, torch.float64):
+            J = J.to(torch.float32)
+        return affine_interp(J.contiguous(), Ainv.contiguous(), Tinv.contiguous()).squeeze(0)

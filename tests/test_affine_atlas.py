@@ -1,0 +1,88 @@
+"""affine_atlas / StandardizedDataset (host mirror of affine.py:288-438) on the oracle backend (CPU)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _subjects(lm, n, sp, seed=3):
+    """A smooth blob pushed through small random affine maps."""
+    rng = np.random.default_rng(seed)
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in sp], indexing="ij")
+    c = [(s - 1) / 2 for s in sp]
+    blob = np.exp(-sum((g - ci) ** 2 for g, ci in zip(grids, c)) / (2 * (min(sp) / 5) ** 2))
+    base = torch.from_numpy(blob)[None, None]
+    d = len(sp)
+    A = torch.eye(d, dtype=torch.float64)[None] + 0.08 * torch.from_numpy(rng.standard_normal((n, d, d)))
+    T = 0.8 * torch.from_numpy(rng.standard_normal((n, d)))
+    return lm.affine_interp(base, A.contiguous(), T.contiguous()).detach()
+
+
+@pytest.mark.parametrize("sp", [(14, 12), (8, 9, 7)])
+def test_affine_atlas_reduces_the_loss_and_moves_the_parameters(oracle_ext, sp):
+    import lagomorph_amd as lm
+
+    n, d = 6, len(sp)
+    images = _subjects(lm, n, sp)
+    As = torch.zeros((n, d, d), dtype=torch.float64)
+    Ts = torch.zeros((n, d), dtype=torch.float64)
+    I, As2, Ts2, ep, it = lm.affine_atlas(images, As, Ts, num_epochs=6, batch_size=4, learning_rate_A=2e-3,
+                                          learning_rate_T=5e-2, learning_rate_I=1.0)
+    assert I.shape == (1, 1) + sp and len(ep) == 6 and len(it) == 6 * 2
+    assert ep[-1] < ep[0]
+    assert float(As2.abs().max()) > 0 and float(Ts2.abs().max()) > 0
+    # epoch loss = sum of the per-iteration losses of that epoch
+    assert ep[0] == pytest.approx(it[0] + it[1], rel=1e-12)
+
+
+def test_affine_atlas_first_iteration_matches_the_formulas(oracle_ext):
+    """lr = 0: the atlas stays the mean image and every loss is the plain mean squared error."""
+    import lagomorph_amd as lm
+
+    sp, n = (10, 11), 5
+    images = _subjects(lm, n, sp, seed=9)
+    As = torch.zeros((n, 2, 2), dtype=torch.float64)
+    Ts = torch.zeros((n, 2), dtype=torch.float64)
+    I, _, _, ep, it = lm.affine_atlas(images, As, Ts, num_epochs=1, batch_size=2, learning_rate_A=0.0, learning_rate_T=0.0,
+                                      learning_rate_I=0.0, reg_weightA=0.3, reg_weightT=0.2)
+    mean = images.mean(dim=0, keepdim=True)
+    assert torch.allclose(I, mean, rtol=0, atol=1e-14)
+    want = [(((mean - images[b:b + 2]) ** 2).sum() / (sp[0] * sp[1]) / images[b:b + 2].size(0)
+             * (images[b:b + 2].size(0) / n)).item() for b in range(0, n, 2)]
+    assert it == pytest.approx(want, rel=1e-10)
+    assert ep[0] == pytest.approx(sum(want), rel=1e-10)
+
+
+def test_affine_atlas_image_update_frequency(oracle_ext):
+    """image_update_freq = 1 takes an image step after every minibatch (affine.py:389-396)."""
+    import lagomorph_amd as lm
+
+    sp, n = (9, 8), 4
+    images = _subjects(lm, n, sp, seed=1)
+    z = lambda *s: torch.zeros(s, dtype=torch.float64)
+    I0, *_ = lm.affine_atlas(images, z(n, 2, 2), z(n, 2), num_epochs=1, batch_size=2, image_update_freq=0,
+                             learning_rate_A=0.0, learning_rate_T=0.0, learning_rate_I=0.5)
+    I1, *_ = lm.affine_atlas(images, z(n, 2, 2), z(n, 2), num_epochs=1, batch_size=2, image_update_freq=1,
+                             learning_rate_A=0.0, learning_rate_T=0.0, learning_rate_I=0.5)
+    mean = images.mean(dim=0, keepdim=True)
+    # with A = T = 0 the deformed atlas is the atlas: d/dI of the per-minibatch loss is 2 (I - img) / (nvox B)
+    g = [2 * (mean - images[b:b + 2]).sum(dim=0, keepdim=True) / (sp[0] * sp[1] * 2) for b in (0, 2)]
+    assert torch.allclose(I0, mean - 0.5 * (g[0] + g[1]) / 2, atol=1e-13)
+    step1 = mean - 0.5 * g[0]
+    g1 = 2 * (step1 - images[2:4]).sum(dim=0, keepdim=True) / (sp[0] * sp[1] * 2)
+    assert torch.allclose(I1, step1 - 0.5 * g1, atol=1e-13)
+
+
+def test_standardized_dataset_inverts_the_fitted_map(oracle_ext):
+    import lagomorph_amd as lm
+
+    sp = (12, 12)
+    base = _subjects(lm, 1, sp, seed=0)[0]  # (1, 12, 12), one channel
+    A = torch.tensor([[[0.05, -0.03], [0.02, -0.04]]], dtype=torch.float64)
+    T = torch.tensor([[0.4, -0.3]], dtype=torch.float64)
+    eye = torch.eye(2, dtype=torch.float64)[None]
+    moved = lm.affine_interp(base[None], (A + eye).contiguous(), T.contiguous())[0]
+    ds = lm.StandardizedDataset([moved], A, T, device="cpu")
+    back = ds[0]
+    assert len(ds) == 1 and back.shape == base.shape
+    inner = (slice(None), slice(3, 9), slice(3, 9))
+    assert float((back[inner] - base[inner]).abs().max()) < 0.1 * float(base.abs().max())  # two bilinear resamplings
