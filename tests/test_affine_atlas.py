@@ -86,3 +86,30 @@ def test_standardized_dataset_inverts_the_fitted_map(oracle_ext):
     assert len(ds) == 1 and back.shape == base.shape
     inner = (slice(None), slice(3, 9), slice(3, 9))
     assert float((back[inner] - base[inner]).abs().max()) < 0.1 * float(base.abs().max())  # two bilinear resamplings
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sp", [(14, 12), (8, 9, 7)])
+def test_affine_atlas_hip_matches_oracle_backend(sp, monkeypatch):
+    """The same atlas run through the HIP kernels and through the oracle backend agree (float64; the
+    scatter-add gradients differ only in summation order)."""
+    import lagomorph_amd as lm
+    from oracle.lago_oracle import OracleExt
+
+    n, d = 6, len(sp)
+    # subjects built on the oracle backend (CPU) so that both runs see identical inputs
+    o = OracleExt()
+    saved = {k: getattr(lm.lagomorph_ext, k) for k in ("affine_interp_forward", "affine_interp_backward")}
+    for k in saved:
+        monkeypatch.setattr(lm.lagomorph_ext, k, getattr(o, k))
+    images = _subjects(lm, n, sp)
+    kw = dict(num_epochs=3, batch_size=4, learning_rate_A=2e-3, learning_rate_T=5e-2, learning_rate_I=1.0,
+              image_update_freq=1, affine_steps=2)
+    z = lambda *s, dev="cpu": torch.zeros(s, dtype=torch.float64, device=dev)
+    Ic, Ac, Tc, epc, _ = lm.affine_atlas(images, z(n, d, d), z(n, d), **kw)
+    for k, f in saved.items():
+        monkeypatch.setattr(lm.lagomorph_ext, k, f)
+    Ig, Ag, Tg, epg, _ = lm.affine_atlas(images.cuda(), z(n, d, d, dev="cuda"), z(n, d, dev="cuda"), **kw)
+    assert epg == pytest.approx(epc, rel=1e-9)
+    assert torch.allclose(Ig.cpu(), Ic, rtol=0, atol=1e-10)
+    assert torch.allclose(Ag.cpu(), Ac, rtol=0, atol=1e-10) and torch.allclose(Tg.cpu(), Tc, rtol=0, atol=1e-10)
