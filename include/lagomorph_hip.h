@@ -145,7 +145,7 @@ int lago_compose_f32(float *out, const float *u, const float *v, double ds, doub
 int lago_compose_f64(double *out, const double *u, const double *v, double ds, double dt, int dim, int64_t nn,
                      int64_t nx, int64_t ny, int64_t nz, void *stream);
 
-/* ad_star: out = (D phiinv + I) (m o (id + phiinv)) -- adjrep.Ad_star
+/* Ad_star (the coadjoint action of a diffeomorphism): out = (D phiinv + I) (m o (id + phiinv)) -- adjrep.Ad_star
  * (/root/reference/lagomorph/adjrep.py:86-97), which the reference evaluates as interp_forward
  * followed by jacobian_times_vectorfield_forward(displacement = true).  phiinv, m, out:
  * (nn, dim, sp); out may not alias an input.  Bit-identical to the two-call sequence (the
@@ -154,6 +154,16 @@ int lago_Ad_star_f32(float *out, const float *phiinv, const float *m, int dim, i
                      int64_t nz, void *stream);
 int lago_Ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx,
                      int64_t ny, int64_t nz, void *stream);
+
+/* ad_star (the infinitesimal coadjoint action): out = (Dv)^T m - sum_d D_d^T (v_d m) -- adjrep.ad_star
+ * (/root/reference/lagomorph/adjrep.py:69-83), which the reference evaluates as
+ * jacobian_times_vectorfield_forward(v, m, transpose = true) minus
+ * jacobian_times_vectorfield_adjoint_forward(m, v).  v, m, out: (nn, dim, sp); out may not alias an input.
+ * Bit-identical to the three-call sequence. */
+int lago_ad_star_f32(float *out, const float *v, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+                     int64_t nz, void *stream);
+int lago_ad_star_f64(double *out, const double *v, const double *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+                     int64_t nz, void *stream);
 
 /* fluid_metric: the whole FluidMetricOperator.forward of the reference
  * (/root/reference/lagomorph/metric.py:11-19) in one call: out = irfft(L^(+-2) rfft(m)).

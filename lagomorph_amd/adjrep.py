@@ -44,8 +44,30 @@ def Ad(phi, v):
     raise NotImplementedError
 
 
+class AdStarSmallFunction(torch.autograd.Function):
+    """ad^*(v, m) as ONE stencil kernel (csrc/diff.hip), bit-identical to the three-call sequence of
+    adjrep.py:69-83; the backward is the difference of the two reference backward kernels."""
+
+    @staticmethod
+    def forward(ctx, v, m):
+        ctx.save_for_backward(v, m)
+        return lagomorph_ext.ad_star(v.contiguous(), m.contiguous())
+
+    @staticmethod
+    def backward(ctx, gradout):
+        v, m = ctx.saved_tensors
+        v, m, gradout = v.contiguous(), m.contiguous(), gradout.contiguous()
+        need_v, need_m = ctx.needs_input_grad
+        dA_v, dA_m = lagomorph_ext.jacobian_times_vectorfield_backward(gradout, v, m, False, True, need_v, need_m)
+        dB_m, dB_v = lagomorph_ext.jacobian_times_vectorfield_adjoint_backward(gradout, m, v, need_m, need_v)
+        return dA_v.sub_(dB_v) if need_v else None, dA_m.sub_(dB_m) if need_m else None
+
+
 def ad_star(v, m):
     r"""ad^*(v, m) = (Dv)^T m + Dm v + m div v, as the numerical adjoint of ad(v, .)  (adjrep.py:69-83)"""
+    if (USE_FUSED_AD_STAR and hasattr(lagomorph_ext, "ad_star") and v.shape == m.shape
+            and m.size(1) == m.dim() - 2 and v.dtype == m.dtype):
+        return AdStarSmallFunction.apply(v, m)
     return jacobian_times_vectorfield(v, m, displacement=False, transpose=True) - jacobian_times_vectorfield_adjoint(
         m, v
     )

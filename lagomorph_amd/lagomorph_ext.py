@@ -52,6 +52,7 @@ _SIGS = {
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_Ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
+    "lago_ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_fluid_metric": [_vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64, _i64,
                           _i64, _vp],
 }
@@ -427,6 +428,22 @@ def Ad_star(phiinv, m):
         raise RuntimeError("Ad_star: phiinv and m must be vector fields of the same shape")
     out = torch.empty_like(m)
     _call("lago_Ad_star", m, _ptr(out), _ptr(phiinv), _ptr(m), dim, m.size(0), nx, ny, nz)
+    return out
+
+
+def ad_star(v, m):
+    """Fused adjrep.ad_star (adjrep.py:69-83): jacobian_times_vectorfield(v, m, transpose=True) minus
+    jacobian_times_vectorfield_adjoint(m, v) in one kernel.  Not part of the reference's extension surface."""
+    _check_input(v, "v")
+    _check_input(m, "m")
+    _same(v, m)
+    dim, nx, ny, nz = _spatial(v)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional jacobian times vectorfield is supported")
+    if v.shape != m.shape or m.size(1) != dim:
+        raise RuntimeError("ad_star: v and m must be vector fields of the same shape")
+    out = torch.empty_like(m)
+    _call("lago_ad_star", m, _ptr(out), _ptr(v), _ptr(m), dim, m.size(0), nx, ny, nz)
     return out
 
 

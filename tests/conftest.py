@@ -58,5 +58,6 @@ def oracle_ext(monkeypatch):
     ):
         monkeypatch.setattr(mod, name, getattr(ext, name))
     monkeypatch.delattr(mod, "fluid_metric")  # the host mirror then takes its rfft / fluid_operator / irfft form
-    monkeypatch.delattr(mod, "Ad_star")       # ... and Ad_star its interp + jacobian_times_vectorfield form
+    monkeypatch.delattr(mod, "Ad_star")
+    monkeypatch.delattr(mod, "ad_star")       # ... and Ad_star its interp + jacobian_times_vectorfield form
     return ext

@@ -24,6 +24,7 @@ def _patch_oracle():
         setattr(lm.lagomorph_ext, name, getattr(o, name))
     delattr(lm.lagomorph_ext, "fluid_metric")
     delattr(lm.lagomorph_ext, "Ad_star")
+    delattr(lm.lagomorph_ext, "ad_star")
     return lm
 
 

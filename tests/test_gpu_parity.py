@@ -568,3 +568,34 @@ def test_lds_staged_gathers_bit_exact(ext, dtype, sp, kind):
     finally:
         ext.set_gather_mode(0)
         ext.set_gather_tile(8, 8, 64, 1, 1, 1, 1024)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(5, 6, 7), (2, 2, 2), (4, 3, 64), (9, 5, 70), (7, 9), (2, 2), (3, 130)])
+def test_fused_small_ad_star_bit_exact(ext, dtype, sp):
+    """ad^*(v, m) in one kernel == jtv(v, m, transpose) - jtv_adjoint(m, v), bit for bit (oracle and
+    this library's own three calls); its autograd backward == autograd through the unfused form."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import adjrep
+
+    rng = np.random.default_rng(hash(sp) % 2**31)
+    d = len(sp)
+    v = rnd(rng, (2, d) + sp, dtype)
+    m = rnd(rng, (2, d) + sp, dtype)
+    want = orc.jacobian_times_vectorfield_forward(v, m, False, True) - orc.jacobian_times_vectorfield_adjoint_forward(m, v)
+    vd, md = dev(v), dev(m)
+    got = ext.ad_star(vd, md)
+    assert_bits(got, want, "ad_star")
+    assert torch.equal(got, ext.jacobian_times_vectorfield_forward(vd, md, False, True)
+                       - ext.jacobian_times_vectorfield_adjoint_forward(md, vd))
+    go = dev(rnd(rng, (2, d) + sp, dtype))
+    grads = {}
+    for fused in (True, False):
+        adjrep.USE_FUSED_AD_STAR = fused
+        try:
+            p, q = vd.clone().requires_grad_(True), md.clone().requires_grad_(True)
+            lm.ad_star(p, q).backward(go)
+            grads[fused] = (p.grad, q.grad)
+        finally:
+            adjrep.USE_FUSED_AD_STAR = True
+    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
