@@ -222,9 +222,10 @@ def micro_atlas_step(lm, dev, size, batch=8):
 
 
 def cpu_baseline(size, euler_steps, sample_batch=1):
-    """Times the CPU oracle (test infrastructure, 1 thread) on a bounded sample of the headline
-    workload: `sample_batch` volumes of size^3, one expmap of `euler_steps` steps.  The oracle
-    stands in for lagomorph_ext only inside this function."""
+    """Times the CPU oracle (test infrastructure) on a bounded sample of the headline workload --
+    `sample_batch` volumes of size^3, one expmap of `euler_steps` steps -- on the host's cores (OpenMP,
+    at most 64 threads) and on one thread.  The oracle stands in for lagomorph_ext only inside this
+    function."""
     import numpy as np
 
     import lagomorph_amd as lm
@@ -243,24 +244,41 @@ def cpu_baseline(size, euler_steps, sample_batch=1):
         lma.USE_FUSED_AD_STAR = False  # ... and Ad_star as interp + jacobian_times_vectorfield
         for n in names:
             setattr(lm.lagomorph_ext, n, getattr(o, n))
+        import oracle.lago_oracle as orc
+
         rng = np.random.default_rng(7)
-        m = torch.from_numpy((0.01 * rng.standard_normal((sample_batch, 3, size, size, size))).astype(np.float32))
         met = lm.FluidMetric([0.1, 0.0, 0.01])
-        torch.set_num_threads(1)
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            lm.expmap(met, m, num_steps=euler_steps)
-        dt = time.perf_counter() - t0
+        runs = {}
+        nthreads = max(1, min(os.cpu_count() or 1, 64))
+        prev_threads = torch.get_num_threads()
+        # all host cores (capped at 64 OpenMP threads) on the full sample, one thread on a quarter of it
+        for tag, threads, batch in (("all", nthreads, sample_batch), ("one", 1, max(1, sample_batch // 4))):
+            m = torch.from_numpy((0.01 * rng.standard_normal((batch, 3, size, size, size))).astype(np.float32))
+            orc.set_threads(threads)
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                lm.expmap(met, m, num_steps=euler_steps)
+            dt = time.perf_counter() - t0
+            runs[tag] = (batch * size ** 3 * euler_steps / dt, dt, batch, threads)
     finally:
+        try:
+            orc.set_threads(1)
+            torch.set_num_threads(prev_threads)
+        except Exception:
+            pass
         lmm.USE_FUSED_FLUID = fused_flag
         lma.USE_FUSED_AD_STAR = fused_ad
         for n, f in saved.items():
             setattr(lm.lagomorph_ext, n, f)
-    vox = sample_batch * size ** 3 * euler_steps
+    v_all, dt_all, b_all, th_all = runs["all"]
+    v_one, dt_one, b_one, _ = runs["one"]
     return {
-        "value": vox / dt, "unit": "voxels/s", "cores": 1, "kind": "port",
-        "sample": f"expmap {euler_steps} Euler steps, batch {sample_batch} x 3x{size}^3 fp32, oracle C port "
-                  f"(1 thread; FFTs by torch CPU/pocketfft), {dt:.1f} s",
+        "value": v_all, "unit": "voxels/s", "cores": th_all, "kind": "port",
+        "sample": f"expmap {euler_steps} Euler steps, batch {b_all} x 3x{size}^3 fp32, oracle C port with OpenMP over "
+                  f"the voxel loops ({th_all} threads; FFTs by torch CPU/pocketfft), {dt_all:.1f} s",
+        "one_thread": {"value": v_one, "cores": 1,
+                       "sample": f"same, batch {b_one}, 1 thread, {dt_one:.1f} s"},
         "host_cpus": os.cpu_count(),
     }
 

@@ -35,6 +35,12 @@ def set_strict(flag):
     _strict = bool(flag)
 
 
+def set_threads(n):
+    """OpenMP threads for the forward kernels expmap uses (interp, jacobian-times-vectorfield, fluid
+    operator); every voxel is independent there, so results do not depend on it.  Default 1."""
+    lib().oracle_set_threads(int(n))
+
+
 def lib():
     if _strict not in _libs:
         path = _LIB_PATHS[_strict]

@@ -193,6 +193,7 @@ int FN(oracle_interp_forward)(REAL *out, const REAL *I, const REAL *u, double dt
         for (long c = 0; c < nc; ++c) {
             const REAL *Ic = In + (size_t)c * nvox;
             REAL *oc = on + (size_t)c * nvox;
+            LG_PARALLEL_FOR
             for (long i = 0; i < nx; ++i)
                 for (long j = 0; j < ny; ++j) {
                     if (dim == 2) {
@@ -333,14 +334,15 @@ int FN(oracle_jtv_forward)(REAL *out, const REAL *v, const REAL *w, int displace
     if (dim == 2) nz = 1;
     if ((displacement || transpose) && nc != dim) return -1;
     const size_t nvox = (size_t)nx * ny * nz;
-    REAL g[3];
     for (long n = 0; n < nn; ++n) {
         const REAL *vn = v + (size_t)n * nc * nvox;
         const REAL *wn = w + (size_t)n * dim * nvox;
         REAL *on = out + (size_t)n * nc * nvox;
+        LG_PARALLEL_FOR
         for (long i = 0; i < nx; ++i)
             for (long j = 0; j < ny; ++j)
                 for (long k = 0; k < nz; ++k) {
+                    REAL g[3];
                     size_t ix = ((size_t)i * ny + j) * nz + k;
                     if (transpose) {
                         /* out[d] = sum_c (d_d v_c + delta) w_c, accumulated c = 0,1,2 */
@@ -562,6 +564,7 @@ int FN(oracle_fluid_operator)(REAL *Fm, int inverse, const REAL *cosX, const REA
         return 0;
     }
     const size_t nxyz = 2 * (size_t)nx * ny * nz;
+    LG_PARALLEL_FOR
     for (long i = 0; i < nx; ++i)
         for (long j = 0; j < ny; ++j)
             for (long k = 0; k < nz; ++k) {
