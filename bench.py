@@ -293,7 +293,8 @@ def main():
     ap.add_argument("--euler-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-sample-batch", type=int, default=16,
+                    help="volumes in the all-cores CPU baseline sample (the one-thread sample is a quarter of it)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

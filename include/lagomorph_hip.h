@@ -59,7 +59,7 @@ int lago_get_splat_mode(void);
  * tile), window margins MX MY MZ, threads per workgroup (256 / 512 / 1024).
  * Default 0 8 0 1 1 4 512.  Affects speed only, never results. */
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
-/* 1 (default): use the 4x-unrolled 3D gather kernels when the shape allows; 0: one-voxel-per-lane kernels only. */
+/* 1 (default): use the slab-unrolled 3D gather kernels (two voxels per lane) when the shape allows; 0: one-voxel-per-lane kernels only. */
 void lago_set_vector_kernels(int on);
 /* 0 (default): direct gathers from global memory; 1: 3D interp_forward / compose / ad_star stage the
  * sampled image in LDS tile by tile (float32, volumes of at least one 8 x 8 x 64 tile) -- slower than

@@ -144,7 +144,7 @@ def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
 
 
 def set_vector_kernels(on):
-    """1 (default): 16-byte vectorised 3D kernels where shapes allow; 0: scalar kernels only."""
+    """1 (default): slab-unrolled 3D gather kernels (two voxels per lane) where shapes allow; 0: one-voxel-per-lane kernels only."""
     _lib.lago_set_vector_kernels(1 if on else 0)
 
 

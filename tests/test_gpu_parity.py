@@ -368,7 +368,7 @@ def test_fused_fluid_metric_matches_three_call_form(ext, dtype, sp, inverse):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
-    """The 16-byte vectorised 3D kernels are a launch-shape choice only."""
+    """The slab-unrolled 3D kernels are a launch-shape choice only."""
     rng = np.random.default_rng(77)
     sp = (6, 7, 32)
     I = rnd(rng, (2, 3) + sp, dtype)
