@@ -169,7 +169,10 @@ int lago_ad_star_f64(double *out, const double *v, const double *m, int dim, int
  * (/root/reference/lagomorph/metric.py:11-19) in one call: out = irfft(L^(+-2) rfft(m)).
  * m, out: (nn, dim, nx, ny[, nz]) real; work: caller-provided scratch for the half spectrum,
  * nn*dim*nx*ny*(nz/2+1)*2 reals for dim == 3 (nn*dim*nx*(ny/2+1)*2 for dim == 2), clobbered.
- * m is not modified; out may not alias m.  LUTs as for lago_fluid_operator.  rocFFT (via hipFFT)
+ * m is not modified; out may not alias m.  LUTs as for lago_fluid_operator; the float32 3D fast paths
+ * tabulate the per-frequency coefficients once per (shape, alpha/beta/gamma, direction, LUT pointers) in a
+ * library-owned device buffer (24 bytes per frequency bin, at most 16 tables kept), so the contents
+ * behind a given set of LUT pointers must not change between calls.  rocFFT (via hipFFT)
  * does the transforms; plans are cached inside the library per shape. */
 int lago_fluid_metric_f32(float *out, const float *m, float *work, int inverse, const float *cosX,
                           const float *sinX, const float *cosY, const float *sinY, const float *cosZ,
