@@ -51,12 +51,20 @@ __global__ __launch_bounds__(256) void fluid_xpass2_kernel(fl::XArgs a) {
     using K = fl::XPass<LOGNX, INV, 256>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *buf = reinterpret_cast<float2 *>(lago_smem), *tw = buf + 3 * K::NX * K::KCP;
-    const typename K::Block b = K::locate(a, xcd_swizzle(blockIdx.x, a.total));
+    const uint32_t blk = xcd_swizzle(blockIdx.x, a.total);
+    typename K::Block b = K::locate(a, blk);
     typename K::Regs r;
+    // consecutive batch items under the same coefficients (held in registers): the 24-byte table
+    // entry of a bin is then read once per `ipw` items instead of once per item
+    const uint32_t n0 = blk / (uint32_t)a.items_per_n * (uint32_t)a.ipw;
+    const int nit = min(a.ipw, a.nn - (int)n0);
+    for (int it = 0; it < nit; ++it) {
 #pragma unroll
-    for (int ph = 0; ph < K::NPH; ++ph) {
-        K::phase(ph, threadIdx.x, r, b, buf, tw, a.scale);
-        if (ph + 1 < K::NPH) __syncthreads();
+        for (int ph = 0; ph < K::NPH; ++ph) {
+            K::phase(ph, threadIdx.x, r, b, buf, tw, a.scale, it == 0);
+            if (ph + 1 < K::NPH || it + 1 < nit) __syncthreads();
+        }
+        b.base += (size_t)3 * K::NX * b.xs;  // next batch item, same bins
     }
 }
 
@@ -136,6 +144,7 @@ static hipError_t xpass2_launch(const fl::XArgs &a, bool inverse, hipStream_t s)
     return hipSuccess;
 }
 
+int g_xpass_ipw = 2;  // batch items per x-pass workgroup
 int g_native_stage_mask = 7;  // profiling only: bit 0 zy forward, bit 1 x pass, bit 2 zy inverse
 
 // out = irfftn(operator(rfftn(m))) * scale.  tab: split-layout coefficient table (fluid_coef_launch
@@ -162,7 +171,9 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     xa.nch = (int)(nzh / 16);
     xa.items_per_n = (int)items;
     xa.scale = (float)scale;
-    xa.total = (uint32_t)(nn * items);
+    xa.nn = (int)nn;
+    xa.ipw = g_xpass_ipw > 0 ? g_xpass_ipw : 1;
+    xa.total = (uint32_t)((nn + xa.ipw - 1) / xa.ipw * items);
     hipError_t e = hipSuccess;
     if (g_native_stage_mask & 1) e = zy_dispatch(ly, lz, za, false, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy forward)");
@@ -180,3 +191,4 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
 }  // namespace lago
 
 extern "C" void lago_debug_fluid_stage_mask(int m) { lago::g_native_stage_mask = m; }
+extern "C" void lago_debug_xpass_ipw(int n) { lago::g_xpass_ipw = n; }

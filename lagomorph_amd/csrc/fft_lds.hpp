@@ -173,8 +173,9 @@ struct XArgs {
     float2 *main_, *nyq;        // split spectrum (see the header comment)
     const float *tabM, *tabN;   // coefficients [kx][ky][kz < nzh][6] and [kx][ky][6]
     int ny, nzh, nch, items_per_n;
+    int nn, ipw;                // batch size; batch items one workgroup runs through with the same coefficients
     float scale;
-    uint32_t total;
+    uint32_t total;             // ceil(nn / ipw) * items_per_n workgroups
 };
 
 template <int LOGNX, bool INV, int NT = 256>
@@ -197,7 +198,7 @@ struct XPass {
     struct Regs { float coef[NOP][6]; };
 
     LAGO_HD static Block locate(const XArgs &a, uint32_t blk) {
-        const uint32_t n = blk / (uint32_t)a.items_per_n, item = blk % (uint32_t)a.items_per_n;
+        const uint32_t n = blk / (uint32_t)a.items_per_n * (uint32_t)a.ipw, item = blk % (uint32_t)a.items_per_n;
         const uint32_t nmain = (uint32_t)a.ny * a.nch;
         Block b;
         if (item < nmain) {
@@ -216,9 +217,12 @@ struct XPass {
         return b;
     }
 
-    LAGO_HD static void phase(int ph, int tid, Regs &r, const Block &b, float2 *buf, float2 *tw, float scale) {
+    // `first`: the workgroup's first batch item -- twiddles and coefficients are loaded then and kept
+    LAGO_HD static void phase(int ph, int tid, Regs &r, const Block &b, float2 *buf, float2 *tw, float scale,
+                              bool first = true) {
         if (ph == 0) {
-            for (int t = tid; t < NX / 2; t += NT) tw[t] = twiddle(t, NX);
+            if (first)
+                for (int t = tid; t < NX / 2; t += NT) tw[t] = twiddle(t, NX);
             const int rg = tid >> 3, l8 = tid & 7;
             float4 v[KLD];
 #pragma unroll
@@ -228,6 +232,7 @@ struct XPass {
             const int kc = tid & (KL - 1), row0 = tid / KL;
 #pragma unroll
             for (int i = 0; i < NOP; ++i) {
+                if (!first) break;
                 const float *t = b.tb + (size_t)brev(row0 + i * RG, LOGNX) * b.tks + kc * 6;
 #pragma unroll
                 for (int e = 0; e < 3; ++e) {

@@ -107,7 +107,7 @@ static int run_case() {
     XArgs xa;
     xa.main_ = mainb; xa.nyq = nyqb; xa.tabM = tabM; xa.tabN = tabN;
     xa.ny = NY; xa.nzh = NZH; xa.nch = NZH / 16; xa.items_per_n = NY * xa.nch + NY / 16;
-    xa.scale = scale; xa.total = (uint32_t)(NN * xa.items_per_n);
+    xa.nn = NN; xa.ipw = 1; xa.scale = scale; xa.total = (uint32_t)(NN * xa.items_per_n);
     std::vector<typename Xp::Regs> regs(256);
     for (uint32_t blk = 0; blk < xa.total; ++blk) {
         const auto b = Xp::locate(xa, blk);
