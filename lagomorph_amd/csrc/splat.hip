@@ -96,7 +96,12 @@ __device__ __forceinline__ void analytic_pos(R &hx, R &hy, R &hz, int i, int j, 
     }
 }
 
-template <typename R, int MODE, bool BC, bool NEED_U, int NT, int VPL>
+// MC ("multi-channel"): displacement mode with d_u wanted and more than one channel, tile covered by
+// ONE pass of the workgroup -- positions are computed once, d_u is accumulated in registers over the
+// channels and written once (the channel-by-channel form re-reads u and read-modify-writes d_u per
+// channel: 132 instead of 60 bytes per voxel at C = 3).  The per-channel expressions and their order
+// are unchanged, so the result is bit-identical.
+template <typename R, int MODE, bool BC, bool NEED_U, int NT, int VPL, bool MC = false>
 __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R *__restrict__ d_u,
                                                          const R *__restrict__ go, const R *__restrict__ I,
                                                          PosArgs pa, int nc, TileGeom tg) {
@@ -161,6 +166,124 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const int ispx = wex - 1, ispy = wey - 1, ispz = wez - 1;
     const int wbase = -((wx0 * WY + wy0) * WZ + wz0);
 
+    // one voxel's contribution to the window / d_I (include/interp.h:431-453: floor corner,
+    // sequentially flipped weights) -- shared by both loop structures below
+    auto splat_voxel = [&](R hx, R hy, R hz, R diff, R *dIc) {
+        const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+        const R dx = (R)1.f - (hx - (R)fx);
+        const R dy = (R)1.f - (hy - (R)fy);
+        const R dz = (R)1.f - (hz - (R)fz);
+        R wgt[8];
+        {
+            R ddx = dx, ddy = dy, ddz = dz;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                wgt[q] = (ddx * ddy * ddz) * diff;
+                ddz = (R)1.f - ddz;
+                if (q & 1) ddy = (R)1.f - ddy;
+                if ((q & 3) == 3) ddx = (R)1.f - ddx;
+            }
+        }
+        const bool interior = (unsigned)(fx - ilox) < (unsigned)ispx && (unsigned)(fy - iloy) < (unsigned)ispy &&
+                              (unsigned)(fz - iloz) < (unsigned)ispz;
+        if (interior) {
+            double *w0 = win + ((fx * WY + fy) * WZ + fz + wbase);
+            double *w1 = w0 + WZ, *w2 = w0 + WY * WZ, *w3 = w2 + WZ;
+            lds_add(w0, (double)wgt[0]);
+            lds_add(w0 + 1, (double)wgt[1]);
+            lds_add(w1, (double)wgt[2]);
+            lds_add(w1 + 1, (double)wgt[3]);
+            lds_add(w2, (double)wgt[4]);
+            lds_add(w2 + 1, (double)wgt[5]);
+            lds_add(w3, (double)wgt[6]);
+            lds_add(w3 + 1, (double)wgt[7]);
+        } else {
+            const int gi[2] = {clamp1(fx, nx), clamp1(fx + 1, nx)};
+            const int gj[2] = {clamp1(fy, ny), clamp1(fy + 1, ny)};
+            const int gk[2] = {clamp1(fz, nz), clamp1(fz + 1, nz)};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cx = gi[q >> 2], cy = gj[(q >> 1) & 1], cz = gk[q & 1];
+                const int lx = cx - wx0, ly = cy - wy0, lz = cz - wz0;
+                const bool inside = (unsigned)lx < (unsigned)wex && (unsigned)ly < (unsigned)wey &&
+                                    (unsigned)lz < (unsigned)wez;
+                if (inside) lds_add(&win[(lx * WY + ly) * WZ + lz], (double)wgt[q]);
+                else atomic_add(dIc + ((size_t)cx * ny + cy) * nz + cz, wgt[q]);
+            }
+        }
+    };
+    // flush touched cells: one wave per window row (lx, ly) -- the row decode and both base
+    // addresses are wave-uniform (scalar), the lanes run along z
+    auto flush = [&](R *dIc) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const uint32_t nrows = (uint32_t)(wex * wey);
+        for (uint32_t row = wv; row < nrows; row += NT / 64) {
+            const uint32_t lx = tg.d_wey.div(row), ly = row - lx * (uint32_t)wey;
+            const double *wrow = win + (lx * (uint32_t)WY + ly) * (uint32_t)WZ;
+            R *grow = dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + wz0;
+            for (int lz = lane; lz < wez; lz += 64) {
+                const double acc = wrow[lz];
+                if (acc != 0.0) atomic_add(grow + lz, (R)acc);
+            }
+        }
+    };
+
+    if constexpr (MC) {
+        uint32_t sv[VPL];
+        bool live[VPL];
+        R hx[VPL], hy[VPL], hz[VPL], dux[VPL], duy[VPL], duz[VPL];
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) {
+            const uint32_t t = threadIdx.x + e * NT;
+            const uint32_t a = tg.d_TyTzq.div(t);
+            const uint32_t rr = t - a * (uint32_t)(tg.TY * tg.TZ);
+            const uint32_t b = tg.d_Tzq.div(rr);
+            const uint32_t cc = rr - b * (uint32_t)tg.TZ;
+            live[e] = t < tg.tile_groups && (int)a < ex && (int)b < ey && (int)cc < ez;
+            const int vi = x0 + a, vj = y0 + b, vk = z0 + cc;
+            sv[e] = live[e] ? ((uint32_t)vi * sny + vj) * snz + vk : 0;
+            hx[e] = sample_pos_t<R, MODE == POS_DISP_UNIT>(vi, dt, un[sv[e]]);
+            hy[e] = sample_pos_t<R, MODE == POS_DISP_UNIT>(vj, dt, un[sv[e] + nv]);
+            hz[e] = sample_pos_t<R, MODE == POS_DISP_UNIT>(vk, dt, un[sv[e] + 2 * nv]);
+            dux[e] = duy[e] = duz[e] = (R)0;
+        }
+        for (int c = 0; c < nc; ++c) {
+            for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0.0;
+            __syncthreads();
+            const R *Ic = In + (size_t)c * nv;
+            R *dIc = dIn + (size_t)c * nv;
+            const R *gc = gon + (size_t)c * snv;
+            R gv[VPL];
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) gv[e] = gc[sv[e]];
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) {
+                if (!live[e]) continue;
+                splat_voxel(hx[e], hy[e], hz[e], gv[e], dIc);
+                Lerp3<R, false> Lq;  // nz >= 2 guaranteed by the host
+                Lq.setup(hx[e], hy[e], hz[e], nx, ny, nz);
+                R gx, gy, gz;
+                Lq.grad(Ic, gx, gy, gz);
+                const R diff = (R)((double)gv[e] * dt);  // cuda/interp.cu:230
+                dux[e] = lg_fma(gx, diff, dux[e]);
+                duy[e] = lg_fma(gy, diff, duy[e]);
+                duz[e] = lg_fma(gz, diff, duz[e]);
+            }
+            __syncthreads();
+            flush(dIc);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < VPL; ++e)
+            if (live[e]) {
+                dun[sv[e]] = dux[e];
+                dun[sv[e] + nv] = duy[e];
+                dun[sv[e] + 2 * nv] = duz[e];
+            }
+        return;
+    }
+
     for (int c = 0; c < nc; ++c) {
         for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0.0;
         __syncthreads();
@@ -209,53 +332,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                     analytic_pos<R, MODE>(hx, hy, hz, vi[e], vj[e], vk[e], An, Tn, pa, tg);
                 }
                 R diff = gv[e];
-                // include/interp.h:431-453: floor corner, sequentially flipped weights
-                const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
-                R dx = (R)1.f - (hx - (R)fx);
-                R dy = (R)1.f - (hy - (R)fy);
-                R dz = (R)1.f - (hz - (R)fz);
-                // weights in the reference's order: dz flips after every corner, dy after every
-                // second, dx after the fourth (1 - (1 - d) is not always d, so the chain is kept)
-                R wgt[8];
-                {
-                    R ddx = dx, ddy = dy, ddz = dz;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        wgt[q] = (ddx * ddy * ddz) * diff;
-                        ddz = (R)1.f - ddz;
-                        if (q & 1) ddy = (R)1.f - ddy;
-                        if ((q & 3) == 3) ddx = (R)1.f - ddx;
-                    }
-                }
-                // fast path: the 2x2x2 footprint is unclamped and inside the window -> one address,
-                // eight LDS adds at fixed offsets
-                const bool interior = (unsigned)(fx - ilox) < (unsigned)ispx && (unsigned)(fy - iloy) < (unsigned)ispy &&
-                                      (unsigned)(fz - iloz) < (unsigned)ispz;
-                if (interior) {
-                    double *w0 = win + ((fx * WY + fy) * WZ + fz + wbase);
-                    double *w1 = w0 + WZ, *w2 = w0 + WY * WZ, *w3 = w2 + WZ;
-                    lds_add(w0, (double)wgt[0]);
-                    lds_add(w0 + 1, (double)wgt[1]);
-                    lds_add(w1, (double)wgt[2]);
-                    lds_add(w1 + 1, (double)wgt[3]);
-                    lds_add(w2, (double)wgt[4]);
-                    lds_add(w2 + 1, (double)wgt[5]);
-                    lds_add(w3, (double)wgt[6]);
-                    lds_add(w3 + 1, (double)wgt[7]);
-                } else {
-                    const int gi[2] = {clamp1(fx, nx), clamp1(fx + 1, nx)};
-                    const int gj[2] = {clamp1(fy, ny), clamp1(fy + 1, ny)};
-                    const int gk[2] = {clamp1(fz, nz), clamp1(fz + 1, nz)};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int cx = gi[q >> 2], cy = gj[(q >> 1) & 1], cz = gk[q & 1];
-                        const int lx = cx - wx0, ly = cy - wy0, lz = cz - wz0;
-                        const bool inside = (unsigned)lx < (unsigned)wex && (unsigned)ly < (unsigned)wey &&
-                                            (unsigned)lz < (unsigned)wez;
-                        if (inside) lds_add(&win[(lx * WY + ly) * WZ + lz], (double)wgt[q]);
-                        else atomic_add(dIc + ((size_t)cx * ny + cy) * nz + cz, wgt[q]);
-                    }
-                }
+                splat_voxel(hx, hy, hz, diff, dIc);
                 if (NEED_U) {
                     Lerp3<R, false> Lq;  // nz >= 2 guaranteed by the host: lets the compiler batch the gathers
                     Lq.setup(hx, hy, hz, nx, ny, nz);
@@ -269,22 +346,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
             }
         }
         __syncthreads();
-        // flush touched cells: one wave per window row (lx, ly) -- the row decode and both base
-        // addresses are wave-uniform (scalar), the lanes run along z
-        {
-            const int lane = threadIdx.x & 63;
-            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            const uint32_t nrows = (uint32_t)(wex * wey);
-            for (uint32_t row = wv; row < nrows; row += NT / 64) {
-                const uint32_t lx = tg.d_wey.div(row), ly = row - lx * (uint32_t)wey;
-                const double *wrow = win + (lx * (uint32_t)WY + ly) * (uint32_t)WZ;
-                R *grow = dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + wz0;
-                for (int lz = lane; lz < wez; lz += 64) {
-                    const double acc = wrow[lz];
-                    if (acc != 0.0) atomic_add(grow + lz, (R)acc);
-                }
-            }
-        }
+        flush(dIc);
         __syncthreads();
     }
 }
@@ -360,10 +422,12 @@ static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, 
     return true;
 }
 
-template <typename R, int MODE, bool BC, bool NEED_U, int NT, int VPL>
+int g_splat_mc = 1;  // 1: multi-channel single-pass form of interp_backward where it applies
+
+template <typename R, int MODE, bool BC, bool NEED_U, int NT, int VPL, bool MC = false>
 static hipError_t launch_tiled(R *d_I, R *d_u, const R *go, const R *I, const PosArgs &pa, int nc,
                                const TileGeom &tg, size_t smem, hipStream_t s) {
-    auto k = splat_tiled_kernel<R, MODE, BC, NEED_U, NT, VPL>;
+    auto k = splat_tiled_kernel<R, MODE, BC, NEED_U, NT, VPL, MC>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -398,6 +462,23 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     pa.dt = dt;
     hipError_t e;
     const bool unit = unit_dt<R>(dt);
+    // several channels with d_u wanted: the single-pass multi-channel form when one workgroup pass
+    // covers the tile (1024 threads x 4 voxels for the default 4096-voxel tile)
+    if (g_splat_mc && vec && need_u && nc > 1 && tg.tile_groups <= 1024u * V) {
+        const int ntm = tg.tile_groups <= 256u * V ? 256 : (tg.tile_groups <= 512u * V ? 512 : 1024);
+#define GOMC(M, B)                                                                                                 \
+    e = ntm == 1024  ? launch_tiled<R, M, B, true, 1024, V, true>(d_I, d_u, go, I, pa, nc, tg, smem, s)           \
+        : ntm == 512 ? launch_tiled<R, M, B, true, 512, V, true>(d_I, d_u, go, I, pa, nc, tg, smem, s)            \
+                     : launch_tiled<R, M, B, true, 256, V, true>(d_I, d_u, go, I, pa, nc, tg, smem, s)
+        if (unit) {
+            if (bc) GOMC(POS_DISP_UNIT, true); else GOMC(POS_DISP_UNIT, false);
+        } else {
+            if (bc) GOMC(POS_DISP, true); else GOMC(POS_DISP, false);
+        }
+#undef GOMC
+        if (e != hipSuccess) return fail_hip(e, "interp_backward (tiled splat)");
+        return finish_launch(s, "interp_backward (tiled splat)");
+    }
 #define GO(B, U) \
     e = !vec   ? by_threads<R, POS_DISP, B, U, 1>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s)          \
         : unit ? by_threads<R, POS_DISP_UNIT, B, U, V>(d_I, d_u, go, I, pa, nc, tg, smem, nt, s)     \
@@ -472,6 +553,7 @@ template int regrid_splat_lds<double>(double *, const double *, int64_t, const G
 extern "C" {
 // Tuning hook (bench / tests): tile TX, TY, TZ (0 = auto), window margins, threads per workgroup.
 // Affects speed only, never results.
+void lago_debug_splat_mc(int on) { lago::g_splat_mc = on; }
 void lago_set_splat_tile(int tx, int ty, int tz, int ex, int ey, int ez, int nthreads) {
     lago::g_tile_cfg[0] = tx; lago::g_tile_cfg[1] = ty; lago::g_tile_cfg[2] = tz;
     lago::g_tile_cfg[3] = ex; lago::g_tile_cfg[4] = ey; lago::g_tile_cfg[5] = ez;
