@@ -139,3 +139,35 @@ def test_oracle_builds_agree():
         orc.set_strict(False)
     assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
     assert not np.array_equal(a, b)  # they really are two different evaluations
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/lagomorph_hip.h is the drop-in boundary: it must compile as strict C99 (no C++, no torch
+    types) and a C program must link against the shared library and read its housekeeping symbols
+    (no GPU needed for those)."""
+    import shutil
+    import subprocess
+
+    import lagomorph_amd.lagomorph_ext as ext
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "lagomorph_hip.h"\n'
+        "int main(void) {\n"
+        "    if (lago_abi_version() != LAGO_ABI_VERSION) return 1;\n"
+        "    if (!lago_version() || !strlen(lago_version())) return 2;\n"
+        "    lago_set_debug(1); if (lago_get_debug() != 1) return 3; lago_set_debug(0);\n"
+        "    /* argument validation happens before any HIP call */\n"
+        "    if (lago_interp_forward_f32(0, 0, 0, 1.0, 5, 1, 1, 4, 4, 4, 0, 0) != LAGO_ERR_INVALID) return 4;\n"
+        '    printf("%s\\n", lago_last_error());\n'
+        "    return 0;\n}\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(ext.LIB_PATH)
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", f"-I{inc}", str(src), "-o", str(exe),
+                    f"-L{libdir}", "-llagomorph_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "two- and three-dimensional" in r.stdout
