@@ -95,3 +95,53 @@ def test_two_rank_atlas_equals_sequential_emulation(tmp_path, oracle_ext, sp):
     assert np.allclose(r["loss"], losses, rtol=1e-10)
     assert np.allclose(r["m0"], ms[0].numpy(), rtol=1e-10, atol=1e-12)  # rank 0 owns the first minibatch
     assert not np.allclose(r["I"], data.mean(0, keepdim=True).numpy())  # the atlas actually moved
+
+
+def _run_affine(rank, world, port, sp, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import lagomorph_amd as lm
+        from oracle.lago_oracle import OracleExt
+
+        o = OracleExt()
+        for name in ("affine_interp_forward", "affine_interp_backward"):
+            setattr(lm.lagomorph_ext, name, getattr(o, name))
+        data = _dataset(8, sp)
+        per = data.shape[0] // world
+        shard = data[rank * per:(rank + 1) * per].contiguous()
+        d = len(sp)
+        As = torch.zeros((per, d, d), dtype=torch.float64)
+        Ts = torch.zeros((per, d), dtype=torch.float64)
+        I, As, Ts, ep, _ = lm.affine_atlas(shard, As, Ts, num_epochs=3, batch_size=2, learning_rate_A=1e-3,
+                                           learning_rate_T=2e-2, learning_rate_I=0.5, world_size=world, rank=rank,
+                                           dataset_size=data.shape[0])
+        np.savez(out + f".{rank}.npz", I=I.numpy(), A=As.numpy(), T=Ts.numpy(), ep=np.array(ep))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sp", [(9, 8), (6, 5, 7)])
+def test_two_rank_affine_atlas_equals_one_process(tmp_path, oracle_ext, sp):
+    """affine_atlas sharded over 2 ranks (mean-image all-reduce, one SUM all-reduce of the atlas gradient
+    per epoch divided by image_iters * world_size, epoch-loss all-reduce; affine.py:328-333, 389-409)
+    equals one process over all subjects: with the image updated once per epoch the per-subject
+    (A, T) steps only depend on that epoch's atlas, and both runs average the same minibatch
+    gradients."""
+    import lagomorph_amd as lm
+
+    out = str(tmp_path / "aff")
+    mp.spawn(_run_affine, args=(2, _free_port(), sp, out), nprocs=2, join=True)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["I"], r1["I"])  # every rank ends with the same atlas
+    data = _dataset(8, sp)
+    d = len(sp)
+    As = torch.zeros((8, d, d), dtype=torch.float64)
+    Ts = torch.zeros((8, d), dtype=torch.float64)
+    I, As, Ts, ep, _ = lm.affine_atlas(data, As, Ts, num_epochs=3, batch_size=2, learning_rate_A=1e-3,
+                                       learning_rate_T=2e-2, learning_rate_I=0.5)
+    assert np.allclose(r0["I"], I.numpy(), rtol=0, atol=1e-12)
+    assert np.allclose(np.concatenate([r0["A"], r1["A"]]), As.numpy(), rtol=0, atol=1e-12)
+    assert np.allclose(np.concatenate([r0["T"], r1["T"]]), Ts.numpy(), rtol=0, atol=1e-12)
+    assert np.allclose(r0["ep"], np.array(ep), rtol=1e-12)
