@@ -106,6 +106,9 @@ static int get_coef(float *&tab, int inverse, const float *cosX, const float *si
     LAGO_HIP_TRY(hipMalloc((void **)&t.d, (size_t)nx * ny * nzc * 6 * sizeof(float)));
     int rc = fluid_coef_launch(t.d, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, split, s);
     if (rc != LAGO_OK) return rc;
+    // one-time: the table is shared by later calls on ANY stream, so it must be complete before it is
+    // published (steady-state calls never synchronise)
+    LAGO_HIP_TRY(hipStreamSynchronize(s));
     if (g_tabs.size() >= 16) {  // bounded cache
         (void)hipFree(g_tabs.front().d);
         g_tabs.erase(g_tabs.begin());
