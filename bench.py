@@ -417,6 +417,9 @@ def main():
             result["other_ops"] = micro_ops(lm, dev, S)
             torch.cuda.empty_cache()
             result["atlas_step"] = micro_atlas_step(lm, dev, S)
+            if S == 128:  # BASELINE configs[4] volume size (not a power of two: rocFFT-based fluid metric)
+                torch.cuda.empty_cache()
+                result["atlas_step_160"] = micro_atlas_step(lm, dev, 160)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S, E, args.cpu_sample_batch)
         print(json.dumps(result))
