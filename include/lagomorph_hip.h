@@ -55,7 +55,7 @@ const char *lago_last_error(void);
 void lago_set_splat_mode(int mode);
 int lago_get_splat_mode(void);
 /* Tuning hook for the LDS-privatised splat: source tile TX x TY x TZ (TZ = 0:
- * whole z rows, split evenly above 160 voxels; TX = 0: about 4096 voxels per
+ * whole z rows, split evenly above 128 voxels; TX = 0: about 4096 voxels per
  * tile), window margins MX MY MZ, threads per workgroup (256 / 512 / 1024).
  * Default 0 8 0 1 1 4 512.  Affects speed only, never results. */
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);

@@ -360,14 +360,22 @@ static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, 
     const int EX = cfg[3], EY = cfg[4], EZ = cfg[5];
     nthreads = cfg[6] >= 1024 ? 1024 : (cfg[6] >= 512 ? 512 : 256);
     if (TY < 1 || EX < 0 || EY < 0 || EZ < 0) return false;
-    if (TZ <= 0) {  // auto: whole z rows, split evenly when they are longer than 160 voxels
-        const int parts = (gs.nz + 159) / 160;
+    if (TZ <= 0) {  // auto: whole z rows, split evenly when they are longer than 128 voxels (a longer row
+                    // pushes the f64 window of a 4 x 8 tile past 80 KB, i.e. down to one workgroup per CU:
+                    // 647 -> 486 us at 8 x 1 x 160^3)
+        const int parts = (gs.nz + 127) / 128;
         TZ = (((gs.nz + parts - 1) / parts + 15) / 16) * 16;
     }
     if (TX <= 0) {  // auto: about 4096 voxels per tile (measured optimum at 128^3: 4 x 8 x 128, 512 threads)
         const int per = TY * (TZ < gs.nz ? TZ : gs.nz);
         TX = (4096 + per - 1) / per;
         if (TX < 4) TX = 4;
+        // ... but keep the f64 window under 80 KB so that two workgroups fit a CU
+        auto wbytes = [&](int tx) {
+            const int wz = ((TZ + 1 + 2 * EZ + 15 + 15) / 16) * 16;
+            return (size_t)(tx + 1 + 2 * EX) * (TY + 1 + 2 * EY) * (wz < g.nz ? wz : g.nz) * sizeof(double);
+        };
+        while (TX > 4 && wbytes(TX) > 80 * 1024) --TX;
     }
     TX = TX < gs.nx ? TX : gs.nx;
     TY = TY < gs.ny ? TY : gs.ny;

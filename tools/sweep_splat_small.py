@@ -7,15 +7,17 @@ import lagomorph_amd as lm
 from bench import gaussian_blur, time_op
 ext = lm.lagomorph_ext
 dev = torch.device("cuda")
-S, B = 128, 8
+S, B = (int(sys.argv[1]) if len(sys.argv) > 1 else 128), 8
 g = torch.Generator(device=dev).manual_seed(1234)
 u = gaussian_blur(torch.randn((B, 3, S, S, S), device=dev, generator=g), 8.0); u = u * (4.0 / u.abs().max())
 data = {}
 for C in (1, 3):
     I = gaussian_blur(torch.randn((B, C, S, S, S), device=dev, generator=g), 2.0); I = I / I.std()
     data[C] = (I, torch.randn((B, C, S, S, S), device=dev, generator=g))
-for cfg in ((16, 8, 64, 1, 1, 4, 1024), (4, 8, 128, 1, 1, 4, 512), (8, 8, 64, 1, 1, 0, 512), (8, 8, 128, 1, 1, 4, 1024),
-            (8, 4, 128, 1, 1, 4, 512), (8, 8, 32, 1, 1, 0, 512), (4, 4, 128, 1, 1, 4, 256), (8, 4, 64, 1, 1, 0, 256)):
+cfgs = [tuple(int(x) for x in a.split(",")) for a in sys.argv[2:]] or [
+    (16, 8, 64, 1, 1, 4, 1024), (4, 8, 128, 1, 1, 4, 512), (8, 8, 64, 1, 1, 0, 512), (8, 8, 128, 1, 1, 4, 1024),
+    (8, 4, 128, 1, 1, 4, 512), (8, 8, 32, 1, 1, 0, 512), (4, 4, 128, 1, 1, 4, 256), (8, 4, 64, 1, 1, 0, 256)]
+for cfg in cfgs:
     ext.set_splat_tile(*cfg)
     row = []
     for C in (1, 3):
