@@ -248,6 +248,9 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
             hz[e] = sample_pos_t<R, MODE == POS_DISP_UNIT>(vk, dt, un[sv[e] + 2 * nv]);
             dux[e] = duy[e] = duz[e] = (R)0;
         }
+        Lerp3<R, false> Lq[VPL];  // gather geometry: once per voxel, reused by every channel (nz >= 2: host)
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) Lq[e].setup(hx[e], hy[e], hz[e], nx, ny, nz);
         for (int c = 0; c < nc; ++c) {
             for (uint32_t f = threadIdx.x; f < tg.win_cells; f += NT) win[f] = 0.0;
             __syncthreads();
@@ -261,10 +264,8 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
             for (int e = 0; e < VPL; ++e) {
                 if (!live[e]) continue;
                 splat_voxel(hx[e], hy[e], hz[e], gv[e], dIc);
-                Lerp3<R, false> Lq;  // nz >= 2 guaranteed by the host
-                Lq.setup(hx[e], hy[e], hz[e], nx, ny, nz);
                 R gx, gy, gz;
-                Lq.grad(Ic, gx, gy, gz);
+                Lq[e].grad(Ic, gx, gy, gz);
                 const R diff = (R)((double)gv[e] * dt);  // cuda/interp.cu:230
                 dux[e] = lg_fma(gx, diff, dux[e]);
                 duy[e] = lg_fma(gy, diff, duy[e]);
