@@ -180,3 +180,37 @@ class LDDMMAtlasBuilder:
             self.epoch_losses.append(l)
             self.epoch_reg_terms.append(r)
         return self.I.detach()
+
+    # ---- checkpoint / resume (the reference writes the same fields to HDF5, lddmm.py:238-285) ----
+
+    def state_dict(self):
+        """Atlas, this rank's momenta (one tensor per minibatch, as the reference stores them with a
+        `batch_sizes` attribute) and the loss histories -- what `LDDMMAtlasBuilder.save` of the
+        reference writes (lddmm.py:238-262), as a plain dict of CPU tensors."""
+        return {
+            "atlas": self.I.detach().cpu().clone(),
+            "momenta": [m.detach().cpu().clone() for m in self.ms],
+            "batch_sizes": [int(m.shape[0]) for m in self.ms],
+            "epoch_losses": [float(x) for x in self.epoch_losses],
+            "epoch_reg_terms": [float(x) for x in self.epoch_reg_terms],
+            "rank": self.rank, "world_size": self.world_size,
+        }
+
+    def load_state_dict(self, state):
+        """Resume from `state_dict()` (reference: `load`, lddmm.py:264-285)."""
+        if state["batch_sizes"] != [int(m.shape[0]) for m in self.ms]:
+            raise ValueError("checkpoint was written with a different shard / batch size")
+        with torch.no_grad():
+            self.I.copy_(state["atlas"].to(self.I.device, self.I.dtype))
+            for m, s in zip(self.ms, state["momenta"]):
+                m.detach_().copy_(s.to(m.device, m.dtype))
+        self.epoch_losses = list(state["epoch_losses"])
+        self.epoch_reg_terms = list(state["epoch_reg_terms"])
+        self.image_iters = 0
+        self.image_optimizer.zero_grad()
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location="cpu"))

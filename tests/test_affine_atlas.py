@@ -113,3 +113,24 @@ def test_affine_atlas_hip_matches_oracle_backend(sp, monkeypatch):
     assert epg == pytest.approx(epc, rel=1e-9)
     assert torch.allclose(Ig.cpu(), Ic, rtol=0, atol=1e-10)
     assert torch.allclose(Ag.cpu(), Ac, rtol=0, atol=1e-10) and torch.allclose(Tg.cpu(), Tc, rtol=0, atol=1e-10)
+
+
+def test_lddmm_atlas_builder_checkpoint_resume(oracle_ext, tmp_path):
+    """Two epochs, save, one more epoch == load into a fresh builder, one more epoch (lddmm.py:238-285)."""
+    import lagomorph_amd as lm
+
+    g = torch.Generator().manual_seed(2)
+    sp = (6, 6, 6)
+    data = torch.randn((1, 1) + sp, generator=g, dtype=torch.float64) + 0.3 * torch.randn((4, 1) + sp, generator=g, dtype=torch.float64)
+    kw = dict(batch_size=2, lddmm_integration_steps=2, reg_weight=1e-1, learning_rate_pose=1e-2, learning_rate_image=1e-1)
+    a = lm.LDDMMAtlasBuilder(data, **kw)
+    a.run(num_epochs=2)
+    path = str(tmp_path / "ckpt.pt")
+    a.save(path)
+    Ia = a.run(num_epochs=1).clone()
+    b = lm.LDDMMAtlasBuilder(data, **kw)
+    b.load(path)
+    Ib = b.run(num_epochs=1)
+    assert torch.equal(Ia, Ib)
+    assert all(torch.equal(x, y) for x, y in zip(a.ms, b.ms))
+    assert [float(x) for x in a.epoch_losses] == [float(x) for x in b.epoch_losses]
