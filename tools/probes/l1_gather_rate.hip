@@ -36,6 +36,15 @@ __global__ __launch_bounds__(256) void k(const float *buf, float *out, int iters
             acc += __builtin_bit_cast(float, v.x) + __builtin_bit_cast(float, v.w);
         } else if (SHAPE == 5) {  // dword per lane, every other lane active (fallback-style masked load)
             if (lane & 1) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0));
+        } else if (SHAPE == 7) {  // global_load_dwordx2 (64-bit address per lane) at a 4-byte lane stride
+            typedef unsigned long long ull4 __attribute__((aligned(4)));
+            const ull4 v = *reinterpret_cast<const ull4 *>(reinterpret_cast<const char *>(buf) + o);
+            acc += __builtin_bit_cast(float, (unsigned)v) + __builtin_bit_cast(float, (unsigned)(v >> 32));
+        } else if (SHAPE == 8) {  // global_load_dword, consecutive lanes
+            acc += *reinterpret_cast<const float *>(reinterpret_cast<const char *>(buf) + o);
+        } else if (SHAPE == 9) {  // dwordx2 buffer load, every lane the SAME pair as its neighbour pair-wise (lanes 2k, 2k+1 share)
+            unsigned long long v = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, (o & ~7u) - (lane & 1) * 4 + 0, 0, 0));
+            acc += __builtin_bit_cast(float, (unsigned)v) + __builtin_bit_cast(float, (unsigned)(v >> 32));
         } else if (SHAPE == 6) {  // dword per lane, one lane in four active
             if ((lane & 3) == 0) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0));
         }
@@ -72,6 +81,9 @@ int main() {
         run<4>("dwordx4 at 12 B lane stride", buf, out, 512, mis);
         run<5>("dword, every other lane", buf, out, 512, mis);
         run<6>("dword, one lane in four", buf, out, 512, mis);
+        run<7>("global_load_dwordx2 at 4 B lane stride", buf, out, 512, mis);
+        run<8>("global_load_dword, consecutive lanes", buf, out, 512, mis);
+        run<9>("dwordx2, 8-byte aligned, lanes pairwise overlapping", buf, out, 512, mis);
     }
     return 0;
 }
