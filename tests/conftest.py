@@ -36,8 +36,12 @@ def _built():
     import subprocess
 
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    from lagomorph_amd import build as lbuild
+    # by path: `import lagomorph_amd` needs the library this builds
+    import importlib.util
 
+    spec = importlib.util.spec_from_file_location("lagomorph_amd_build", os.path.join(ROOT, "lagomorph_amd", "build.py"))
+    lbuild = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lbuild)
     lbuild.build()
 
 

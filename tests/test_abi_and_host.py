@@ -171,3 +171,23 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "two- and three-dimensional" in r.stdout
+
+
+def test_builder_does_not_need_the_package():
+    """A fresh checkout has no library, and `import lagomorph_amd` fails loudly without it -- so the
+    builder must be loadable on its own (by path, as __graft_entry__.build() and conftest do) and
+    `python -m lagomorph_amd.build` must get past the package import."""
+    import subprocess
+    import sys
+
+    import __graft_entry__ as ge
+
+    b = ge._load_builder()
+    assert callable(b.build) and b.LIB.endswith("liblagomorph_hip.so")
+    src = open(os.path.join(ROOT, "lagomorph_amd", "build.py")).read()
+    assert "from ." not in src and "import lagomorph_amd" not in src
+    # the package import is skipped when the interpreter was started as `-m lagomorph_amd.build`
+    code = ("import sys; sys.orig_argv = ['python', '-m', 'lagomorph_amd.build']; import lagomorph_amd; "
+            "print(lagomorph_amd._BUILDING, hasattr(lagomorph_amd, 'expmap'))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and r.stdout.split() == ["True", "False"], (r.stdout, r.stderr)
