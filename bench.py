@@ -283,6 +283,29 @@ def cpu_baseline(size, euler_steps, sample_batch=1):
     }
 
 
+def ensure_built(local_rank):
+    """A fresh checkout carries no binaries: local rank 0 builds the HIP library and the oracle (what
+    __graft_entry__.build() does), the other ranks of the node wait for the files."""
+    lib = os.path.join(ROOT, "lagomorph_amd", "_lib", "liblagomorph_hip.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "liblago_oracle.so")
+    if os.path.exists(lib) and os.path.exists(orc):
+        return
+    if local_rank == 0:
+        import contextlib
+
+        import __graft_entry__ as ge
+
+        with contextlib.redirect_stdout(sys.stderr):  # stdout carries the one JSON line only
+            ge.build()
+        return
+    t0 = time.time()
+    while not (os.path.exists(lib) and os.path.exists(orc)):
+        if time.time() - t0 > 1200:
+            raise SystemExit("bench.py: timed out waiting for local rank 0 to build the HIP library")
+        time.sleep(2.0)
+    time.sleep(2.0)  # let the linker finish writing
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,6 +325,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ensure_built(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
