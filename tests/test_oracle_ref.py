@@ -9,6 +9,10 @@ import torch
 from oracle import build_ref
 from oracle import lago_oracle as orc
 
+try:  # (re)build from /root/reference when it is there (a fresh checkout has no binaries); no-op otherwise
+    build_ref.build()
+except Exception as e:  # pragma: no cover - toolchain trouble must not break collection
+    print(f"[tests] oracle/_ref not built: {e}")
 ref = build_ref.load_ref() if __import__("os").path.exists(build_ref.built_path()) else None
 pytestmark = pytest.mark.skipif(ref is None, reason="oracle/_ref not built (needs /root/reference)")
 
