@@ -2,9 +2,10 @@
 
 Host-side mirror of ``/root/reference/lagomorph/lddmm.py:20-105`` (shooting)
 and of the per-minibatch arithmetic of ``LDDMMAtlasBuilder``
-(``lddmm.py:287-341``).  Data loading, HDF5 checkpoints and the CLI of the
-reference are outside this build's scope.
+(``lddmm.py:108-375``) on device-resident tensors.  Data loading and the CLI of
+the reference are outside this build's scope.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -71,14 +72,14 @@ def lddmm_step(I, m, img, metric, dataset_size, integration_steps=5, reg_weight=
         m.grad.zero_()
     regrid_momenta = tuple(m.shape[2:]) != tuple(I.shape[2:])
     h = expmap(metric, m, num_steps=integration_steps)
-    if regrid_momenta:
-        h = regrid(h, shape=I.shape[2:])
+    if regrid_momenta:  # upscale the deformation to apply to the atlas (lddmm.py:306-307; as coded there,
+        h = regrid(h, shape=I.shape[2:])  # without displacement=True: values stay in coarse-grid voxels)
     Idef = deform.interp(I, h)
     v = metric.sharp(m)
     reg_term = reg_weight * (v * m).sum() / img.numel()
-    if regrid_momenta:
+    if regrid_momenta:  # account for downscaling in averaging (lddmm.py:311-312)
         reg_term = reg_term * (I.numel() / v[0, 0, ...].numel())
-    loss = ((Idef - img) ** 2).sum() / img.numel() + reg_term
+    loss = torch.nn.functional.mse_loss(Idef, img, reduction="sum") / img.numel() + reg_term
     loss.backward()
     with torch.no_grad():
         norm_factor = img.shape[0] / dataset_size
@@ -91,21 +92,52 @@ def lddmm_step(I, m, img, metric, dataset_size, integration_steps=5, reg_weight=
     return m.detach(), loss, reg_term
 
 
+def streaming_batch_average(images, batch_size):
+    """Mean over the first axis as the reference's `batch_average` computes it for the initial atlas
+    (data.py:308-336): minibatch sums in float64 folded into a running average, returned in the images'
+    dtype.  On the device the images live on; shape (*images.shape[1:])."""
+    avg, seen = None, 0
+    for b in range(0, images.shape[0], batch_size):
+        img = images[b:b + batch_size]
+        sz = img.shape[0]
+        avi = img.to(torch.float64).sum(dim=0)
+        if avg is None:
+            avg = avi / sz
+        else:
+            avg = avg * (seen / (seen + sz)) + avi / (seen + sz)
+        seen += sz
+    if images.dtype in (torch.float32, torch.float64):
+        avg = avg.to(images.dtype)
+    return avg
+
+
 class LDDMMAtlasBuilder:
     """Batch-sharded atlas building over in-memory volumes (lddmm.py:108-375, compute path only).
 
     Each rank owns a contiguous shard of the subjects and of their momenta, both resident in HBM
     (the reference parks momenta in pinned host memory and copies them every iteration,
-    lddmm.py:236,328,337).  The only collectives are the SUM all-reduce of the atlas gradient per
-    image update (lddmm.py:292-297), one all-reduce of the initial mean image (lddmm.py:196-198)
-    and one of the two scalar losses per epoch (the reference reduces them every iteration and
-    then calls .item(), lddmm.py:333-341)."""
+    lddmm.py:236,328,337).  Every rank must hold the same number of minibatches (the reference's
+    DistributedSampler pads the shards to equal length for the same reason).
 
-    def __init__(self, images, batch_size=8, lddmm_integration_steps=5, image_update_freq=0, reg_weight=1e2,
-                 learning_rate_pose=2e2, learning_rate_image=1e4, metric=None, momentum_shape=None,
-                 momentum_preconditioning=False, I0=None, world_size=1, rank=0, dataset_size=None):
+    Collectives -- the atlas gradient only, as lddmm.py:292-297 prescribes:
+      * ONE SUM all-reduce of `I.grad` (1, 1, *image_shape) per image update.  It is issued
+        asynchronously from a post-accumulate-grad hook on the atlas: `I.grad` is final as soon as the
+        splat of `deform.interp`'s backward has run -- the first node of the backward pass -- so the
+        reduction travels over xGMI while the backward continues through the `integration_steps` Euler
+        steps of `expmap`, and is waited for just before `image_optimizer.step()`.  (With the
+        reference's blocking call it starts only after the whole backward and the momentum update.)
+      * one all-reduce of the initial mean image (lddmm.py:196-198);
+      * one all-reduce of the stacked per-iteration (loss, reg) pairs per epoch -- the reference
+        reduces both scalars every iteration and then calls .item() (lddmm.py:333-341), a host
+        synchronisation per minibatch; the per-iteration histories come out identical."""
+
+    def __init__(self, images, batch_size=8, lddmm_steps=1, lddmm_integration_steps=5, image_update_freq=0,
+                 reg_weight=1e2, learning_rate_pose=2e2, learning_rate_image=1e4, metric=None, momentum_shape=None,
+                 image_shape=None, momentum_preconditioning=False, I0=None, ms=None, world_size=1, rank=0,
+                 dataset_size=None, checkpoint_format=None, overlap_allreduce=True):
         self.images = images  # this rank's shard: (n_local, 1, *sp) on the device
         self.batch_size = batch_size
+        self.lddmm_steps = lddmm_steps
         self.lddmm_integration_steps = lddmm_integration_steps
         self.image_update_freq = image_update_freq
         self.reg_weight = reg_weight
@@ -115,26 +147,59 @@ class LDDMMAtlasBuilder:
         self.momentum_preconditioning = momentum_preconditioning
         self.world_size = world_size
         self.rank = rank
+        self.checkpoint_format = checkpoint_format
+        self.overlap_allreduce = overlap_allreduce
         n_local = images.shape[0]
         self.dataset_size = dataset_size if dataset_size is not None else n_local * world_size
         dim = images.dim() - 2
+        # lddmm.py:186-207: mean image (all-reduced and averaged over ranks) unless I0 is given; brought
+        # onto `image_shape` by regrid when the shapes differ
+        self.image_shape = tuple(image_shape) if image_shape is not None else tuple(images.shape[2:])
         with torch.no_grad():
-            if I0 is None:  # lddmm.py:186-198: mean image, all-reduced and averaged over ranks
-                I0 = images.mean(dim=0, keepdim=True)
+            if I0 is None:
+                I0 = streaming_batch_average(images, batch_size).unsqueeze(0)
                 if world_size > 1:
                     dist.all_reduce(I0)
                     I0 /= world_size
-            self.I = I0.detach().clone().view(1, 1, *images.shape[2:])
+            else:
+                I0 = I0.detach().to(images.device, images.dtype)
+                I0 = I0.reshape(1, 1, *I0.shape[-dim:])
+            if tuple(I0.shape[2:]) != self.image_shape:
+                I0 = regrid(I0.contiguous(), self.image_shape)
+            self.I = I0.detach().clone().view(1, 1, *self.image_shape)
         self.I.requires_grad_(True)
         self.image_optimizer = torch.optim.SGD([self.I], lr=learning_rate_image, weight_decay=0)
         self.image_optimizer.zero_grad()
-        msp = tuple(momentum_shape) if momentum_shape is not None else tuple(images.shape[2:])
-        self.ms = [
-            torch.zeros((min(batch_size, n_local - b), dim) + msp, dtype=images.dtype, device=images.device)
-            for b in range(0, n_local, batch_size)
-        ]
+        self.momentum_shape = tuple(momentum_shape) if momentum_shape is not None else self.image_shape
+        self.regrid_momenta = self.momentum_shape != self.image_shape
+        bsz = [min(batch_size, n_local - b) for b in range(0, n_local, batch_size)]
+        if ms is None:  # lddmm.py:229-235
+            ms = [torch.zeros((b, dim) + self.momentum_shape, dtype=images.dtype, device=images.device) for b in bsz]
+        else:
+            ms = [m.detach().to(images.device, images.dtype).contiguous() for m in ms]
+            if [int(m.shape[0]) for m in ms] != bsz:
+                raise ValueError("ms does not match this rank's minibatches")
+        self.ms = ms
         self.image_iters = 0
         self.epoch_losses, self.epoch_reg_terms = [], []
+        self.iter_losses, self.iter_reg_terms = [], []
+        self._pending_hist = []    # per-epoch (iterations, 2) device tensors not yet moved to the host
+        self._epoch = 0
+        # async all-reduce plumbing
+        self._reduce_now = False   # set by iteration(): the hook should start the reduction
+        self._work = None          # outstanding all-reduce of I.grad
+        self._hook = self.I.register_post_accumulate_grad_hook(self._on_image_grad)
+
+    # ---- atlas gradient all-reduce -------------------------------------------------------
+
+    def _on_image_grad(self, param):
+        """Runs inside the backward pass right after `I.grad` received the splat of this minibatch."""
+        if self._reduce_now and self.world_size > 1 and self._work is None:
+            self._work = dist.all_reduce(param.grad, async_op=True)
+
+    def _will_update(self, last_of_epoch):
+        # the decision update_base_image() is going to take after this iteration (lddmm.py:287-291)
+        return self.image_iters + 1 >= self.image_update_freq or last_of_epoch
 
     def update_base_image(self, force=False):
         """lddmm.py:287-298"""
@@ -142,75 +207,160 @@ class LDDMMAtlasBuilder:
             return
         with torch.no_grad():
             if self.world_size > 1:
-                dist.all_reduce(self.I.grad)
+                if self._work is not None:
+                    self._work.wait()
+                    self._work = None
+                else:
+                    dist.all_reduce(self.I.grad)
             self.I.grad = self.I.grad / (self.image_iters * self.world_size)
             self.image_optimizer.step()
             self.image_optimizer.zero_grad()
         self.image_iters = 0
 
-    def iteration(self, b):
+    # ---- one minibatch ---------------------------------------------------------------------
+
+    def iteration(self, b, last_of_epoch=False):
+        """lddmm.py:327-341.  Returns (loss, reg_term) of this rank's minibatch as 0-dim device
+        tensors (they are reduced over ranks once per epoch)."""
         img = self.images[b * self.batch_size:(b + 1) * self.batch_size]
-        m, loss, reg = lddmm_step(self.I, self.ms[b], img, self.metric, self.dataset_size,
-                                  integration_steps=self.lddmm_integration_steps, reg_weight=self.reg_weight,
-                                  learning_rate_pose=self.learning_rate_pose,
-                                  momentum_preconditioning=self.momentum_preconditioning)
+        m = self.ms[b]
+        for lit in range(self.lddmm_steps):
+            last = lit == self.lddmm_steps - 1
+            self.I.requires_grad_(last)  # lddmm.py:331-332: the image gradient comes from the last step only
+            self._reduce_now = last and self.overlap_allreduce and self._will_update(last_of_epoch)
+            m, loss, reg = lddmm_step(self.I, m, img, self.metric, self.dataset_size,
+                                      integration_steps=self.lddmm_integration_steps, reg_weight=self.reg_weight,
+                                      learning_rate_pose=self.learning_rate_pose,
+                                      momentum_preconditioning=self.momentum_preconditioning)
+        self._reduce_now = False
         self.ms[b] = m
         self.image_iters += 1
         self.update_base_image()
         return loss, reg
 
     def epoch(self):
-        """lddmm.py:343-362; returns (epoch_loss, epoch_reg_term) as 0-dim device tensors."""
+        """lddmm.py:343-362; returns (epoch_loss, epoch_reg_term) as 0-dim device tensors and appends
+        the per-iteration values (reduced over ranks) to iter_losses / iter_reg_terms."""
         if self.image_update_freq == 0:
             self.image_optimizer.zero_grad()
         self.image_iters = 0
-        tot = torch.zeros(2, dtype=self.images.dtype, device=self.images.device)
-        for b in range(len(self.ms)):
-            loss, reg = self.iteration(b)
-            tot[0] += loss
-            tot[1] += reg
+        nb = len(self.ms)
+        hist = torch.zeros((max(nb, 1), 2), dtype=self.images.dtype, device=self.images.device)
+        for b in range(nb):
+            loss, reg = self.iteration(b, last_of_epoch=b == nb - 1)
+            hist[b, 0] = loss
+            hist[b, 1] = reg
         self.update_base_image(force=True)
         if self.world_size > 1:
-            dist.all_reduce(tot)
+            dist.all_reduce(hist)
+        self._pending_hist.append(hist[:nb])
+        tot = hist[:nb].sum(dim=0)
+        if self.checkpoint_format is not None:
+            self.save(self.checkpoint_format.format(epoch=self._epoch))
         return tot[0], tot[1]
 
+    def _flush_history(self):
+        """Move the device-side histories to host floats (one synchronisation)."""
+        if self._pending_hist:
+            h = torch.cat(self._pending_hist, dim=0).cpu().tolist()
+            self.iter_losses.extend(x[0] for x in h)
+            self.iter_reg_terms.extend(x[1] for x in h)
+            self._pending_hist = []
+        self.epoch_losses = [float(x) for x in self.epoch_losses]
+        self.epoch_reg_terms = [float(x) for x in self.epoch_reg_terms]
+
     def run(self, num_epochs=1):
+        """lddmm.py:364-375.  Losses stay on the device during the run and are converted once at the end."""
+        self.image_optimizer.zero_grad()
         for _ in range(num_epochs):
             l, r = self.epoch()
             self.epoch_losses.append(l)
             self.epoch_reg_terms.append(r)
+            self._epoch += 1
+        self._flush_history()
         return self.I.detach()
 
-    # ---- checkpoint / resume (the reference writes the same fields to HDF5, lddmm.py:238-285) ----
+    # ---- checkpoint / resume: the reference's HDF5 layout (lddmm.py:238-285) ---------------
 
     def state_dict(self):
-        """Atlas, this rank's momenta (one tensor per minibatch, as the reference stores them with a
-        `batch_sizes` attribute) and the loss histories -- what `LDDMMAtlasBuilder.save` of the
-        reference writes (lddmm.py:238-262), as a plain dict of CPU tensors."""
+        """What `LDDMMAtlasBuilder.save` of the reference writes (lddmm.py:238-262), as numpy arrays under
+        the reference's dataset names: `atlas`, `momenta` (this rank's minibatches concatenated along the
+        batch axis; in the momenta's own dtype -- the reference always narrows to float32, which would make a
+        float64 run resume inexactly) with its `batch_sizes` attribute, `epoch_losses`, `epoch_reg_terms`, `iter_losses`,
+        `iter_reg_terms`."""
+        self._flush_history()
         return {
-            "atlas": self.I.detach().cpu().clone(),
-            "momenta": [m.detach().cpu().clone() for m in self.ms],
+            "atlas": self.I.detach().cpu().numpy(),
+            "momenta": torch.cat([m.detach() for m in self.ms], dim=0).cpu().numpy(),
             "batch_sizes": [int(m.shape[0]) for m in self.ms],
-            "epoch_losses": [float(x) for x in self.epoch_losses],
-            "epoch_reg_terms": [float(x) for x in self.epoch_reg_terms],
-            "rank": self.rank, "world_size": self.world_size,
+            "epoch_losses": np.asarray(self.epoch_losses, dtype=np.float64),
+            "epoch_reg_terms": np.asarray(self.epoch_reg_terms, dtype=np.float64),
+            "iter_losses": np.asarray(self.iter_losses, dtype=np.float64),
+            "iter_reg_terms": np.asarray(self.iter_reg_terms, dtype=np.float64),
         }
 
-    def load_state_dict(self, state):
+    def load_state_dict(self, state, load_image=True, load_momenta=True, load_losses=True):
         """Resume from `state_dict()` (reference: `load`, lddmm.py:264-285)."""
-        if state["batch_sizes"] != [int(m.shape[0]) for m in self.ms]:
-            raise ValueError("checkpoint was written with a different shard / batch size")
         with torch.no_grad():
-            self.I.copy_(state["atlas"].to(self.I.device, self.I.dtype))
-            for m, s in zip(self.ms, state["momenta"]):
-                m.detach_().copy_(s.to(m.device, m.dtype))
-        self.epoch_losses = list(state["epoch_losses"])
-        self.epoch_reg_terms = list(state["epoch_reg_terms"])
+            if load_image:
+                atlas = torch.as_tensor(np.asarray(state["atlas"])).to(self.I.device, self.I.dtype)
+                self.I.copy_(atlas.view_as(self.I))
+            if load_momenta:
+                szs = [int(s) for s in state["batch_sizes"]]
+                if szs != [int(m.shape[0]) for m in self.ms]:
+                    raise ValueError("checkpoint was written with a different shard / batch size")
+                mom = np.asarray(state["momenta"])
+                i = 0
+                for m, s in zip(self.ms, szs):
+                    m.detach_().copy_(torch.as_tensor(mom[i:i + s]).to(m.device, m.dtype))
+                    i += s
+        if load_losses:
+            self.epoch_losses = [float(x) for x in state["epoch_losses"]]
+            self.epoch_reg_terms = [float(x) for x in state["epoch_reg_terms"]]
+            self.iter_losses = [float(x) for x in state["iter_losses"]]
+            self.iter_reg_terms = [float(x) for x in state["iter_reg_terms"]]
         self.image_iters = 0
         self.image_optimizer.zero_grad()
 
-    def save(self, path):
-        torch.save(self.state_dict(), path)
+    def _rank_path(self, filename):
+        # every rank owns different momenta: rank r > 0 writes next to rank 0's file
+        return filename if self.rank == 0 else f"{filename}.rank{self.rank}"
 
-    def load(self, path):
-        self.load_state_dict(torch.load(path, map_location="cpu"))
+    def save(self, filename):
+        """HDF5 with the reference's dataset names when h5py is importable (lddmm.py:251-262); otherwise
+        the same dictionary through torch.save.  Rank r > 0 writes `<filename>.rank<r>`."""
+        st = self.state_dict()
+        path = self._rank_path(filename)
+        try:
+            import h5py
+        except ImportError:
+            torch.save(st, path)
+            return path
+        with h5py.File(path, "w") as f:
+            f.create_dataset("atlas", data=st["atlas"])
+            hms = f.create_dataset("momenta", shape=st["momenta"].shape, dtype=st["momenta"].dtype)
+            hms[...] = st["momenta"]
+            hms.attrs["batch_sizes"] = st["batch_sizes"]
+            for k in ("epoch_losses", "epoch_reg_terms", "iter_losses", "iter_reg_terms"):
+                f.create_dataset(k, data=st[k])
+        return path
+
+    def load(self, filename, load_image=True, load_momenta=True, load_losses=True):
+        path = self._rank_path(filename)
+        try:
+            import h5py
+        except ImportError:
+            h5py = None
+        is_h5 = False
+        with open(path, "rb") as fh:
+            is_h5 = fh.read(8) == b"\x89HDF\r\n\x1a\n"
+        if is_h5:
+            if h5py is None:
+                raise RuntimeError(f"{path} is an HDF5 checkpoint but h5py is not importable")
+            with h5py.File(path, "r") as f:
+                st = {k: np.asarray(f[k]) for k in ("atlas", "momenta", "epoch_losses", "epoch_reg_terms",
+                                                    "iter_losses", "iter_reg_terms")}
+                st["batch_sizes"] = [int(s) for s in f["momenta"].attrs["batch_sizes"]]
+        else:
+            st = torch.load(path, map_location="cpu", weights_only=False)
+        self.load_state_dict(st, load_image=load_image, load_momenta=load_momenta, load_losses=load_losses)

@@ -43,13 +43,23 @@ def _run(rank, world, port, sp, out):
         data = _dataset(4, sp)
         per = data.shape[0] // world
         shard = data[rank * per:(rank + 1) * per]
+        # record every all-reduce: (numel, async?, issued from inside the backward pass?)
+        calls = []
+        real_all_reduce = dist.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append((t.numel(), bool(k.get("async_op", False)), torch._C._current_graph_task_id() != -1))
+            return real_all_reduce(t, *a, **k)
+
+        lm.lddmm.dist.all_reduce = spy
         b = lm.LDDMMAtlasBuilder(shard, batch_size=2, lddmm_integration_steps=2, reg_weight=1e-1,
                                  learning_rate_pose=1e-2, learning_rate_image=1e-1, world_size=world, rank=rank,
                                  dataset_size=data.shape[0])
         I = b.run(num_epochs=2)
         res = {"I": I.numpy(), "loss": [float(x) for x in b.epoch_losses], "m0": b.ms[0].numpy()}
         if rank == 0:
-            np.savez(out, I=res["I"], loss=np.array(res["loss"]), m0=res["m0"])
+            np.savez(out, I=res["I"], loss=np.array(res["loss"]), m0=res["m0"], calls=np.array(calls, dtype=np.int64),
+                     iter_loss=np.array(b.iter_losses))
     finally:
         dist.destroy_process_group()
 
@@ -95,6 +105,13 @@ def test_two_rank_atlas_equals_sequential_emulation(tmp_path, oracle_ext, sp):
     assert np.allclose(r["loss"], losses, rtol=1e-10)
     assert np.allclose(r["m0"], ms[0].numpy(), rtol=1e-10, atol=1e-12)  # rank 0 owns the first minibatch
     assert not np.allclose(r["I"], data.mean(0, keepdim=True).numpy())  # the atlas actually moved
+    assert np.allclose(r["iter_loss"], losses, rtol=1e-10)  # one iteration per epoch here: iteration loss == epoch loss
+    # collectives: the mean image once, then per epoch ONE all-reduce of the atlas gradient -- asynchronous and
+    # issued from inside the backward pass (it overlaps the rest of the backward through expmap) -- and one of the
+    # stacked (loss, reg) history; nothing else
+    nv = int(np.prod(sp))
+    calls = [tuple(c) for c in r["calls"].tolist()]
+    assert calls == [(nv, 0, 0), (nv, 1, 1), (2, 0, 0), (nv, 1, 1), (2, 0, 0)], calls
 
 
 def _run_affine(rank, world, port, sp, out):
