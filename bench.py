@@ -3,18 +3,27 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no WORLD_SIZE in the environment this process only parses its arguments and starts N
+fresh worker processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) BEFORE anything
+touches a GPU; it never initialises HIP itself.  Started by a launcher (WORLD_SIZE set), it is one of
+the workers and refuses to run when WORLD_SIZE != --gpus.
+
 Headline (BASELINE.json `metric`): LDDMM step voxels/sec, 3D 128^3 -- one "step" of this
 benchmark is one `lddmm.expmap` call (10 Euler steps of the integrated EPDiff equation,
-BASELINE configs[3]) over a batch of 32 momentum fields of 3x128^3 fp32 per GPU, inputs
-resident in HBM.  value = (voxels * Euler steps) processed by all ranks / wall time.
-The batch is sharded over ranks with no data-path collective ("weak": per-GPU batch fixed).
+BASELINE configs[3]) over a GLOBAL batch of 32 momentum fields of 3x128^3 fp32, sharded 32/N per
+GPU ("strong" scaling: the global batch is fixed), inputs resident in HBM, no data-path collective.
+value = (voxels * Euler steps) processed by all ranks / wall time (max over ranks).
 
 Also on the same JSON line:
-  roofline      -- the dominant hand-written kernel of the timed region (3D interp forward,
-                   C = 3): algorithmic bytes / mean launch time measured live with HIP events.
-  cpu_baseline  -- the CPU oracle (scalar C port, 1 thread) on a bounded sample of the same
-                   workload, timed on this host (rank 0, N = 1 only).
-  interp_splat, fluid -- BASELINE configs[1] / configs[2] micro-measurements (interp HBM GB/s).
+  atlas_step    -- BASELINE configs[4], at every N: `LDDMMAtlasBuilder.iteration` (lddmm_step = 5-step expmap
+                   -> interp -> loss -> backward through every operator -> momentum update, then ONE RCCL
+                   all-reduce of the atlas gradient and the image update) on 160^3 subjects, global
+                   minibatch 32 split N ways; voxels/s, ms per step, the all-reduce time, rank count.
+  roofline      -- the dominant hand-written kernel of the timed region: algorithmic bytes / mean launch
+                   time measured live with HIP events on the launch stream; PMC traffic from profiles/.
+  cpu_baseline  -- the CPU oracle (C port, OpenMP) on bounded samples of the same workloads, timed on
+                   this host (rank 0, N = 1 only): the expmap sample plus per-operator figures.
+  interp_splat, fluid, other_ops -- BASELINE configs[1] / configs[2] micro-measurements (N = 1 only).
 """
 import argparse
 import json
@@ -217,15 +226,115 @@ def micro_atlas_step(lm, dev, size, batch=8):
         lm.lddmm_step(I, m, img, metric, dataset_size=batch, integration_steps=5, learning_rate_pose=0.0)
 
     med, _ = time_op(step, reps=5, warm=2)
+    bpv = lddmm_step_alg_bytes_per_voxel(5)
+    gbps = bpv * batch * size ** 3 / med / 1e6
     return {"workload": f"lddmm_step (fwd + bwd + update) batch {batch} x {size}^3 fp32, 5 integration steps",
-            "ms": med, "Gvoxel_per_s": batch * size ** 3 / med / 1e6}
+            "ms": med, "Gvoxel_per_s": batch * size ** 3 / med / 1e6, "alg_bytes_per_voxel": bpv,
+            "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+
+
+# Algorithmic bytes per voxel of one lddmm_step with S integration steps (fp32, d = 3, one image channel; every
+# tensor counted once per operator of an ideally fused implementation, SURVEY 8d conventions):
+#   forward  per Euler step: Ad_star 36 + sharp 72.8 + compose 36                                   = 144.8
+#   backward per Euler step: compose^T 60 (go, u, v in; d_u, d_v out) + sharp 72.8 + Ad_star^T 60     = 192.8
+#   once: interp(I, h) 16 + its backward 28 (atlas broadcast: I and d_I are 1/B of a voxel each) + mse fwd/bwd 8 + 12
+#         + reg term: sharp 72.8 forward and backward + <v, m> 24 + momentum update 36
+def lddmm_step_alg_bytes_per_voxel(steps):
+    return steps * (144.8 + 192.8) + 16 + 28 + 8 + 12 + 2 * 72.8 + 24 + 36
+
+
+def atlas_leg(lm, dev, world, rank, args):
+    """BASELINE configs[4]: the batched atlas step at `args.atlas_size`^3, global minibatch `args.atlas_batch`
+    split over the ranks, one all-reduce of the atlas gradient per image update (image_update_freq = 0:
+    every iteration, lddmm.py:287-298).  Timed exactly like the headline: barrier + synchronize on both sides,
+    max over ranks.  Learning rates are small so that every timed step sees a comparable state."""
+    S, GB = args.atlas_size, args.atlas_batch
+    if GB % world:
+        raise SystemExit(f"bench.py: --atlas-batch {GB} is not divisible by {world} ranks")
+    B = GB // world
+    iters = args.atlas_warmup + args.atlas_steps
+    g = torch.Generator(device=dev).manual_seed(777)  # the template is the same on every rank
+    tmpl = gaussian_blur(torch.randn((1, 1, S, S, S), device=dev, generator=g), 3.0)
+    tmpl = tmpl / tmpl.std()
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    subj = []
+    with torch.no_grad():
+        for _ in range(iters):  # this rank's shard: `iters` minibatches of B subjects = template o (id + smooth u) + noise
+            u = gaussian_blur(torch.randn((B, 3, S, S, S), device=dev, generator=g), 8.0)
+            u *= 3.0 / u.abs().max()
+            x = lm.interp(tmpl, u) + 0.05 * torch.randn((B, 1, S, S, S), device=dev, generator=g)
+            subj.append(x)
+            del u
+        images = torch.cat(subj)
+        del subj
+    builder = lm.LDDMMAtlasBuilder(images, batch_size=B, lddmm_integration_steps=5, reg_weight=1e2,
+                                   learning_rate_pose=1e-3, learning_rate_image=1e-2, world_size=world, rank=rank,
+                                   dataset_size=GB * iters)
+    # momenta that shoot to ~3 voxels, so that the gathers and splats see a realistic displacement
+    with torch.no_grad():
+        for b in range(len(builder.ms)):
+            m = gaussian_blur(torch.randn(builder.ms[b].shape, device=dev, generator=g), 4.0)
+            m *= 3.0 / builder.metric.sharp(m).abs().max()
+            builder.ms[b] = m
+    torch.cuda.empty_cache()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for b in range(args.atlas_warmup):
+        builder.iteration(b)
+    sync()
+    t0 = time.perf_counter()
+    for b in range(args.atlas_warmup, iters):
+        builder.iteration(b)
+    sync()
+    T = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(T, op=dist.ReduceOp.MAX)
+    T = T.item()
+    # the collective on its own: a blocking all-reduce of one (1, 1, S, S, S) fp32 gradient
+    ar_ms = None
+    if world > 1:
+        buf = torch.zeros((1, 1, S, S, S), device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        ts = []
+        for _ in range(10):
+            sync()
+            t1 = time.perf_counter()
+            dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        ar = torch.tensor([sorted(ts)[len(ts) // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        ar_ms = 1e3 * ar.item()
+    vox = GB * S ** 3 * args.atlas_steps
+    bpv = lddmm_step_alg_bytes_per_voxel(5)
+    gbps = bpv * vox / T / 1e9
+    finite = bool(torch.isfinite(builder.I).all().item())
+    del builder, images
+    torch.cuda.empty_cache()
+    return {
+        "workload": f"LDDMMAtlasBuilder.iteration (lddmm_step fwd + bwd + momentum update, all-reduce of the atlas "
+                    f"gradient, image update), {S}^3 fp32, global minibatch {GB} = {B} per GPU x {world}, 5 integration "
+                    f"steps (BASELINE configs[4])",
+        "value": vox / T, "unit": "voxels/s", "ms_per_step": 1e3 * T / args.atlas_steps, "steps": args.atlas_steps,
+        "warmup": args.atlas_warmup, "n_ranks": world, "global_batch": GB, "per_gpu_batch": B, "scaling": "strong",
+        "collective": "RCCL all_reduce(SUM) of I.grad, %.1f MB fp32, issued from the backward pass" % (4 * S ** 3 / 1e6)
+                      if world > 1 else None,
+        "allreduce_ms": ar_ms, "alg_bytes_per_voxel": bpv, "achieved_GBps": gbps,
+        "frac_of_hbm_peak": gbps / (HBM_PEAK_GBPS * world), "finite": finite,
+    }
 
 
 def cpu_baseline(size, euler_steps, sample_batch=1):
-    """Times the CPU oracle (test infrastructure) on a bounded sample of the headline workload --
-    `sample_batch` volumes of size^3, one expmap of `euler_steps` steps -- on the host's cores (OpenMP,
-    at most 64 threads) and on one thread.  The oracle stands in for lagomorph_ext only inside this
-    function."""
+    """Times the CPU oracle (test infrastructure) on bounded samples of the benchmark's workloads on the host's
+    cores (OpenMP, at most 64 threads) and on one thread: the headline sample (`sample_batch` volumes of size^3,
+    one expmap of `euler_steps` steps) and the four operators of BASELINE.md section 4 (interp, splat, jtv, sharp)
+    at batch 8.  The oracle stands in for lagomorph_ext only inside this function."""
     import numpy as np
 
     import lagomorph_amd as lm
@@ -256,11 +365,37 @@ def cpu_baseline(size, euler_steps, sample_batch=1):
             m = torch.from_numpy((0.01 * rng.standard_normal((batch, 3, size, size, size))).astype(np.float32))
             orc.set_threads(threads)
             torch.set_num_threads(threads)
+            with torch.no_grad():  # untimed: thread pool start-up, FFT plans, LUTs
+                lm.expmap(met, m[:1], num_steps=1)
             t0 = time.perf_counter()
             with torch.no_grad():
                 lm.expmap(met, m, num_steps=euler_steps)
             dt = time.perf_counter() - t0
             runs[tag] = (batch * size ** 3 * euler_steps / dt, dt, batch, threads)
+        # per-operator figures, batch 8 x size^3: voxels/s and algorithmic GB/s
+        nb = 8
+        V = nb * size ** 3
+        I1 = rng.standard_normal((nb, 1, size, size, size)).astype(np.float32)
+        u3 = (2.0 * rng.standard_normal((nb, 3, size, size, size))).astype(np.float32)
+        w3 = rng.standard_normal((nb, 3, size, size, size)).astype(np.float32)
+        w3t = torch.from_numpy(w3)
+        per_op = {}
+        cases = {
+            "interp_forward(C=1)": (lambda: orc.interp_forward(I1, u3, 1.0), 20),
+            "interp_backward(C=1, splat + d_u)": (lambda: orc.interp_backward(I1, I1, u3, 1.0, True, True), 36),
+            "jtv_forward(C=3)": (lambda: orc.jacobian_times_vectorfield_forward(u3, w3, True, False), 36),
+            "sharp(3x)": (lambda: met.sharp(w3t), 72.8),
+        }
+        for tag, threads in (("all", nthreads), ("one", 1)):
+            orc.set_threads(threads)
+            torch.set_num_threads(threads)
+            for name, (fn, bpv) in cases.items():
+                with torch.no_grad():
+                    t0 = time.perf_counter()
+                    fn()
+                    dt = time.perf_counter() - t0
+                per_op.setdefault(name, {"alg_bytes_per_voxel": bpv})[tag] = {
+                    "threads": threads, "s": dt, "voxels_per_s": V / dt, "GBps": bpv * V / dt / 1e9}
     finally:
         try:
             orc.set_threads(1)
@@ -276,9 +411,10 @@ def cpu_baseline(size, euler_steps, sample_batch=1):
     return {
         "value": v_all, "unit": "voxels/s", "cores": th_all, "kind": "port",
         "sample": f"expmap {euler_steps} Euler steps, batch {b_all} x 3x{size}^3 fp32, oracle C port with OpenMP over "
-                  f"the voxel loops ({th_all} threads; FFTs by torch CPU/pocketfft), {dt_all:.1f} s",
+                  f"the output voxels ({th_all} threads; FFTs by torch CPU/pocketfft), {dt_all:.1f} s",
         "one_thread": {"value": v_one, "cores": 1,
                        "sample": f"same, batch {b_one}, 1 thread, {dt_one:.1f} s"},
+        "per_op": {"sample": f"one call each at batch {nb} x {size}^3 fp32 (rough displacement, 2 voxels rms)", "ops": per_op},
         "host_cpus": os.cpu_count(),
     }
 
@@ -306,23 +442,59 @@ def ensure_built(local_rank):
     time.sleep(2.0)  # let the linker finish writing
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="momentum fields per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="momentum fields over ALL GPUs (sharded batch/N per GPU)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--euler-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
+    ap.add_argument("--no-atlas", action="store_true")
+    ap.add_argument("--atlas-size", type=int, default=160)
+    ap.add_argument("--atlas-batch", type=int, default=32, help="subjects per atlas update over ALL GPUs")
+    ap.add_argument("--atlas-steps", type=int, default=4)
+    ap.add_argument("--atlas-warmup", type=int, default=1)
     ap.add_argument("--cpu-sample-batch", type=int, default=16,
                     help="volumes in the all-cores CPU baseline sample (the one-thread sample is a quarter of it)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_workers(args):
+    """Parent of an N-GPU run started without a launcher: start N fresh workers, one per GPU, before any GPU call
+    (counting devices does not initialise HIP) and hand their output through.  Returns the exit code."""
+    import socket
+    import subprocess
+
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_workers(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a run on the wrong "
+                         "number of ranks")
+    if args.batch % world:
+        raise SystemExit(f"bench.py: --batch {args.batch} is not divisible by {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     ensure_built(local_rank)
@@ -330,12 +502,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import lagomorph_amd as lm
 
     ext = lm.lagomorph_ext
-    B, S, E = args.batch, args.size, args.euler_steps
+    GBATCH, S, E = args.batch, args.size, args.euler_steps
+    B = GBATCH // world
     torch.manual_seed(1234 + rank)
     metric = lm.FluidMetric([0.1, 0.0, 0.01])  # the atlas builder's default, lddmm.py:213
     with torch.no_grad():
@@ -373,7 +545,7 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     T = elapsed.item()
-    vox_steps = world * B * S ** 3 * E * args.steps
+    vox_steps = GBATCH * S ** 3 * E * args.steps
     V = B * S ** 3
 
     result = {
@@ -385,19 +557,27 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * T / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"lddmm.expmap, {E} Euler steps, batch {B} x 3x{S}^3 fp32 per GPU (BASELINE configs[3]); "
-                        "value counts voxels x Euler steps",
-            "global_batch": B * world, "per_gpu_batch": B, "volume": [S, S, S], "euler_steps": E,
-            "parallelism": f"batch-sharded x{world}, no data-path collective",
+            "workload": f"lddmm.expmap, {E} Euler steps, global batch {GBATCH} x 3x{S}^3 fp32 sharded {B} per GPU "
+                        "(BASELINE configs[3]); value counts voxels x Euler steps",
+            "global_batch": GBATCH, "per_gpu_batch": B, "volume": [S, S, S], "euler_steps": E,
+            "parallelism": f"batch-sharded x{world}, no data-path collective in expmap; the atlas step "
+                           "(atlas_step below) all-reduces the atlas gradient over RCCL",
             "max_abs_displacement_vox": hmax,
         },
     }
+    del m
+    torch.cuda.empty_cache()
+    atlas = None
+    if not args.no_atlas:
+        atlas = atlas_leg(lm, dev, world, rank, args)
     if rank == 0:
+        if atlas is not None:
+            result["atlas_step"] = atlas
         # the dominant single kernel of the timed region (fluid_metric is three kernels and is reported
         # separately): all four candidates move 36 algorithmic bytes per voxel at C = 3
         cands = {
@@ -415,12 +595,15 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
             # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath) and B == 32 and S == 128:
-                for name, rec in json.load(open(tpath)).items():
-                    if name.startswith(prefix):
-                        traffic, tsrc = rec["traffic_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc, same workload)"
-                        break
+            for tname in ("r02_traffic.json", "r01_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if os.path.exists(tpath) and B == 32 and S == 128:
+                    for name, rec in json.load(open(tpath)).items():
+                        if name.startswith(prefix):
+                            traffic, tsrc = rec["traffic_bytes"], f"profiles/{tname} (rocprofv3 --pmc, same workload)"
+                            break
+                if traffic is not None:
+                    break
             result["roofline"] = {
                 "kernel": kname, "op": op, "bound": "hbm", "achieved": ach,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
@@ -440,14 +623,13 @@ def main():
             torch.cuda.empty_cache()
             result["other_ops"] = micro_ops(lm, dev, S)
             torch.cuda.empty_cache()
-            result["atlas_step"] = micro_atlas_step(lm, dev, S)
-            if S == 128:  # BASELINE configs[4] volume size (not a power of two: rocFFT-based fluid metric)
-                torch.cuda.empty_cache()
-                result["atlas_step_160"] = micro_atlas_step(lm, dev, 160)
+            result["atlas_step_128"] = micro_atlas_step(lm, dev, S)
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S, E, args.cpu_sample_batch)
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -37,7 +37,7 @@ extern "C" {
 #define LAGO_ERR_INVALID (-1)
 #define LAGO_ERR_HIP (-2)
 
-#define LAGO_ABI_VERSION 1
+#define LAGO_ABI_VERSION 2
 
 /* ---- housekeeping --------------------------------------------------------- */
 
@@ -169,19 +169,25 @@ int lago_ad_star_f64(double *out, const double *v, const double *m, int dim, int
  * (/root/reference/lagomorph/metric.py:11-19) in one call: out = irfft(L^(+-2) rfft(m)).
  * m, out: (nn, dim, nx, ny[, nz]) real; work: caller-provided scratch for the half spectrum,
  * nn*dim*nx*ny*(nz/2+1)*2 reals for dim == 3 (nn*dim*nx*(ny/2+1)*2 for dim == 2), clobbered.
- * m is not modified; out may not alias m.  LUTs as for lago_fluid_operator; the float32 3D fast paths
- * tabulate the per-frequency coefficients once per (shape, alpha/beta/gamma, direction, LUT pointers) in a
- * library-owned device buffer (24 bytes per frequency bin, at most 16 tables kept), so the contents
- * behind a given set of LUT pointers must not change between calls.  rocFFT (via hipFFT)
- * does the transforms; plans are cached inside the library per shape. */
-int lago_fluid_metric_f32(float *out, const float *m, float *work, int inverse, const float *cosX,
-                          const float *sinX, const float *cosY, const float *sinY, const float *cosZ,
-                          const float *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn,
-                          int64_t nx, int64_t ny, int64_t nz, void *stream);
-int lago_fluid_metric_f64(double *out, const double *m, double *work, int inverse, const double *cosX,
-                          const double *sinX, const double *cosY, const double *sinY, const double *cosZ,
-                          const double *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn,
-                          int64_t nx, int64_t ny, int64_t nz, void *stream);
+ * m is not modified; out may not alias m.  LUTs as for lago_fluid_operator.
+ * lut_generation: the float32 3D fast paths tabulate the per-frequency coefficients once per
+ * (lut_generation, shape, alpha/beta/gamma, direction) in a library-owned device buffer (24 bytes per
+ * frequency bin; the cache is bounded to 1 GiB and evicts oldest-first).  The table is a function of the
+ * LUT *contents*, so the caller names a set of contents by a non-zero generation number and passes a new
+ * number whenever it passes different contents (another shape, a refilled buffer); pointers are not part of
+ * the key.  0 means "do not cache": the call takes the table-free path (rocFFT 3D plan + operator kernel).
+ * hipFFT plans are cached inside the library per shape; their SetStream + Exec pairs are serialised. */
+int lago_fluid_metric_f32(float *out, const float *m, float *work, int64_t lut_generation, int inverse,
+                          const float *cosX, const float *sinX, const float *cosY, const float *sinY,
+                          const float *cosZ, const float *sinZ, double alpha, double beta, double gamma, int dim,
+                          int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream);
+int lago_fluid_metric_f64(double *out, const double *m, double *work, int64_t lut_generation, int inverse,
+                          const double *cosX, const double *sinX, const double *cosY, const double *sinY,
+                          const double *cosZ, const double *sinZ, double alpha, double beta, double gamma, int dim,
+                          int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream);
+/* Drops every cached coefficient table (buffers still read by enqueued kernels are freed after them). */
+void lago_fluid_cache_clear(void);
+int lago_fluid_cache_entries(void);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@
 
 #include <string.h>
 
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -43,15 +44,25 @@ int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int6
 int g_fluid_xpass = 2;
 
 // Operator coefficient tables (see fftx.hip), cached like the FFT plans: one device buffer per
-// (shape, parameters, direction, LUT identity), filled by a kernel on first use.
+// (LUT generation, shape, parameters, direction), filled by a kernel on first use.  The key holds no
+// pointer: a table is a function of the LUT *contents*, which the caller identifies by a generation
+// number it changes whenever it passes different contents (0 = "do not cache": such calls take the
+// table-free path).  Entries are shared_ptrs: a lookup keeps its table alive until its launches are
+// enqueued, eviction only drops the cache's reference, and the deleter's hipFree waits for kernels
+// still reading the buffer.
 struct CoefTab {
-    int64_t nx, ny, nzc;
+    int64_t gen, nx, ny, nz;
     int inverse, device, split;
     double a, b, g;
-    const void *luts[6];
+    size_t bytes;
     float *d;
+    ~CoefTab() {
+        if (d) (void)hipFree(d);
+    }
 };
-static std::vector<CoefTab> g_tabs;
+typedef std::shared_ptr<CoefTab> CoefRef;
+static std::vector<CoefRef> g_tabs;
+static const size_t kCoefCacheBytes = (size_t)1 << 30;  // at most 1 GiB of tables (24 B per frequency bin each)
 
 struct FftPlan {
     int dim, n[3], batch, dbl, device;
@@ -88,39 +99,51 @@ static int get_plan(FftPlan &out, int dim, const int *n, int batch, int dbl) {
     return LAGO_OK;
 }
 
-static int get_coef(float *&tab, int inverse, const float *cosX, const float *sinX, const float *cosY,
+static int get_coef(CoefRef &ref, int64_t gen, int inverse, const float *cosX, const float *sinX, const float *cosY,
                     const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta, double gamma,
-                    int64_t nx, int64_t ny, int64_t nzc, int split, hipStream_t s) {
+                    int64_t nx, int64_t ny, int64_t nz, int split, hipStream_t s) {
     int device = 0;
     LAGO_HIP_TRY(hipGetDevice(&device));
-    const void *l[6] = {cosX, sinX, cosY, sinY, cosZ, sinZ};
+    const int64_t nzc = nz / 2 + 1;
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    for (const CoefTab &t : g_tabs)
-        if (t.nx == nx && t.ny == ny && t.nzc == nzc && t.inverse == inverse && t.device == device && t.split == split &&
-            t.a == alpha &&
-            t.b == beta && t.g == gamma && !memcmp(t.luts, l, sizeof(l))) {
-            tab = t.d;
+    for (const CoefRef &t : g_tabs)
+        if (t->gen == gen && t->nx == nx && t->ny == ny && t->nz == nz && t->inverse == inverse && t->device == device &&
+            t->split == split && t->a == alpha && t->b == beta && t->g == gamma) {
+            ref = t;
             return LAGO_OK;
         }
-    CoefTab t{nx, ny, nzc, inverse, device, split, alpha, beta, gamma, {cosX, sinX, cosY, sinY, cosZ, sinZ}, nullptr};
-    LAGO_HIP_TRY(hipMalloc((void **)&t.d, (size_t)nx * ny * nzc * 6 * sizeof(float)));
-    int rc = fluid_coef_launch(t.d, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, split, s);
+    CoefRef t = std::make_shared<CoefTab>();
+    *t = CoefTab{gen, nx, ny, nz, inverse, device, split, alpha, beta, gamma, (size_t)nx * ny * nzc * 6 * sizeof(float), nullptr};
+    LAGO_HIP_TRY(hipMalloc((void **)&t->d, t->bytes));  // on failure below ~CoefTab frees it
+    int rc = fluid_coef_launch(t->d, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, split, s);
     if (rc != LAGO_OK) return rc;
     // one-time: the table is shared by later calls on ANY stream, so it must be complete before it is
     // published (steady-state calls never synchronise)
     LAGO_HIP_TRY(hipStreamSynchronize(s));
-    if (g_tabs.size() >= 16) {  // bounded cache
-        (void)hipFree(g_tabs.front().d);
+    size_t total = t->bytes;
+    for (const CoefRef &o : g_tabs) total += o->bytes;
+    while (!g_tabs.empty() && (total > kCoefCacheBytes || g_tabs.size() >= 64)) {  // bounded by bytes, oldest first
+        total -= g_tabs.front()->bytes;
         g_tabs.erase(g_tabs.begin());
     }
     g_tabs.push_back(t);
-    tab = t.d;
+    ref = t;
     return LAGO_OK;
+}
+
+// hipFFT plans are shared process-wide and hipfftSetStream + Exec is not atomic: both are issued under the
+// plan mutex (the Exec only enqueues).
+template <typename F>
+static hipfftResult exec_on(hipfftHandle plan, hipStream_t s, F &&exec) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    hipfftResult r = hipfftSetStream(plan, s);
+    if (r != HIPFFT_SUCCESS) return r;
+    return exec();
 }
 
 // float32, 3D, power-of-two nx: rocFFT does the (y, z) transforms as a batched 2D real plan, the
 // x transform + operator + inverse x transform are one kernel (fftx.hip).
-static int fluid_metric_xpass(float *out, const float *m, float *work, int inverse, const float *cosX,
+static int fluid_metric_xpass(float *out, const float *m, float *work, int64_t gen, int inverse, const float *cosX,
                               const float *sinX, const float *cosY, const float *sinY, const float *cosZ,
                               const float *sinZ, double alpha, double beta, double gamma, int64_t nn, int64_t nx,
                               int64_t ny, int64_t nz, hipStream_t s) {
@@ -129,24 +152,20 @@ static int fluid_metric_xpass(float *out, const float *m, float *work, int inver
     int rc = get_plan(p, 2, n2, (int)(nn * 3 * nx), 0);
     if (rc != LAGO_OK) return rc;
     const int64_t nzc = nz / 2 + 1;
-    float *tab = nullptr;
-    rc = get_coef(tab, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nzc, 0, s);
+    CoefRef tab;
+    rc = get_coef(tab, gen, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nz, 0, s);
     if (rc != LAGO_OK) return rc;
-    hipfftResult r = hipfftSetStream(p.fwd, s);
-    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftSetStream");
-    r = hipfftSetStream(p.inv, s);
-    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftSetStream");
-    r = hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work);
+    hipfftResult r = exec_on(p.fwd, s, [&] { return hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work); });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecR2C(2D)");
-    rc = fluid_xpass_launch(work, tab, inverse, nn, nx, ny, nzc, 1.0 / ((double)nx * (double)ny * (double)nz), s);
+    rc = fluid_xpass_launch(work, tab->d, inverse, nn, nx, ny, nzc, 1.0 / ((double)nx * (double)ny * (double)nz), s);
     if (rc != LAGO_OK) return rc;
-    r = hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out);
+    r = exec_on(p.inv, s, [&] { return hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out); });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecC2R(2D)");
     return finish_launch(s, "fluid_metric");
 }
 
 template <typename R>
-static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *cosX, const R *sinX, const R *cosY,
+static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inverse, const R *cosX, const R *sinX, const R *cosY,
                              const R *sinY, const R *cosZ, const R *sinZ, double alpha, double beta, double gamma,
                              int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {
     if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional fluid metric is supported");
@@ -155,18 +174,19 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
         return fail_invalid("fluid_metric: bad extent");
     if (nn == 0) return LAGO_OK;
     if (!out || !m || !work) return fail_invalid("fluid_metric: null pointer");
-    if (sizeof(R) == 4 && dim == 3 && g_fluid_xpass >= 2 && fluid_native_supported(nx, ny, nz) &&
+    // the table-based fast paths need a LUT generation to key their cached coefficient table on
+    if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass >= 2 && fluid_native_supported(nx, ny, nz) &&
         (((uintptr_t)out | (uintptr_t)m | (uintptr_t)work) & 15) == 0) {  // 16-byte vector accesses
-        float *tab = nullptr;
-        int rc = get_coef(tab, inverse, (const float *)cosX, (const float *)sinX, (const float *)cosY,
+        CoefRef tab;
+        int rc = get_coef(tab, gen, inverse, (const float *)cosX, (const float *)sinX, (const float *)cosY,
                           (const float *)sinY, (const float *)cosZ, (const float *)sinZ, alpha, beta, gamma, nx, ny,
-                          nz / 2 + 1, 1, (hipStream_t)stream);
+                          nz, 1, (hipStream_t)stream);
         if (rc != LAGO_OK) return rc;
-        return fluid_metric_native((float *)out, (const float *)m, (float *)work, tab, inverse, nn, nx, ny, nz,
+        return fluid_metric_native((float *)out, (const float *)m, (float *)work, tab->d, inverse, nn, nx, ny, nz,
                                    1.0 / ((double)nx * (double)ny * (double)nz), (hipStream_t)stream);
     }
-    if (sizeof(R) == 4 && dim == 3 && g_fluid_xpass && fluid_xpass_supported(nx) && nn * 3 * nx < (1ll << 31))
-        return fluid_metric_xpass((float *)out, (const float *)m, (float *)work, inverse, (const float *)cosX,
+    if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass && fluid_xpass_supported(nx) && nn * 3 * nx < (1ll << 31))
+        return fluid_metric_xpass((float *)out, (const float *)m, (float *)work, gen, inverse, (const float *)cosX,
                                   (const float *)sinX, (const float *)cosY, (const float *)sinY, (const float *)cosZ,
                                   (const float *)sinZ, alpha, beta, gamma, nn, nx, ny, nz, (hipStream_t)stream);
     const int n[3] = {(int)nx, (int)ny, (int)nz};
@@ -174,14 +194,10 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
     int rc = get_plan(p, dim, n, (int)(nn * dim), sizeof(R) == 8);
     if (rc != LAGO_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipfftResult r = hipfftSetStream(p.fwd, s);
-    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftSetStream");
-    r = hipfftSetStream(p.inv, s);
-    if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftSetStream");
-    if (sizeof(R) == 4)
-        r = hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work);
-    else
-        r = hipfftExecD2Z(p.fwd, (hipfftDoubleReal *)m, (hipfftDoubleComplex *)work);
+    hipfftResult r = exec_on(p.fwd, s, [&] {
+        return sizeof(R) == 4 ? hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work)
+                              : hipfftExecD2Z(p.fwd, (hipfftDoubleReal *)m, (hipfftDoubleComplex *)work);
+    });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExec(forward)");
     // half-spectrum extents: the last axis keeps n/2 + 1 bins
     const int64_t cx = nx, cy = dim == 2 ? ny / 2 + 1 : ny, cz = dim == 3 ? nz / 2 + 1 : 1;
@@ -189,10 +205,10 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
     rc = fluid_operator_impl<R>(work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, cx, cy,
                                 cz, stream, scale);
     if (rc != LAGO_OK) return rc;
-    if (sizeof(R) == 4)
-        r = hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out);
-    else
-        r = hipfftExecZ2D(p.inv, (hipfftDoubleComplex *)work, (hipfftDoubleReal *)out);
+    r = exec_on(p.inv, s, [&] {
+        return sizeof(R) == 4 ? hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out)
+                              : hipfftExecZ2D(p.inv, (hipfftDoubleComplex *)work, (hipfftDoubleReal *)out);
+    });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExec(inverse)");
     return finish_launch(s, "fluid_metric");
 }
@@ -201,13 +217,21 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int inverse, const R *
 
 extern "C" {
 void lago_set_fluid_xpass(int mode) { lago::g_fluid_xpass = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+void lago_fluid_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(lago::g_plan_mu);
+    lago::g_tabs.clear();
+}
+int lago_fluid_cache_entries(void) {
+    std::lock_guard<std::mutex> lk(lago::g_plan_mu);
+    return (int)lago::g_tabs.size();
+}
 #define LAGO_DEFINE(REAL, SUF)                                                                                     \
-    int lago_fluid_metric##SUF(REAL *out, const REAL *m, REAL *work, int inverse, const REAL *cosX,               \
-                               const REAL *sinX, const REAL *cosY, const REAL *sinY, const REAL *cosZ,            \
-                               const REAL *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn,    \
-                               int64_t nx, int64_t ny, int64_t nz, void *stream) {                                \
-        return lago::fluid_metric_impl<REAL>(out, m, work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha,    \
-                                             beta, gamma, dim, nn, nx, ny, nz, stream);                           \
+    int lago_fluid_metric##SUF(REAL *out, const REAL *m, REAL *work, int64_t lut_generation, int inverse,         \
+                               const REAL *cosX, const REAL *sinX, const REAL *cosY, const REAL *sinY,            \
+                               const REAL *cosZ, const REAL *sinZ, double alpha, double beta, double gamma,       \
+                               int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {           \
+        return lago::fluid_metric_impl<REAL>(out, m, work, lut_generation, inverse, cosX, sinX, cosY, sinY, cosZ, \
+                                             sinZ, alpha, beta, gamma, dim, nn, nx, ny, nz, stream);              \
     }
 LAGO_DEFINE(float, _f32)
 LAGO_DEFINE(double, _f64)

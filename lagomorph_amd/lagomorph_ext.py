@@ -53,8 +53,8 @@ _SIGS = {
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_Ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
-    "lago_fluid_metric": [_vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64, _i64,
-                          _i64, _vp],
+    "lago_fluid_metric": [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64,
+                          _i64, _i64, _vp],
 }
 _fn = {}
 for _name, _args in _SIGS.items():
@@ -198,7 +198,10 @@ def interp_backward(grad_out, I, u, dt, need_I, need_u):
         raise RuntimeError("Only two- and three-dimensional interpolation is supported")
     nn = max(u.size(0), I.size(0))
     bc = I.size(0) < nn
-    if tuple(grad_out.shape) != (nn, I.size(1)) + tuple(I.shape[2:]) or u.size(1) != dim or u.size(0) != nn:
+    if (bc and I.size(0) != 1) or u.size(0) != nn:
+        raise RuntimeError("interp_backward: batch sizes of I and u are incompatible")
+    if (tuple(grad_out.shape) != (nn, I.size(1)) + tuple(I.shape[2:]) or u.dim() != I.dim() or u.size(1) != dim
+            or tuple(u.shape[2:]) != tuple(I.shape[2:])):
         raise RuntimeError("interp_backward: grad_out / I / u shapes are inconsistent")
     d_I = torch.empty_like(I)
     d_u = torch.empty_like(u)
@@ -320,9 +323,20 @@ def fluid_operator(Fmv, inverse, cosluts, sinluts, alpha, beta, gamma):
     return None
 
 
-def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma):
+def fluid_cache_clear():
+    """Drop the library's cached per-frequency coefficient tables."""
+    _lib.lago_fluid_cache_clear()
+
+
+def fluid_cache_entries():
+    return int(_lib.lago_fluid_cache_entries())
+
+
+def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma, lut_generation=0):
     """Whole FluidMetricOperator.forward (metric.py:11-19) in one call: irfft(L^(+-2) rfft(mv)).
-    Not part of the reference's extension surface.  Returns a new tensor; mv is not modified."""
+    Not part of the reference's extension surface.  Returns a new tensor; mv is not modified.
+    `lut_generation` names the CONTENTS of the LUTs (see include/lagomorph_hip.h): non-zero lets the
+    library cache its coefficient table under that number; 0 takes the table-free path."""
     _check_input(mv, "mv")
     dim, nx, ny, nz = _spatial(mv)
     if dim not in (2, 3):
@@ -344,7 +358,7 @@ def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma):
     out = torch.empty_like(mv)
     work = torch.empty((mv.size(0), dim, *csh, 2), dtype=mv.dtype, device=mv.device)
     p = [_ptr(t) for t in luts] + [None] * (6 - 2 * dim)
-    _call("lago_fluid_metric", mv, _ptr(out), _ptr(mv), _ptr(work), int(bool(inverse)), *p, float(alpha), float(beta),
+    _call("lago_fluid_metric", mv, _ptr(out), _ptr(mv), _ptr(work), int(lut_generation), int(bool(inverse)), *p, float(alpha), float(beta),
           float(gamma), dim, mv.size(0), nx, ny, nz)
     return out
 

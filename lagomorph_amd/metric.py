@@ -5,6 +5,8 @@ rocFFT through ``torch.fft`` (the reference used ``torch.rfft``/``irfft``,
 removed in torch 1.8; ``rfftn(norm="ortho")`` + ``view_as_real`` is the same
 transform and layout); the per-frequency operator is ``csrc/metric.hip``.
 """
+import itertools
+
 import numpy as np
 import torch
 
@@ -26,7 +28,8 @@ def _apply(mv, inverse, luts, params):
     (hipFFT on caller buffers + csrc/metric.hip, 1/N folded into the kernel); the three-call
     form below is the reference's literal sequence and is what the extension surface exposes."""
     if USE_FUSED_FLUID and hasattr(lagomorph_ext, "fluid_metric"):
-        return lagomorph_ext.fluid_metric(mv.contiguous(), inverse, luts["cos"], luts["sin"], *params)
+        return lagomorph_ext.fluid_metric(mv.contiguous(), inverse, luts["cos"], luts["sin"], *params,
+                                          lut_generation=luts.get("gen", 0))
     sh = mv.shape
     spatial_dim = len(sh) - 2
     Fmv = _rfft(mv.contiguous(), spatial_dim)
@@ -66,7 +69,12 @@ def fluid_luts(spatial_shape, dtype, device):
         s = np.sin(2.0 * np.pi * k / N).astype(np.float32)
         cos.append(torch.from_numpy(c).to(dtype).to(device))
         sin.append(torch.from_numpy(s).to(dtype).to(device))
-    return {"cos": cos, "sin": sin}
+    # "gen" names these LUT contents for the library's coefficient-table cache (include/lagomorph_hip.h):
+    # a fresh number per LUT set, so a later set that lands on recycled device addresses cannot hit a stale table
+    return {"cos": cos, "sin": sin, "gen": next(_LUT_GENERATION)}
+
+
+_LUT_GENERATION = itertools.count(1)
 
 
 class FluidMetric(object):

@@ -20,8 +20,8 @@
 #include <string.h>
 
 /* Contraction switch, see lago_oracle_impl.h. */
-/* Optional OpenMP over the outer voxel loop of the forward kernels that expmap uses (interp,
- * jacobian-times-vectorfield, fluid operator): every voxel is independent there, so the results do
+/* Optional OpenMP over independent work items -- output voxels of the forward kernels (interp,
+ * jacobian-times-vectorfield, fluid operator), batch items of interp_backward -- so the results do
  * not depend on the thread count.  Only bench.py's cpu_baseline leg raises it above 1. */
 static int lg_oracle_threads = 1;
 void oracle_set_threads(int n) { lg_oracle_threads = n > 0 ? n : 1; }
@@ -29,8 +29,10 @@ int oracle_get_threads(void) { return lg_oracle_threads; }
 #ifdef _OPENMP
 #define LG_PRAGMA(x) _Pragma(#x)
 #define LG_PARALLEL_FOR LG_PRAGMA(omp parallel for schedule(static) num_threads(lg_oracle_threads) if (lg_oracle_threads > 1))
+#define LG_PARALLEL_FOR_IF(cond) LG_PRAGMA(omp parallel for schedule(dynamic, 1) num_threads(lg_oracle_threads) if (lg_oracle_threads > 1 && (cond)))
 #else
 #define LG_PARALLEL_FOR
+#define LG_PARALLEL_FOR_IF(cond)
 #endif
 
 #ifdef LAGO_ORACLE_STRICT

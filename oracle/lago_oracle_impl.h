@@ -186,31 +186,29 @@ int FN(oracle_interp_forward)(REAL *out, const REAL *I, const REAL *u, double dt
     if (dim != 2 && dim != 3) return -1;
     if (dim == 2) nz = 1;
     const size_t nvox = (size_t)nx * ny * nz;
-    for (long n = 0; n < nn; ++n) {
+    /* every output voxel is independent: (n, c, i) flattened into one loop so that OpenMP (bench.py's
+     * cpu_baseline leg only) has nn*nc*nx work items */
+    LG_PARALLEL_FOR
+    for (long t = 0; t < nn * nc * nx; ++t) {
+        const long n = t / (nc * nx), c = (t / nx) % nc, i = t % nx;
         const REAL *un = u + (size_t)n * dim * nvox;
-        const REAL *In = broadcast_I ? I : I + (size_t)n * nc * nvox;
-        REAL *on = out + (size_t)n * nc * nvox;
-        for (long c = 0; c < nc; ++c) {
-            const REAL *Ic = In + (size_t)c * nvox;
-            REAL *oc = on + (size_t)c * nvox;
-            LG_PARALLEL_FOR
-            for (long i = 0; i < nx; ++i)
-                for (long j = 0; j < ny; ++j) {
-                    if (dim == 2) {
-                        size_t ix = (size_t)i * ny + j;
-                        double hx = LG_FMAD(dt, (double)un[ix], (double)(REAL)i);
-                        double hy = LG_FMAD(dt, (double)un[ix + nvox], (double)(REAL)j);
-                        oc[ix] = FN(lg_bilerp)(Ic, (REAL)hx, (REAL)hy, nx, ny);
-                    } else {
-                        for (long k = 0; k < nz; ++k) {
-                            size_t ix = ((size_t)i * ny + j) * nz + k;
-                            double hx = LG_FMAD(dt, (double)un[ix], (double)(REAL)i);
-                            double hy = LG_FMAD(dt, (double)un[ix + nvox], (double)(REAL)j);
-                            double hz = LG_FMAD(dt, (double)un[ix + 2 * nvox], (double)(REAL)k);
-                            oc[ix] = FN(lg_trilerp)(Ic, (REAL)hx, (REAL)hy, (REAL)hz, nx, ny, nz);
-                        }
-                    }
+        const REAL *Ic = (broadcast_I ? I : I + (size_t)n * nc * nvox) + (size_t)c * nvox;
+        REAL *oc = out + (size_t)n * nc * nvox + (size_t)c * nvox;
+        for (long j = 0; j < ny; ++j) {
+            if (dim == 2) {
+                size_t ix = (size_t)i * ny + j;
+                double hx = LG_FMAD(dt, (double)un[ix], (double)(REAL)i);
+                double hy = LG_FMAD(dt, (double)un[ix + nvox], (double)(REAL)j);
+                oc[ix] = FN(lg_bilerp)(Ic, (REAL)hx, (REAL)hy, nx, ny);
+            } else {
+                for (long k = 0; k < nz; ++k) {
+                    size_t ix = ((size_t)i * ny + j) * nz + k;
+                    double hx = LG_FMAD(dt, (double)un[ix], (double)(REAL)i);
+                    double hy = LG_FMAD(dt, (double)un[ix + nvox], (double)(REAL)j);
+                    double hz = LG_FMAD(dt, (double)un[ix + 2 * nvox], (double)(REAL)k);
+                    oc[ix] = FN(lg_trilerp)(Ic, (REAL)hx, (REAL)hy, (REAL)hz, nx, ny, nz);
                 }
+            }
         }
     }
     return 0;
@@ -227,6 +225,9 @@ int FN(oracle_interp_backward)(REAL *d_I, REAL *d_u, const REAL *go, const REAL 
     const size_t nI = (broadcast_I ? 1 : (size_t)nn) * nc * nvox;
     memset(d_I, 0, nI * sizeof(REAL));
     memset(d_u, 0, (size_t)nn * dim * nvox * sizeof(REAL));
+    /* a batch item owns its d_u, and its d_I unless I is broadcast: OpenMP over n (cpu_baseline leg only)
+     * leaves every sum in the sequential order */
+    LG_PARALLEL_FOR_IF(!broadcast_I || !need_I)
     for (long n = 0; n < nn; ++n) {
         const REAL *un = u + (size_t)n * dim * nvox;
         REAL *dun = d_u + (size_t)n * dim * nvox;
@@ -334,12 +335,13 @@ int FN(oracle_jtv_forward)(REAL *out, const REAL *v, const REAL *w, int displace
     if (dim == 2) nz = 1;
     if ((displacement || transpose) && nc != dim) return -1;
     const size_t nvox = (size_t)nx * ny * nz;
-    for (long n = 0; n < nn; ++n) {
+    LG_PARALLEL_FOR
+    for (long t = 0; t < nn * nx; ++t) {
+        const long n = t / nx, i = t % nx;
         const REAL *vn = v + (size_t)n * nc * nvox;
         const REAL *wn = w + (size_t)n * dim * nvox;
         REAL *on = out + (size_t)n * nc * nvox;
-        LG_PARALLEL_FOR
-        for (long i = 0; i < nx; ++i)
+        {
             for (long j = 0; j < ny; ++j)
                 for (long k = 0; k < nz; ++k) {
                     REAL g[3];
@@ -367,6 +369,7 @@ int FN(oracle_jtv_forward)(REAL *out, const REAL *v, const REAL *w, int displace
                         }
                     }
                 }
+        }
     }
     return 0;
 }

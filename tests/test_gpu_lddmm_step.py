@@ -1,0 +1,164 @@
+"""lddmm_step / LDDMMAtlasBuilder through the HIP kernels against the same run on the oracle backend
+(reference: lddmm.py:300-325 and :327-362), float32 and float64, same-grid and multiscale momenta
+(`momentum_shape` != image shape, lddmm.py:306-312), plus size-independent checks at the configs[4] volume
+(160^3): float32 against float64 through independent kernel instantiations and FFT paths, and the
+directional derivative of the matching loss against the gradient the backward kernels return."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ORACLE_NAMES = ("interp_forward", "interp_backward", "compose", "jacobian_times_vectorfield_forward",
+                "jacobian_times_vectorfield_backward", "jacobian_times_vectorfield_adjoint_forward",
+                "jacobian_times_vectorfield_adjoint_backward", "fluid_operator", "regrid_forward", "regrid_backward")
+
+
+class oracle_backend:
+    """Stand the CPU oracle in for lagomorph_ext inside a `with` block (tests only)."""
+
+    def __enter__(self):
+        import lagomorph_amd as lm
+        from oracle.lago_oracle import OracleExt
+
+        self.lm, self.saved, self.removed = lm, {}, {}
+        o = OracleExt()
+        for n in ORACLE_NAMES:
+            self.saved[n] = getattr(lm.lagomorph_ext, n)
+            setattr(lm.lagomorph_ext, n, getattr(o, n))
+        for n in ("fluid_metric", "Ad_star", "ad_star"):
+            self.removed[n] = getattr(lm.lagomorph_ext, n)
+            delattr(lm.lagomorph_ext, n)
+        return lm
+
+    def __exit__(self, *exc):
+        for n, f in {**self.saved, **self.removed}.items():
+            setattr(self.lm.lagomorph_ext, n, f)
+
+
+def smooth_np(rng, shape, sigma):
+    from scipy.ndimage import gaussian_filter
+
+    x = rng.standard_normal(shape)
+    ax = tuple(range(2, len(shape)))
+    return gaussian_filter(x, sigma=[0, 0] + [sigma] * len(ax), mode="wrap")
+
+
+def make_problem(sp, msp, dtype, seed):
+    rng = np.random.default_rng(seed)
+    d = len(sp)
+    base = smooth_np(rng, (1, 1) + sp, 1.5)
+    base /= base.std()
+    imgs = base + 0.2 * smooth_np(rng, (2, 1) + sp, 1.0)
+    m = smooth_np(rng, (2, d) + msp, 1.5)
+    return (torch.from_numpy(base).to(dtype), torch.from_numpy(imgs).to(dtype), torch.from_numpy(m).to(dtype))
+
+
+def scale_momenta(lm, m, vox):
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    return m * (vox / met.sharp(m).abs().max())
+
+
+CASES = [((20, 24, 28), (20, 24, 28)), ((20, 24, 28), (10, 12, 16)), ((40, 36), (40, 36)), ((40, 36), (18, 20))]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("sp,msp", CASES)
+def test_lddmm_step_hip_equals_oracle_backend(sp, msp, dtype, tol):
+    """One matching step: loss, regularisation term, updated momenta and atlas gradient.  The float32 bound is
+    loose on purpose: the step chains ~40 kernels, half of them scatter-adds whose summation order differs."""
+    import lagomorph_amd as lm
+
+    base, imgs, m = make_problem(sp, msp, dtype, 3)
+    with oracle_backend() as lmo:
+        m = scale_momenta(lmo, m, 1.5).contiguous()
+        Ic = base.clone().requires_grad_(True)
+        mc, lc, rc = lmo.lddmm_step(Ic, m.clone(), imgs, lmo.FluidMetric([0.1, 0.0, 0.01]), 2, integration_steps=3,
+                                    reg_weight=1e-2, learning_rate_pose=1e-3)
+    lm.set_debug_mode(True)
+    try:
+        Ig = base.cuda().requires_grad_(True)
+        mg, lg, rg = lm.lddmm_step(Ig, m.clone().cuda(), imgs.cuda(), lm.FluidMetric([0.1, 0.0, 0.01]), 2,
+                                   integration_steps=3, reg_weight=1e-2, learning_rate_pose=1e-3)
+    finally:
+        lm.set_debug_mode(False)
+
+    def rel(a, b):
+        return float((a.cpu().double() - b.double()).abs().max() / b.double().abs().max())
+
+    errs = {"loss": rel(lg, lc), "reg": rel(rg, rc), "m": rel(mg, mc), "I.grad": rel(Ig.grad, Ic.grad)}
+    assert all(e <= tol for e in errs.values()), errs
+    assert float((mg.cpu() - m).abs().max()) > 0  # the step moved the momenta
+
+
+@pytest.mark.parametrize("sp,msp", [((16, 18, 20), (16, 18, 20)), ((16, 18, 20), (8, 10, 12))])
+def test_atlas_builder_two_epochs_hip_equals_oracle_backend(sp, msp):
+    """Two epochs of LDDMMAtlasBuilder (float64, 4 subjects in 2 minibatches, lddmm_steps = 2)."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(11)
+    data = torch.from_numpy(smooth_np(rng, (1, 1) + sp, 1.5) + 0.3 * smooth_np(rng, (4, 1) + sp, 1.0))
+    kw = dict(batch_size=2, lddmm_steps=2, lddmm_integration_steps=2, reg_weight=1e-1, learning_rate_pose=2e-6,
+              learning_rate_image=5e-2, momentum_shape=msp)
+    with oracle_backend() as lmo:
+        bc = lmo.LDDMMAtlasBuilder(data, **kw)
+        bc.run(num_epochs=2)
+    bg = lm.LDDMMAtlasBuilder(data.cuda(), **kw)
+    bg.run(num_epochs=2)
+    assert bg.iter_losses == pytest.approx(bc.iter_losses, rel=1e-9)
+    assert bg.epoch_reg_terms == pytest.approx(bc.epoch_reg_terms, rel=1e-9, abs=1e-14)
+    assert torch.allclose(bg.I.detach().cpu(), bc.I.detach(), rtol=0, atol=1e-10)
+    for a, b in zip(bg.ms, bc.ms):
+        assert torch.allclose(a.cpu(), b, rtol=0, atol=1e-10 * max(1.0, float(b.abs().max())))
+
+
+def _smooth_cuda(shape, sigma, g):
+    import bench
+
+    return bench.gaussian_blur(torch.randn(shape, device="cuda", generator=g), sigma)
+
+
+def test_lddmm_step_160cubed_float32_vs_float64_and_directional_derivative():
+    """BASELINE configs[4] volume.  (1) float32 (own FFT passes where they apply, f32 gathers / splats) against
+    float64 (rocFFT, f64 kernels) on the same inputs: loss to 1e-5, gradients to 2e-4 of their maximum.
+    (2) d/de loss(m + e*d) at e = 0 by central differences in float64 equals <grad_m, d>."""
+    import lagomorph_amd as lm
+
+    S = 160
+    g = torch.Generator(device="cuda").manual_seed(21)
+    base = _smooth_cuda((1, 1, S, S, S), 3.0, g)
+    base = base / base.std()
+    imgs = base + 0.2 * _smooth_cuda((1, 1, S, S, S), 2.0, g)
+    m = _smooth_cuda((1, 3, S, S, S), 4.0, g)
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    m = (m * (2.0 / met.sharp(m).abs().max())).contiguous()
+    d = _smooth_cuda((1, 3, S, S, S), 4.0, g)
+    d = d * (m.abs().max() / d.abs().max())
+
+    def loss_and_grads(dtype, mm):
+        I = base.to(dtype).requires_grad_(True)
+        mm = mm.to(dtype).clone().requires_grad_(True)
+        metd = lm.FluidMetric([0.1, 0.0, 0.01])
+        h = lm.expmap(metd, mm, num_steps=5)
+        Idef = lm.interp(I, h)
+        v = metd.sharp(mm)
+        reg = 1e2 * (v * mm).sum() / imgs.numel()
+        loss = ((Idef - imgs.to(dtype)) ** 2).sum() / imgs.numel() + reg
+        loss.backward()
+        return loss.detach(), mm.grad, I.grad
+
+    l32, gm32, gI32 = loss_and_grads(torch.float32, m)
+    l64, gm64, gI64 = loss_and_grads(torch.float64, m)
+    assert abs(l32.item() - l64.item()) <= 1e-5 * abs(l64.item())
+    em = float((gm32.double() - gm64).abs().max() / gm64.abs().max())
+    eI = float((gI32.double() - gI64).abs().max() / gI64.abs().max())
+    assert em <= 2e-4 and eI <= 2e-4, (em, eI)
+    del gm32, gI32, gI64
+    eps = 1e-3
+    with torch.no_grad():
+        pass
+    lp, _, _ = loss_and_grads(torch.float64, m.double() + eps * d.double())
+    ln, _, _ = loss_and_grads(torch.float64, m.double() - eps * d.double())
+    fd = (lp.item() - ln.item()) / (2 * eps)
+    an = float((gm64 * d.double()).sum())
+    assert abs(fd - an) <= 2e-5 * max(abs(an), abs(fd)), (fd, an)

@@ -118,7 +118,7 @@ def test_tiled_splat_any_tile_config(ext, dtype, tile):
         try:
             dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 1.0, True, True)
         finally:
-            ext.set_splat_tile(16, 8, 64, 1, 1, 4, 1024)
+            ext.set_splat_tile(0, 8, 0, 1, 1, 4, 512)  # the library default
             ext.set_splat_mode(1)
         assert_bits(du, ou, f"d_u mode {mode}")
         assert_close(dI, oI, dtype, f"d_I mode {mode}", mult=4.0)
@@ -599,3 +599,49 @@ def test_fused_small_ad_star_bit_exact(ext, dtype, sp):
         finally:
             adjrep.USE_FUSED_AD_STAR = True
     assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
+
+
+def test_coefficient_table_cache_is_keyed_on_lut_contents(ext):
+    """The cached per-frequency coefficient table of the float32 fast paths is keyed on the LUT generation
+    (contents), the real extents and the parameters -- not on LUT addresses.  New FluidMetric objects per
+    shape, (64, 20, 30) then (64, 20, 31): same nx, ny and the same half-spectrum length nz/2 + 1 = 16, so
+    a key without nz would hand the second shape the first shape's table (and torch's caching allocator
+    readily returns the freed LUT blocks of the first metric to the second)."""
+    import gc
+
+    import lagomorph_amd as lm
+
+    ext.fluid_cache_clear()
+    rng = np.random.default_rng(31)
+    for sp in ((64, 20, 30), (64, 20, 31), (64, 20, 30), (128, 64, 128), (128, 64, 128)):
+        m = rnd(rng, (2, 3) + sp, torch.float32)
+        met = lm.FluidMetric([0.1, 0.05, 0.01])  # a fresh metric: fresh LUT tensors, possibly at recycled addresses
+        for inv, f in ((True, met.sharp), (False, met.flat)):
+            assert_close(f(dev(m)), orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inv), torch.float32,
+                         f"sharp/flat {sp} inverse={inv}", mult=10.0)
+        del met
+        gc.collect()
+        torch.cuda.empty_cache()
+    assert ext.fluid_cache_entries() >= 2
+    # generation 0 = "do not cache": the table-free path, same answer
+    sp = (64, 20, 30)
+    m = rnd(rng, (1, 3) + sp, torch.float32)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    met.initialize_luts((1, 3) + sp, torch.float32, "cuda")
+    n0 = ext.fluid_cache_entries()
+    got = ext.fluid_metric(dev(m), True, met.luts["cos"], met.luts["sin"], 0.1, 0.05, 0.01, lut_generation=0)
+    assert ext.fluid_cache_entries() == n0
+    assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "uncached", mult=10.0)
+    ext.fluid_cache_clear()
+    assert ext.fluid_cache_entries() == 0
+
+
+def test_interp_backward_rejects_bad_broadcast(ext):
+    """interp_backward mirrors interp_forward's argument checks (1 < I.size(0) < u.size(0) is not a broadcast)."""
+    I = torch.zeros((2, 1, 4, 4, 4), device="cuda")
+    u = torch.zeros((3, 3, 4, 4, 4), device="cuda")
+    go = torch.zeros((3, 1, 4, 4, 4), device="cuda")
+    with pytest.raises(RuntimeError, match="batch sizes"):
+        ext.interp_backward(go, I, u, 1.0, True, True)
+    with pytest.raises(RuntimeError, match="inconsistent"):
+        ext.interp_backward(go, I[:1], torch.zeros((3, 3, 4, 4, 5), device="cuda"), 1.0, True, True)
