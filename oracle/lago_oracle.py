@@ -184,6 +184,19 @@ def fluid_operator(Fmv, inverse, cosluts, sinluts, alpha, beta, gamma):
     return None
 
 
+def interp_points(img, pts):
+    """bilinear / trilinear value and gradient of one image (sx, sy[, sz]) at points (npts, dim)."""
+    img = _c(img)
+    pts = _c(pts, img.dtype)
+    dim = img.ndim
+    sh = list(img.shape) + [1] * (3 - dim)
+    lerp = np.empty((pts.shape[0],), dtype=img.dtype)
+    grad = np.empty((pts.shape[0], dim), dtype=img.dtype)
+    _call("oracle_interp_points", img.dtype, _p(lerp), _p(grad), _p(img), _p(pts), c_long(pts.shape[0]), c_int(dim),
+          c_long(sh[0]), c_long(sh[1]), c_long(sh[2]))
+    return lerp, grad
+
+
 def affine_interp_forward(I, A, T, cpuref=False):
     I = _c(I)
     A, T = _c(A, I.dtype), _c(T, I.dtype)

@@ -177,6 +177,25 @@ static void FN(lg_splat3)(REAL *d, REAL mass, REAL x, REAL y, REAL z, long w, lo
     }
 }
 
+/* The interpolation cores at caller-given points (test hook: pinned value by value against the
+ * reference's own biLerp / triLerp / *_grad of include/interp.h compiled into oracle/_ref).
+ * pts: (npts, dim); lerp: (npts); grad: (npts, dim). */
+int FN(oracle_interp_points)(REAL *lerp, REAL *grad, const REAL *img, const REAL *pts, long npts, int dim, long sx,
+                             long sy, long sz) {
+    if (dim != 2 && dim != 3) return -1;
+    for (long q = 0; q < npts; ++q) {
+        if (dim == 2) {
+            lerp[q] = FN(lg_bilerp)(img, pts[2 * q], pts[2 * q + 1], sx, sy);
+            FN(lg_bilerp_grad)(&grad[2 * q], &grad[2 * q + 1], img, pts[2 * q], pts[2 * q + 1], sx, sy);
+        } else {
+            lerp[q] = FN(lg_trilerp)(img, pts[3 * q], pts[3 * q + 1], pts[3 * q + 2], sx, sy, sz);
+            FN(lg_trilerp_grad)(&grad[3 * q], &grad[3 * q + 1], &grad[3 * q + 2], img, pts[3 * q], pts[3 * q + 1],
+                                pts[3 * q + 2], sx, sy, sz);
+        }
+    }
+    return 0;
+}
+
 /* ---- interp forward / backward -------------------------------------------- */
 
 /* cuda/interp.cu:16-78 (kernels), :80-130 (host).  Position = fi + dt*u in

@@ -1,7 +1,10 @@
 """CPU: the strict (unfused) oracle build is bit-identical to oracle/_ref, the reference's own
-cpu/affine.cpp compiled from /root/reference where it lies (BASELINE configs[0] included).  This
-pins the floor rule, clamp and lerp expression order of the oracle's interpolation core to real
-reference code.  Skipped when oracle/_ref has not been built (it needs /root/reference)."""
+cpu/affine.cpp compiled from /root/reference where it lies (BASELINE configs[0] included), and to the
+reference's own biLerp / triLerp / biLerp_grad / triLerp_grad (include/interp.h, compiled into the same
+module) at random points -- negative, far out of range, exactly integer, exactly on the border, 2D and
+3D, float32 and float64.  This pins the floor rule, clamp, lerp and gradient expression order of the
+oracle's interpolation core (rows a1, a2 d_u, a9, a10 of SURVEY section 8) value by value to real reference
+code.  Skipped when oracle/_ref has not been built (it needs /root/reference)."""
 import numpy as np
 import pytest
 import torch
@@ -59,3 +62,44 @@ def test_identity_transform_is_exact():
     T = np.zeros((2, 3))
     want = ref.affine_interp_cpu_forward(torch.from_numpy(I), torch.from_numpy(A), torch.from_numpy(T)).numpy()
     assert np.array_equal(want, I) and np.array_equal(orc.affine_interp_forward(I, A, T), I)
+
+
+def _points(rng, sh, n, dtype):
+    d = len(sh)
+    p = rng.uniform(-3.0, np.array(sh) + 2.0, size=(n, d))
+    p[::7] = np.round(p[::7])                       # exactly integer: weights exactly 0 / 1, gradient one-sided
+    p[::11] = rng.uniform(-40.0, 40.0, size=p[::11].shape)  # far outside: clamp on both corners
+    p[::13, 0] = sh[0] - 1                          # exactly on the upper border
+    p[::17] = -np.abs(p[::17]) - 0.25               # negative non-integers: the floor rule (int)x - 1
+    p[5] = 0.0
+    p[6] = -0.0
+    return p.astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("sh", [(7, 9), (2, 2), (5, 1), (5, 6, 7), (2, 2, 2), (9, 5, 1), (3, 4, 33)])
+def test_interp_cores_bit_exact_against_reference_header(dtype, sh):
+    """include/interp.h:9-122 (biLerp, triLerp) and :128-327 (biLerp_grad, triLerp_grad), CLAMP background."""
+    rng = np.random.default_rng(len(sh) * 1000 + sum(sh))
+    img = rng.standard_normal(sh).astype(dtype)
+    pts = _points(rng, sh, 4000, dtype)
+    lerp_ref, grad_ref = (t.numpy() for t in ref.interp_points(torch.from_numpy(img), torch.from_numpy(pts)))
+    lerp, grad = orc.interp_points(img, pts)
+    assert np.array_equal(lerp, lerp_ref), np.abs(lerp - lerp_ref).max()
+    assert np.array_equal(grad, grad_ref[:, 1:]), np.abs(grad - grad_ref[:, 1:]).max()
+    # the value the *_grad functions return alongside (Ix) is the same interpolant up to association order
+    assert np.allclose(grad_ref[:, 0], lerp_ref, rtol=0, atol=(1e-5 if dtype == np.float32 else 1e-13) * np.abs(img).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_interp_forward_through_reference_cores(dtype):
+    """interp_forward of the oracle at dt = 1 equals the reference's triLerp evaluated at i + u (positions formed
+    as the kernel forms them, cuda/interp.cu:68-70: double sum narrowed to Real)."""
+    rng = np.random.default_rng(5)
+    sh = (6, 7, 8)
+    I = rng.standard_normal((1, 1) + sh).astype(dtype)
+    u = (3.0 * rng.standard_normal((1, 3) + sh)).astype(dtype)
+    ii = np.stack(np.meshgrid(*[np.arange(s) for s in sh], indexing="ij")).astype(dtype)
+    pos = (ii.astype(np.float64) + 1.0 * u[0].astype(np.float64)).astype(dtype).reshape(3, -1).T.copy()
+    want = ref.interp_points(torch.from_numpy(I[0, 0].copy()), torch.from_numpy(pos))[0].numpy().reshape(sh)
+    assert np.array_equal(orc.interp_forward(I, u, 1.0)[0, 0], want)
