@@ -213,6 +213,13 @@ __device__ __forceinline__ void buf_load2<float>(BufRsrc r, uint32_t off, float 
     lo = __builtin_bit_cast(float, (unsigned int)q);
     hi = __builtin_bit_cast(float, (unsigned int)(q >> 32));
 }
+// the same with an extra wave-uniform byte offset in the instruction's scalar-offset field
+__device__ __forceinline__ void buf_load2s(BufRsrc r, uint32_t off, uint32_t soff, float &lo, float &hi) {
+    const lg_u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0);
+    const unsigned long long q = __builtin_bit_cast(unsigned long long, p);
+    lo = __builtin_bit_cast(float, (unsigned int)q);
+    hi = __builtin_bit_cast(float, (unsigned int)(q >> 32));
+}
 struct lg_u64x2 {
     unsigned long long a, b;
 };

@@ -125,7 +125,8 @@ def test_option_b_module_equals_ctypes_shim(optb, dtype, sp):
         ext.fluid_operator(F2, True, met.luts["cos"], met.luts["sin"], 0.1, 0.05, 0.01)
         assert torch.equal(F1, F2)
         if d == 2:
-            assert torch.equal(optb.interp_hessian_diagonal_image(I, u, 1.0), ext.interp_hessian_diagonal_image(I, u, 1.0))
+            a, b = optb.interp_hessian_diagonal_image(I, u, 1.0), ext.interp_hessian_diagonal_image(I, u, 1.0)
+            assert torch.allclose(a, b, rtol=0, atol=1e-5 * float(b.abs().max()))  # atomic accumulation order
     finally:
         optb.set_debug_mode(False)
         lm.set_debug_mode(False)

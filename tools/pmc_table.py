@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""Average PMC counter values per kernel from rocprofv3 counter_collection.csv files.
-usage: tools/pmc_table.py <csv> [<csv> ...]  (kernels filtered to lago::*)"""
-import csv, re, sys
-from collections import defaultdict
-acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+"""Condense a rocprofv3 --pmc counter_collection CSV: per kernel dispatch (in order) one row of counters."""
+import csv
+import sys
+from collections import OrderedDict
+
+rows = OrderedDict()
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        k = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"]))
-        if not k.startswith("lago::"):
-            continue
-        a = acc[k][r["Counter_Name"]]
-        a[0] += float(r["Counter_Value"]); a[1] += 1
-for k, cs in acc.items():
-    print(k)
-    print("   " + "  ".join(f"{c}={v[0]/v[1]:.4g}" for c, v in sorted(cs.items())))
+        key = (int(r["Dispatch_Id"]), r["Kernel_Name"][:70])
+        rows.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
+names = sorted({c for v in rows.values() for c in v})
+print("dispatch | kernel | " + " | ".join(names))
+for (d, k), v in rows.items():
+    if "lago::" not in k:
+        continue
+    print(f"{d} | {k} | " + " | ".join(f"{v.get(c, float('nan')):.4g}" for c in names))
