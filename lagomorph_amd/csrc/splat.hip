@@ -353,202 +353,117 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row-mapped splat for float32 displacement fields (interp_backward, 3D) -- the hot form.
+// Sheared-window splat for float32 displacement fields (interp_backward, 3D) -- the hot form.
 //
-// Same tile / window / flush scheme as splat_tiled_kernel above, re-derived around the instruction
-// budget: SQ counters on the kernel above showed the VALU busy about half of the kernel time at ~250
-// vector instructions per voxel-channel, a third of them quarter-rate (32-bit integer multiplies,
-// 64-bit address arithmetic, float64 converts), so the instruction count -- not HBM -- set its speed.
-// Here
-//   * a wave owns a 64-voxel chunk of ONE source row: (i, j) and every row base offset are
-//     wave-uniform and live in SGPRs; the per-lane part of every streamed address is lane*4;
-//   * streamed operands (u, grad_out, d_u) go through buffer descriptors with the row offset in the
-//     scalar offset field: no vector address arithmetic at all;
-//   * the fast path (2x2x2 footprint inside the LDS window, hence inside the grid and unclamped)
-//     computes ONE window address and ONE gather offset with 24-bit multiply-adds (full rate);
-//     the four gather rows are reached through the scalar offset of the buffer load;
-//   * anything else takes the general corner-by-corner path (clamps, global-atomic fallback).
-// Arithmetic (positions, sequentially flipped weights, gradient expressions) is unchanged, so d_u is
-// bit-identical and d_I differs from the kernel above only through the order of the float64 window adds.
-struct RowGeom {
+// What the experiments of round 2 showed (profiles/r02_splat_experiments.md, tools/probes/splat_floor.hip,
+// splat_stages.hip): the bare scheme "tile -> float64 LDS window -> atomic flush" runs the 8 x 128^3 case in
+// 56 us at 1024 threads per workgroup, 73 us at 512; positions + weights bring it to 85 us; the kernel above
+// needs 230 us because (1) a window placed once per 4 x 8 x nz tile loses the footprints of ~10 % of the voxels
+// of a smooth field -- the displacement drifts by +-2 voxels along a 128-voxel row, and every row end needs a
+// clamp -- and each lost corner becomes a lone global atomic: they cost 2-3 times the atomic requests of the whole
+// flush; (2) its 4-voxels-per-lane unrolling needs ~90 VGPRs, which caps a CU at 16 waves.
+// Hence here:
+//  * the window is SHEARED along z: every 16-cell z segment of the window has its own (x, y) origin, the
+//    displacement probed at the tile's centre column at that height.  A margin of one cell then holds all but
+//    ~0.3 % of the footprints of a smooth field (10 % with one origin per tile);
+//  * the window may reach one cell beyond the grid in x and y and the flush folds those cells onto the border
+//    (what the reference's clamp does), z cells are clamped when they are added: a row end or a face of the
+//    volume is no special case;
+//  * one voxel per lane per pass of a rolled loop, 1024 threads, under 64 VGPRs: 32 waves per CU;
+//  * what still misses the window takes the reference's clamped global atomics, corner by corner.
+// Arithmetic (positions, sequentially flipped weights, gradient expressions) is that of the kernel above, so d_u
+// is bit-identical and d_I differs only through the order of the float64 window adds.
+struct ShearGeom {
     int nx, ny, nz;
-    int TX, TY, CZ;        // tile: TX x TY rows of CZ 64-voxel chunks
-    int WX, WY, WZ;        // LDS window (cells)
+    int TX, TY, TZ;        // source tile
+    int WX, WY, WZ;        // window cells; x / y in virtual coordinates [-1, n], z inside the grid
     int MX, MY, MZ;
-    uint32_t ntx, nty, ntz, tiles_per_item, total, chunks_per_tile, win_cells, qcap;
-    FastDiv d_tiles, d_tyz, d_tz, d_tycz, d_cz, d_wey;
-    uint32_t chunks_per_tile_max() const { return (uint32_t)TX * TY * CZ; }
-    int abl;  // diagnostics (tools/ablate_rows.py): bit0 no LDS adds, bit1 no flush atomics, bit2 no window zeroing,
-              // bit3 no u / grad_out loads, bit4 no origin probe, bit5 no flush pass at all.  0 in production.
+    int nseg;              // 16-cell z segments of the window
+    uint32_t ntx, nty, ntz, tiles_per_item, total, tile_vox, win_cells;
+    FastDiv d_tiles, d_tyz, d_tz, d_TyTz, d_Tz, d_wy;
 };
 
 template <bool UNIT>
-__device__ __forceinline__ float row_pos(float base, double dt, float u) {
-    if (UNIT) return __builtin_fmaf((float)dt, u, base);  // one rounding of the exact sum (common.hpp: sample_pos_t)
+__device__ __forceinline__ float shear_pos(int base, double dt, float u) {
+    if (UNIT) return __builtin_fmaf((float)dt, u, (float)base);  // one rounding of the exact sum (common.hpp: sample_pos_t)
     return (float)__builtin_fma(dt, (double)u, (double)base);
 }
 
-template <int NT, bool NEED_U, bool UNIT, bool BC, int VPL>
-__global__ __launch_bounds__(NT) void splat_rows_kernel(float *__restrict__ d_I, float *__restrict__ d_u,
-                                                        const float *__restrict__ go, const float *__restrict__ I,
-                                                        const float *__restrict__ u, double dt, int nc, RowGeom rg) {
-    // Persistent workgroups: each walks a strip of tiles (consecutive tiles of one XCD's share), so that
-    //  * the window is zeroed once and re-zeroed by the flush itself (no separate pass, one barrier less),
-    //  * the next tile's u / grad_out rows are requested BEFORE the flush of the current tile and are in
-    //    registers when the next iteration starts: the HBM round trip hides behind the flush and its barrier,
-    //  * workgroup start-up (kernel arguments, descriptors) is paid once per strip instead of once per tile.
-    // VPL = row chunks a wave holds at a time = chunks_per_tile / (NT / 64): the whole tile in one pass.
+// (<= 80 SGPRs and <= 64 VGPRs: two 1024-thread workgroups per CU, 32 waves; at 81+ SGPRs the CU admits only one)
+template <int NT, bool NEED_U, bool UNIT, bool BC>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat_shear_kernel(float *__restrict__ d_I, float *__restrict__ d_u,
+                                                         const float *__restrict__ go, const float *__restrict__ I,
+                                                         const float *__restrict__ u, double dt, int nc, ShearGeom sg) {
     extern __shared__ __align__(16) unsigned char lago_smem[];
     double *win = reinterpret_cast<double *>(lago_smem);
-    const int nx = rg.nx, ny = rg.ny, nz = rg.nz;
+    int2 *org = reinterpret_cast<int2 *>(lago_smem + (size_t)sg.win_cells * 8);  // (x, y) origin per z segment
+    const int nx = sg.nx, ny = sg.ny, nz = sg.nz;
     const uint32_t nv = (uint32_t)nx * ny * nz;
     const uint32_t planeB = nv * 4u;
-    const uint32_t WY = rg.WY, WZ = rg.WZ;
-    const uint32_t sxB = WY * WZ * 8u, syB = WZ * 8u;            // window strides in bytes (uniform)
-    const uint32_t gxB = (uint32_t)ny * nz * 4u, gyB = (uint32_t)nz * 4u;  // grid strides in bytes (uniform)
-    const int wex = min(rg.WX, nx), wey = min(rg.WY, ny), wez = min(rg.WZ, nz);
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t lane4 = (uint32_t)lane * 4u;
-    constexpr uint32_t NW = NT / 64;
 
-    // strip of this workgroup: XCD x (= blockIdx % 8 under round-robin placement; speed only) owns the tiles
-    // [x*q, (x+1)*q) of the (batch item, channel-independent) tile order, its workgroups interleave inside it
-    const uint32_t nwg = gridDim.x, total = rg.total;
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per = (total + 7u) >> 3, wgs = (nwg + 7u - xcd) >> 3;
-    const uint32_t Tend = min(total, (xcd + 1u) * per);
-    uint32_t T = xcd * per + slot;
+    // workgroup -> (batch item, tile)
+    const uint32_t L = xcd_swizzle(blockIdx.x, sg.total);
+    const uint32_t n = sg.d_tiles.div(L);
+    uint32_t r = L - n * sg.tiles_per_item;
+    const uint32_t bx = sg.d_tyz.div(r);
+    r -= bx * (sg.nty * sg.ntz);
+    const uint32_t by = sg.d_tz.div(r);
+    const uint32_t bz = r - by * sg.ntz;
+    const int x0 = bx * sg.TX, y0 = by * sg.TY, z0 = bz * sg.TZ;
+    const int ex = min(sg.TX, nx - x0), ey = min(sg.TY, ny - y0), ez = min(sg.TZ, nz - z0);
 
-    // chunk e of this wave inside a tile: rc = wave + e*NW -> (a, b, q), identical for every tile
-    int ca[VPL], cb[VPL], cq[VPL];
-#pragma unroll
-    for (int e = 0; e < VPL; ++e) {
-        const uint32_t rc = wave + (uint32_t)e * NW;
-        const uint32_t a = rg.d_tycz.div(rc);
-        const uint32_t rr = rc - a * (uint32_t)(rg.TY * rg.CZ);
-        const uint32_t b = rg.d_cz.div(rr);
-        ca[e] = rc < rg.chunks_per_tile ? (int)a : 1 << 20;   // beyond the tile: never inside ex
-        cb[e] = (int)b;
-        cq[e] = (int)(rr - b * (uint32_t)rg.CZ);
+    const float *un = u + (size_t)n * 3 * nv;
+    const float *In = BC ? I : I + (size_t)n * nc * nv;
+    float *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
+    const float *gon = go + (size_t)n * nc * nv;
+    float *dun = NEED_U ? d_u + (size_t)n * 3 * nv : nullptr;
+
+    const int WX = sg.WX, WY = sg.WY, WZ = sg.WZ;
+    const int wez = min(WZ, nz);
+    // window z range: 16-aligned start (flush rows start on 64-byte boundaries), inside the grid
+    const int cxs = x0 + ex / 2, cys = y0 + ey / 2;
+    int wz0;
+    {
+        const float fdt = (float)dt;
+        const size_t sc = ((size_t)cxs * ny + cys) * nz + (z0 + ez / 2);
+        const int bzo = z0 + (int)floorf(fdt * un[sc + 2 * (size_t)nv]);
+        wz0 = max(0, min((bzo - sg.MZ) & ~15, nz - wez));
     }
+    // origin of every z segment: the displacement of the tile's centre column at the segment's height
+    if ((int)threadIdx.x < sg.nseg) {
+        const float fdt = (float)dt;
+        const int zc = min(wz0 + (int)threadIdx.x * 16 + 8, nz - 1);
+        const size_t sc = ((size_t)cxs * ny + cys) * nz + zc;
+        int2 o;
+        o.x = max(-1, min(x0 + (int)floorf(fdt * un[sc]) - sg.MX, nx + 1 - WX));
+        o.y = max(-1, min(y0 + (int)floorf(fdt * un[sc + nv]) - sg.MY, ny + 1 - WY));
+        org[threadIdx.x] = o;
+    }
+    const uint32_t sxB = (uint32_t)(WY * WZ) * 8u, syB = (uint32_t)WZ * 8u;            // window strides in bytes
+    const uint32_t gxB = (uint32_t)ny * nz * 4u, gyB = (uint32_t)nz * 4u;              // grid strides in bytes
+    const uint32_t wxu1 = (uint32_t)(WX - 1), wyu1 = (uint32_t)(WY - 1), wezu = (uint32_t)wez;
 
-    struct TilePos {
-        uint32_t n;
-        int x0, y0, z0, ex, ey, ez;
-    };
-    auto locate_tile = [&](uint32_t L) {
-        TilePos tp;
-        tp.n = rg.d_tiles.div(L);
-        uint32_t r = L - tp.n * rg.tiles_per_item;
-        const uint32_t bx = rg.d_tyz.div(r);
-        r -= bx * (rg.nty * rg.ntz);
-        const uint32_t by = rg.d_tz.div(r);
-        const uint32_t bz = r - by * rg.ntz;
-        tp.x0 = bx * rg.TX; tp.y0 = by * rg.TY; tp.z0 = bz * rg.CZ * 64;
-        tp.ex = min(rg.TX, nx - tp.x0); tp.ey = min(rg.TY, ny - tp.y0); tp.ez = min(rg.CZ * 64, nz - tp.z0);
-        return tp;
-    };
-    // operands of one tile as they arrive from HBM (one row chunk per e)
-    float pux[VPL], puy[VPL], puz[VPL], pg[VPL], ppx[VPL], ppy[VPL], ppz[VPL];
-    float probe[3] = {0.f, 0.f, 0.f};
-    auto request = [&](const TilePos &tp, int c) {
-        const float *un = u + (size_t)tp.n * 3 * nv;
-        const BufRsrc ru = make_rsrc(un, 3u * planeB);
-        const BufRsrc rgo = make_rsrc(go + ((size_t)tp.n * nc + c) * nv, planeB);
-        const BufRsrc rdu = make_rsrc(NEED_U ? d_u + (size_t)tp.n * 3 * nv : nullptr, NEED_U ? 3u * planeB : 0u);
-        if (!(rg.abl & 16)) {
-            const size_t sc = ((size_t)(tp.x0 + tp.ex / 2) * ny + (tp.y0 + tp.ey / 2)) * nz + (tp.z0 + tp.ez / 2);
-            probe[0] = un[sc]; probe[1] = un[sc + nv]; probe[2] = un[sc + 2 * (size_t)nv];
-        }
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-            const bool rowok = ca[e] < tp.ex && cb[e] < tp.ey;   // uniform
-            const uint32_t rowB = rowok ? (((uint32_t)(tp.x0 + ca[e]) * ny + (tp.y0 + cb[e])) * nz + (tp.z0 + cq[e] * 64)) * 4u : 0u;
-            if (rg.abl & 8) {
-                pux[e] = 0.3f; puy[e] = -0.4f; puz[e] = 0.001f * (float)lane; pg[e] = 1.f + (float)rowB;
-            } else {
-                pux[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, lane4, rowB, 0));
-                puy[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, lane4, rowB + planeB, 0));
-                puz[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, lane4, rowB + 2u * planeB, 0));
-                pg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgo, lane4, rowB, 0));
-            }
-            if (NEED_U && c > 0) {   // d_u is read-modify-written per channel, ascending channel order as the reference
-                ppx[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdu, lane4, rowB, 0));
-                ppy[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdu, lane4, rowB + planeB, 0));
-                ppz[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdu, lane4, rowB + 2u * planeB, 0));
-            } else {
-                ppx[e] = ppy[e] = ppz[e] = 0.f;
-            }
-        }
-    };
-
-    // the window starts out zero; every flush leaves it zero again
-    if (!(rg.abl & 4))
-        for (uint32_t f = threadIdx.x; f < rg.win_cells; f += NT) win[f] = 0.0;
-    if (T >= Tend) return;
-    TilePos tp = locate_tile(T);
-    int c = 0;
-    request(tp, 0);
-    __syncthreads();
-
-    for (;;) {
-        const float *un = u + (size_t)tp.n * 3 * nv;
-        const float *Ic = (BC ? I : I + (size_t)tp.n * nc * nv) + (size_t)c * nv;
-        float *dIc = (BC ? d_I : d_I + (size_t)tp.n * nc * nv) + (size_t)c * nv;
-        const float *gc = go + ((size_t)tp.n * nc + c) * nv;
-        float *dun = NEED_U ? d_u + (size_t)tp.n * 3 * nv : nullptr;
+    for (int c = 0; c < nc; ++c) {
+        for (uint32_t f = threadIdx.x; f < sg.win_cells; f += NT) win[f] = 0.0;
+        __syncthreads();
+        const float *Ic = In + (size_t)c * nv;
+        const float *gc = gon + (size_t)c * nv;
+        const BufRsrc rdI = make_rsrc(dIn + (size_t)c * nv, planeB);
         const BufRsrc rI = make_rsrc(Ic, planeB);
-        const BufRsrc rdu = make_rsrc(dun, NEED_U ? 3u * planeB : 0u);
-        // window origin: tile origin + displacement probed at the tile centre - margin (speed only)
-        int wx0, wy0, wz0;
-        {
-            const float fdt = (float)dt;
-            const int bxo = tp.x0 + (int)floorf(fdt * probe[0]);
-            const int byo = tp.y0 + (int)floorf(fdt * probe[1]);
-            const int bzo = tp.z0 + (int)floorf(fdt * probe[2]);
-            wx0 = max(0, min(bxo - rg.MX, nx - wex));
-            wy0 = max(0, min(byo - rg.MY, ny - wey));
-            wz0 = max(0, min((bzo - rg.MZ) & ~15, nz - wez));
-        }
-
-        // ---- positions of this tile's voxels; the arriving registers are then free for the next tile
-        float hx[VPL], hy[VPL], hz[VPL], gv[VPL], qx[VPL], qy[VPL], qz[VPL];
-        bool live[VPL];
-        uint32_t rowB[VPL];
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-            const bool rowok = ca[e] < tp.ex && cb[e] < tp.ey;
-            const int ri = tp.x0 + ca[e], rj = tp.y0 + cb[e], rk = tp.z0 + cq[e] * 64;
-            live[e] = rowok && rk + lane < tp.z0 + tp.ez;
-            rowB[e] = rowok ? (((uint32_t)ri * ny + rj) * nz + rk) * 4u : 0u;
-            hx[e] = row_pos<UNIT>((float)ri, dt, pux[e]);
-            hy[e] = row_pos<UNIT>((float)rj, dt, puy[e]);
-            hz[e] = row_pos<UNIT>((float)(rk + lane), dt, puz[e]);
-            gv[e] = pg[e];
-            qx[e] = ppx[e]; qy[e] = ppy[e]; qz[e] = ppz[e];
-        }
-
-        // one (x, y) row of a footprint that is not inside the window: the reference's two clamped global
-        // atomics (include/interp.h:330-401 splat_neighbor with CLAMP, :431-453)
-        const BufRsrc rdI = make_rsrc(dIc, planeB);
-        auto row_global = [&](int cx, int cy, int fz, float w0, float w1) {
-            const uint32_t o = __umul24((uint32_t)clamp1(cx, nx), gxB) + __umul24((uint32_t)clamp1(cy, ny), gyB);
-            (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w0, rdI, o + (uint32_t)clamp1(fz, nz) * 4u, 0, 0);
-            (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w1, rdI, o + (uint32_t)clamp1(fz + 1, nz) * 4u, 0, 0);
-        };
-        const uint32_t wexu = (uint32_t)wex, weyu = (uint32_t)wey, wezu1 = (uint32_t)(wez - 1);
-
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-            if (!live[e]) continue;
-            int fx, fy, fz;
-            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(fx) : "v"(hx[e]));
-            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(fy) : "v"(hy[e]));
-            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(fz) : "v"(hz[e]));
-            fx = lg_med3(fx, -1073741824, 1073741824);  // as lg_floor: keeps floor + 1 and the products below in range
-            fy = lg_med3(fy, -1073741824, 1073741824);
-            fz = lg_med3(fz, -1073741824, 1073741824);
-            const float t = hx[e] - (float)fx, uu = hy[e] - (float)fy, v = hz[e] - (float)fz;
+        for (uint32_t tt = threadIdx.x; tt < sg.tile_vox; tt += NT) {
+            const uint32_t a = sg.d_TyTz.div(tt);
+            const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
+            const uint32_t b = sg.d_Tz.div(rr);
+            const uint32_t kk = rr - b * (uint32_t)sg.TZ;
+            if ((int)a >= ex || (int)b >= ey || (int)kk >= ez) continue;
+            const int vi = x0 + a, vj = y0 + b, vk = z0 + kk;
+            const uint32_t sv = ((uint32_t)vi * ny + vj) * nz + vk;
+            const float gv = gc[sv];
+            const float hx = shear_pos<UNIT>(vi, dt, un[sv]);
+            const float hy = shear_pos<UNIT>(vj, dt, un[sv + nv]);
+            const float hz = shear_pos<UNIT>(vk, dt, un[sv + 2 * (size_t)nv]);
+            const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+            const float t = hx - (float)fx, uu = hy - (float)fy, v = hz - (float)fz;
             const float omt = 1.f - t, omu = 1.f - uu, omv = 1.f - v;
             // sequentially flipped weights (include/interp.h:431-453): x outer, y, z inner
             float wq[8];
@@ -556,43 +471,48 @@ __global__ __launch_bounds__(NT) void splat_rows_kernel(float *__restrict__ d_I,
                 float ddx = omt, ddy = omu, ddz = omv;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    wq[q] = (ddx * ddy * ddz) * gv[e];
+                    wq[q] = (ddx * ddy * ddz) * gv;
                     ddz = 1.f - ddz;
                     if (q & 1) ddy = 1.f - ddy;
                     if ((q & 3) == 3) ddx = 1.f - ddx;
                 }
             }
-            // The footprint is four (x, y) rows of two z cells.  A row inside the window goes to the window
-            // (two LDS adds at fixed offsets); a row that is not -- beyond the window, or a cell the clamp
-            // folds onto the border -- takes the reference's two global atomics, row by row: no lane ever
-            // drags its wave through an eight-corner general path.
-            const uint32_t lx = (uint32_t)(fx - wx0), ly = (uint32_t)(fy - wy0), lz = (uint32_t)(fz - wz0);
-            const bool zz = lz < wezu1;
-            const bool xa = lx < wexu && zz, xc = lx + 1u < wexu && zz, ya = ly < weyu, yb = ly + 1u < weyu;
-            const uint32_t wa = (uint32_t)(__mul24((int)lx, (int)sxB) + __mul24((int)ly, (int)syB)) + lz * 8u;
-            if (!(rg.abl & 1)) {
-                if (xa && ya) {
-                    double *w = reinterpret_cast<double *>(lago_smem + wa);
-                    lds_add(w, (double)wq[0]);
-                    lds_add(w + 1, (double)wq[1]);
-                } else row_global(fx, fy, fz, wq[0], wq[1]);
-                if (xa && yb) {
-                    double *w = reinterpret_cast<double *>(lago_smem + wa + syB);
-                    lds_add(w, (double)wq[2]);
-                    lds_add(w + 1, (double)wq[3]);
-                } else row_global(fx, fy + 1, fz, wq[2], wq[3]);
-                if (xc && ya) {
-                    double *w = reinterpret_cast<double *>(lago_smem + wa + sxB);
-                    lds_add(w, (double)wq[4]);
-                    lds_add(w + 1, (double)wq[5]);
-                } else row_global(fx + 1, fy, fz, wq[4], wq[5]);
-                if (xc && yb) {
-                    double *w = reinterpret_cast<double *>(lago_smem + wa + sxB + syB);
-                    lds_add(w, (double)wq[6]);
-                    lds_add(w + 1, (double)wq[7]);
-                } else row_global(fx + 1, fy + 1, fz, wq[6], wq[7]);
-            } else if (wq[0] + wq[1] + wq[2] + wq[3] + wq[4] + wq[5] + wq[6] + wq[7] == 1.2345e30f) {
-                lds_add(reinterpret_cast<double *>(lago_smem), 1.0);  // keeps the weights alive
+            // the two z cells, clamped as the reference clamps them, and the window segment each falls in
+            const int cz0 = clamp1(fz, nz), cz1 = clamp1(fz + 1, nz);
+            const uint32_t lz0 = (uint32_t)(cz0 - wz0), lz1 = (uint32_t)(cz1 - wz0);
+            bool inwin = lz0 < wezu && lz1 < wezu;
+            int2 o0 = {0, 0}, o1 = {0, 0};
+            if (inwin) {
+                o0 = org[lz0 >> 4];
+                o1 = org[lz1 >> 4];
+            }
+            const uint32_t lx0 = (uint32_t)(fx - o0.x), ly0 = (uint32_t)(fy - o0.y);
+            const uint32_t lx1 = (uint32_t)(fx - o1.x), ly1 = (uint32_t)(fy - o1.y);
+            inwin = inwin && lx0 < wxu1 && ly0 < wyu1 && lx1 < wxu1 && ly1 < wyu1;
+            if (inwin) {
+                const uint32_t a0 = __umul24(lx0, sxB) + __umul24(ly0, syB) + lz0 * 8u;
+                const uint32_t a1 = __umul24(lx1, sxB) + __umul24(ly1, syB) + lz1 * 8u;
+                lds_add(reinterpret_cast<double *>(lago_smem + a0), (double)wq[0]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1), (double)wq[1]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + syB), (double)wq[2]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + syB), (double)wq[3]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + sxB), (double)wq[4]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + sxB), (double)wq[5]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + sxB + syB), (double)wq[6]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + sxB + syB), (double)wq[7]);
+            } else {
+                // beyond the window: the reference's clamped global atomics (include/interp.h:330-401, :431-453)
+                const uint32_t X0 = __umul24((uint32_t)clamp1(fx, nx), gxB), X1 = __umul24((uint32_t)clamp1(fx + 1, nx), gxB);
+                const uint32_t Y0 = __umul24((uint32_t)clamp1(fy, ny), gyB), Y1 = __umul24((uint32_t)clamp1(fy + 1, ny), gyB);
+                const uint32_t Z0 = (uint32_t)cz0 * 4u, Z1 = (uint32_t)cz1 * 4u;
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[0], rdI, X0 + Y0 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[1], rdI, X0 + Y0 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[2], rdI, X0 + Y1 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[3], rdI, X0 + Y1 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[4], rdI, X1 + Y0 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[5], rdI, X1 + Y0 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[6], rdI, X1 + Y1 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[7], rdI, X1 + Y1 + Z1, 0, 0);
             }
             if (NEED_U) {
                 float gx, gy, gz;
@@ -602,12 +522,12 @@ __global__ __launch_bounds__(NT) void splat_rows_kernel(float *__restrict__ d_I,
                     // corners are the pair's high half, below the lower border both are its low half
                     const int zb = lg_med3(fz, 0, nz - 2);
                     const bool f_hi = fz > nz - 2, c_lo = fz < 0;
-                    const uint32_t o0 = __umul24((uint32_t)fx, gxB) + __umul24((uint32_t)fy, gyB) + (uint32_t)zb * 4u;
+                    const uint32_t o = __umul24((uint32_t)fx, gxB) + __umul24((uint32_t)fy, gyB) + (uint32_t)zb * 4u;
                     float l0, l1, l2, l3, h0, h1, h2, h3;
-                    buf_load2s(rI, o0, 0u, l0, h0);          // (the full-width-integer form: see common.hpp on the
-                    buf_load2s(rI, o0, gxB, l1, h1);         //  hipcc narrowing of b64 buffer loads)
-                    buf_load2s(rI, o0, gxB + gyB, l2, h2);
-                    buf_load2s(rI, o0, gyB, l3, h3);
+                    buf_load2s(rI, o, 0u, l0, h0);          // (the full-width-integer form: see common.hpp on the
+                    buf_load2s(rI, o, gxB, l1, h1);         //  hipcc narrowing of b64 buffer loads)
+                    buf_load2s(rI, o, gxB + gyB, l2, h2);
+                    buf_load2s(rI, o, gyB, l3, h3);
                     const float c0 = f_hi ? h0 : l0, c1 = f_hi ? h1 : l1, c2 = f_hi ? h2 : l2, c3 = f_hi ? h3 : l3;
                     const float c4 = c_lo ? l0 : h0, c5 = c_lo ? l1 : h1, c6 = c_lo ? l2 : h2, c7 = c_lo ? l3 : h3;
                     // include/interp.h:315-326
@@ -616,168 +536,132 @@ __global__ __launch_bounds__(NT) void splat_rows_kernel(float *__restrict__ d_I,
                     gz = lg_fma(omu, lg_fma(omt, c4 - c0, t * (c5 - c1)), uu * lg_fma(omt, c7 - c3, t * (c6 - c2)));
                 } else {
                     Lerp3<float, false> Lq;
-                    Lq.setup(hx[e], hy[e], hz[e], nx, ny, nz);
+                    Lq.setup(hx, hy, hz, nx, ny, nz);
                     Lq.grad(Ic, gx, gy, gz);
                 }
                 // cuda/interp.cu:230: (Real)((double)diff * dt); for dt = +-1 that is +-diff exactly
-                const float diff = UNIT ? (float)dt * gv[e] : (float)((double)gv[e] * dt);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lg_fma(gx, diff, qx[e])), rdu, lane4, rowB[e], 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lg_fma(gy, diff, qy[e])), rdu, lane4, rowB[e] + planeB, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lg_fma(gz, diff, qz[e])), rdu, lane4, rowB[e] + 2u * planeB, 0);
+                const float diff = UNIT ? (float)dt * gv : (float)((double)gv * dt);
+                // ascending channel order, as the reference's thread-owned accumulation
+                dun[sv] = lg_fma(gx, diff, c > 0 ? dun[sv] : 0.f);
+                dun[sv + nv] = lg_fma(gy, diff, c > 0 ? dun[sv + nv] : 0.f);
+                dun[sv + 2 * (size_t)nv] = lg_fma(gz, diff, c > 0 ? dun[sv + 2 * (size_t)nv] : 0.f);
             }
         }
         __syncthreads();
-
-        // ---- next (tile, channel) of the strip: request its rows now, they travel during the flush
-        int cn = c + 1;
-        uint32_t Tn = T;
-        if (cn == nc) { cn = 0; Tn = T + wgs; }
-        const bool more = Tn < Tend;
-        TilePos tpn = tp;
-        if (more) {
-            if (Tn != T) tpn = locate_tile(Tn);
-            request(tpn, cn);
-        }
-
-        // ---- flush touched cells and leave them zero: one wave per window row (lx, ly), lanes along z
-        if (!(rg.abl & 32)) {
-            const uint32_t nrows = (uint32_t)(wex * wey);
-            for (uint32_t row = wave; row < nrows; row += NW) {
-                const uint32_t lx = rg.d_wey.div(row), ly = row - lx * (uint32_t)wey;
-                double *wrow = win + (lx * WY + ly) * WZ;
-                float *grow = dIc + ((size_t)(wx0 + lx) * ny + (wy0 + ly)) * nz + wz0;
+        // flush touched cells: one wave per window row (lx, ly), lanes along z; the (x, y) a cell belongs to is
+        // its segment's origin + (lx, ly), folded onto the grid (the clamp of the reference)
+        {
+            const int lane = threadIdx.x & 63;
+            const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const uint32_t nrows = (uint32_t)(WX * WY);
+            for (uint32_t row = wave; row < nrows; row += NT / 64) {
+                const uint32_t lx = sg.d_wy.div(row), ly = row - lx * (uint32_t)WY;
+                const double *wrow = win + row * (uint32_t)WZ;
                 for (int lz = lane; lz < wez; lz += 64) {
                     const double acc = wrow[lz];
                     if (acc != 0.0) {
-                        if (!(rg.abl & 2) || acc == 1.2345e300) atomic_add(grow + lz, (float)acc);
-                        wrow[lz] = 0.0;
+                        const int2 o = org[lz >> 4];
+                        const uint32_t off = __umul24((uint32_t)clamp1(o.x + (int)lx, nx), gxB) +
+                                             __umul24((uint32_t)clamp1(o.y + (int)ly, ny), gyB) + (uint32_t)(wz0 + lz) * 4u;
+                        (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((float)acc, rdI, off, 0, 0);
                     }
                 }
             }
         }
-        if (!more) break;
         __syncthreads();
-        T = Tn;
-        c = cn;
-        tp = tpn;
     }
 }
 
-static int g_rows_abl = 0;
-static int g_rows_oversub = 1;  // persistent workgroups per resident slot
-static int g_rows_lds_kb = 80;  // LDS budget per workgroup: 80 KB = two workgroups per CU
-static int g_rows_cfg[6] = {4, 8, 0, 1, 1, 4};  // TX TY CZ(0 = auto) margins MX MY MZ
-static int g_rows_nt = 512, g_rows_vpl = 2, g_rows_on = 0;  // off: measured slower than the tiled kernel (profiles/r02_splat_experiments.md)
+static int g_shear_cfg[6] = {4, 8, 0, 1, 1, 4};  // TX TY TZ(0 = auto) margins MX MY MZ
+static int g_shear_nt = 1024, g_shear_on = 1;
 
-static bool make_rows(RowGeom &rg, const Geom &g, int64_t nn, size_t &smem) {
-    int TX = g_rows_cfg[0], TY = g_rows_cfg[1], CZ = g_rows_cfg[2];
-    const int EX = g_rows_cfg[3], EY = g_rows_cfg[4], EZ = g_rows_cfg[5];
-    if (g.nz < 2 || TX < 1 || TY < 1) return false;
-    const int chunks = (g.nz + 63) / 64;
-    if (CZ <= 0) CZ = chunks <= 2 ? chunks : (chunks + 1) / 2 > 2 ? 2 : (chunks + 1) / 2;  // at most 128 voxels of a row per tile
-    if (CZ > chunks) CZ = chunks;
+static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem) {
+    int TX = g_shear_cfg[0], TY = g_shear_cfg[1], TZ = g_shear_cfg[2];
+    const int EX = g_shear_cfg[3], EY = g_shear_cfg[4], EZ = g_shear_cfg[5];
+    if (g.nz < 2 || TX < 1 || TY < 1 || EX < 0 || EY < 0 || EZ < 0) return false;
+    // strides must fit the 24-bit multiplies
+    if ((uint64_t)g.ny * g.nz * 4 >= (1u << 24) || g.nx >= (1 << 23)) return false;
+    if (TZ <= 0) {  // auto: whole z rows up to 128 voxels, else even parts of at most 128 (multiples of 16)
+        const int parts = (g.nz + 127) / 128;
+        TZ = (((g.nz + parts - 1) / parts + 15) / 16) * 16;
+    }
     TX = TX < g.nx ? TX : g.nx;
     TY = TY < g.ny ? TY : g.ny;
-    // strides must fit the 24-bit multiplies of the fast path; a three-plane field is addressed through one
-    // buffer descriptor (byte offsets below 2^32)
-    if ((uint64_t)g.ny * g.nz * 4 >= (1u << 24) || g.nx >= (1 << 23) || (uint64_t)g.nvox * 12 >= (1ull << 32)) return false;
+    TZ = TZ < g.nz ? TZ : g.nz;
     for (;;) {
-        rg.WX = TX + 1 + 2 * EX;
-        rg.WY = TY + 1 + 2 * EY;
-        rg.WZ = ((CZ * 64 + 1 + 2 * EZ + 15 + 15) / 16) * 16;
-        if (rg.WX > g.nx) rg.WX = g.nx;
-        if (rg.WY > g.ny) rg.WY = g.ny;
-        if (rg.WZ > g.nz) rg.WZ = g.nz;
-        if ((uint64_t)rg.WX * rg.WY * rg.WZ * 8 <= (uint64_t)g_rows_lds_kb * 1024) break;  // workgroups per CU
+        sg.WX = TX + 1 + 2 * EX;
+        sg.WY = TY + 1 + 2 * EY;
+        sg.WZ = TZ >= g.nz ? g.nz : ((TZ + 1 + 2 * EZ + 15 + 15) / 16) * 16;
+        if (sg.WZ > g.nz) sg.WZ = g.nz;
+        sg.nseg = (sg.WZ + 15) / 16;
+        if ((uint64_t)sg.WX * sg.WY * sg.WZ * 8 + (uint64_t)sg.nseg * 8 <= 80 * 1024) break;  // two workgroups per CU
         if (TX > 2) --TX;
         else if (TY > 2) --TY;
-        else if (CZ > 1) --CZ;
+        else if (TZ > 16) TZ = ((TZ / 2 + 15) / 16) * 16;
         else return false;
     }
-    if ((uint64_t)rg.WY * rg.WZ * 8 >= (1u << 24)) return false;
-    rg.nx = g.nx; rg.ny = g.ny; rg.nz = g.nz;
-    rg.TX = TX; rg.TY = TY; rg.CZ = CZ;
-    rg.MX = EX; rg.MY = EY; rg.MZ = EZ;
-    rg.win_cells = (uint32_t)rg.WX * rg.WY * rg.WZ;
-    rg.qcap = 0;
-    smem = (size_t)rg.win_cells * sizeof(double);
-    rg.ntx = (g.nx + TX - 1) / TX;
-    rg.nty = (g.ny + TY - 1) / TY;
-    rg.ntz = (chunks + CZ - 1) / CZ;
-    rg.tiles_per_item = rg.ntx * rg.nty * rg.ntz;
-    const int64_t total = (int64_t)rg.tiles_per_item * nn;
+    if ((uint64_t)sg.WY * sg.WZ * 8 >= (1u << 24) || (int64_t)TX * TY * TZ < 256) return false;
+    sg.nx = g.nx; sg.ny = g.ny; sg.nz = g.nz;
+    sg.TX = TX; sg.TY = TY; sg.TZ = TZ;
+    sg.MX = EX; sg.MY = EY; sg.MZ = EZ;
+    sg.win_cells = (uint32_t)sg.WX * sg.WY * sg.WZ;
+    smem = (size_t)sg.win_cells * sizeof(double) + (size_t)sg.nseg * 8;
+    sg.ntx = (g.nx + TX - 1) / TX;
+    sg.nty = (g.ny + TY - 1) / TY;
+    sg.ntz = (g.nz + TZ - 1) / TZ;
+    sg.tiles_per_item = sg.ntx * sg.nty * sg.ntz;
+    const int64_t total = (int64_t)sg.tiles_per_item * nn;
     if (total >= (1ll << 31)) return false;
-    rg.total = (uint32_t)total;
-    rg.chunks_per_tile = (uint32_t)TX * TY * CZ;
-    rg.d_tiles = FastDiv(rg.tiles_per_item);
-    rg.d_tyz = FastDiv(rg.nty * rg.ntz);
-    rg.d_tz = FastDiv(rg.ntz);
-    rg.d_tycz = FastDiv((uint32_t)(TY * CZ));
-    rg.d_cz = FastDiv((uint32_t)CZ);
-    rg.d_wey = FastDiv((uint32_t)(rg.WY < g.ny ? rg.WY : g.ny));
-    rg.abl = g_rows_abl;
+    sg.total = (uint32_t)total;
+    sg.tile_vox = (uint32_t)TX * TY * TZ;
+    sg.d_tiles = FastDiv(sg.tiles_per_item);
+    sg.d_tyz = FastDiv(sg.nty * sg.ntz);
+    sg.d_tz = FastDiv(sg.ntz);
+    sg.d_TyTz = FastDiv((uint32_t)(TY * TZ));
+    sg.d_Tz = FastDiv((uint32_t)TZ);
+    sg.d_wy = FastDiv((uint32_t)sg.WY);
     return true;
 }
 
-template <int NT, int VPL>
-static hipError_t launch_rows(float *d_I, float *d_u, const float *go, const float *I, const float *u, double dt, int nc,
-                              const RowGeom &rg, size_t smem, bool bc, bool need_u, hipStream_t s) {
+template <int NT>
+static hipError_t launch_shear(float *d_I, float *d_u, const float *go, const float *I, const float *u, double dt, int nc,
+                               const ShearGeom &sg, size_t smem, bool bc, bool need_u, hipStream_t s) {
     const bool unit = unit_dt<float>(dt);
-    // persistent grid: workgroups per CU the LDS budget admits x CUs (a multiple of 8: one strip set per XCD)
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
-    uint32_t per_cu = (uint32_t)((160 * 1024) / (smem ? smem : 1));
-    if (per_cu * NT > 2048) per_cu = 2048 / NT;
-    if (per_cu < 1) per_cu = 1;
-    uint32_t grid = (uint32_t)ncu * per_cu * (uint32_t)g_rows_oversub;
-    grid = (grid + 7u) & ~7u;
-    if (grid > ((rg.total + 7u) & ~7u)) grid = (rg.total + 7u) & ~7u;
-#define LAGO_ROWS(NU, UN, B)                                                                                      \
+#define LAGO_SHEAR(NU, UN, B)                                                                                     \
     do {                                                                                                          \
-        auto k = splat_rows_kernel<NT, NU, UN, B, VPL>;                                                           \
+        auto k = splat_shear_kernel<NT, NU, UN, B>;                                                               \
         if (smem > 64 * 1024) {                                                                                   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
             if (e != hipSuccess) return e;                                                                        \
         }                                                                                                         \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), smem, s, d_I, d_u, go, I, u, dt, nc, rg);                     \
+        hipLaunchKernelGGL(k, dim3(sg.total), dim3(NT), smem, s, d_I, d_u, go, I, u, dt, nc, sg);                 \
     } while (0)
     if (need_u) {
-        if (unit) { if (bc) LAGO_ROWS(true, true, true); else LAGO_ROWS(true, true, false); }
-        else { if (bc) LAGO_ROWS(true, false, true); else LAGO_ROWS(true, false, false); }
+        if (unit) { if (bc) LAGO_SHEAR(true, true, true); else LAGO_SHEAR(true, true, false); }
+        else { if (bc) LAGO_SHEAR(true, false, true); else LAGO_SHEAR(true, false, false); }
     } else {
-        if (unit) { if (bc) LAGO_ROWS(false, true, true); else LAGO_ROWS(false, true, false); }
-        else { if (bc) LAGO_ROWS(false, false, true); else LAGO_ROWS(false, false, false); }
+        if (unit) { if (bc) LAGO_SHEAR(false, true, true); else LAGO_SHEAR(false, true, false); }
+        else { if (bc) LAGO_SHEAR(false, false, true); else LAGO_SHEAR(false, false, false); }
     }
-#undef LAGO_ROWS
+#undef LAGO_SHEAR
     return hipSuccess;
 }
 
-// float32 displacement splat through the row-mapped kernel; returns 1 when the shape is left to the
+// float32 displacement splat through the sheared-window kernel; returns 1 when the shape is left to the
 // general tiled kernel.
-static int interp_backward_rows(float *d_I, float *d_u, const float *go, const float *I, const float *u, double dt,
-                                int nc, int64_t nn, const Geom &g, bool bc, bool need_u, hipStream_t s) {
-    if (!g_rows_on) return 1;
-    RowGeom rg;
+static int interp_backward_shear(float *d_I, float *d_u, const float *go, const float *I, const float *u, double dt,
+                                 int nc, int64_t nn, const Geom &g, bool bc, bool need_u, hipStream_t s) {
+    if (!g_shear_on) return 1;
+    ShearGeom sg;
     size_t smem;
-    if (!make_rows(rg, g, nn, smem)) return 1;
-    hipError_t e = hipSuccess;
-    const int nt = g_rows_nt >= 1024 ? 1024 : (g_rows_nt >= 512 ? 512 : 256);
-    const int vpl = (int)((rg.chunks_per_tile + nt / 64 - 1) / (nt / 64));  // the whole tile in one pass of the workgroup
-#define LAGO_GO(NT_, V_) e = launch_rows<NT_, V_>(d_I, d_u, go, I, u, dt, nc, rg, smem, bc, need_u, s)
-#define LAGO_BYV(NT_)                                                                     \
-    if (vpl <= 1) LAGO_GO(NT_, 1); else if (vpl <= 2) LAGO_GO(NT_, 2); else if (vpl <= 4) LAGO_GO(NT_, 4); \
-    else if (vpl <= 6) LAGO_GO(NT_, 6); else if (vpl <= 8) LAGO_GO(NT_, 8); else return 1
-    if (nt == 1024) { LAGO_BYV(1024); } else if (nt == 512) { LAGO_BYV(512); } else { LAGO_BYV(256); }
-#undef LAGO_BYV
-#undef LAGO_GO
-    if (e != hipSuccess) return fail_hip(e, "interp_backward (row splat)");
-    return finish_launch(s, "interp_backward (row splat)");
+    if (!make_shear(sg, g, nn, smem)) return 1;
+    hipError_t e;
+    if (g_shear_nt >= 1024) e = launch_shear<1024>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, s);
+    else if (g_shear_nt >= 512) e = launch_shear<512>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, s);
+    else e = launch_shear<256>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, s);
+    if (e != hipSuccess) return fail_hip(e, "interp_backward (sheared-window splat)");
+    return finish_launch(s, "interp_backward (sheared-window splat)");
 }
 
 // g: target grid; gs: source grid (tiles): the same grid for interp / affine.  sc[d] = how many
@@ -895,8 +779,8 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     if (g.nz < 2) return 1;  // thin volumes take the plain kernel
     if constexpr (sizeof(R) == 4) {
         if (vec && !(g_splat_mc && need_u && nc > 1)) {
-            const int rc = interp_backward_rows((float *)d_I, (float *)d_u, (const float *)go, (const float *)I,
-                                                (const float *)u, dt, nc, nn, g, bc, need_u, s);
+            const int rc = interp_backward_shear((float *)d_I, (float *)d_u, (const float *)go, (const float *)I,
+                                                 (const float *)u, dt, nc, nn, g, bc, need_u, s);
             if (rc != 1) return rc;
         }
     }
@@ -998,16 +882,12 @@ extern "C" {
 // Tuning hook (bench / tests): tile TX, TY, TZ (0 = auto), window margins, threads per workgroup.
 // Affects speed only, never results.
 void lago_debug_splat_mc(int on) { lago::g_splat_mc = on; }
-// row-mapped float32 splat: on/off, tile TX TY CZ (64-voxel chunks of a row; 0 = auto), margins, threads, rows per wave pass
-void lago_debug_splat_rows_ablate(int mask) { lago::g_rows_abl = mask; }
-void lago_debug_splat_rows_lds_kb(int kb) { lago::g_rows_lds_kb = kb; }
-void lago_debug_splat_rows_oversub(int k) { lago::g_rows_oversub = k < 1 ? 1 : k; }
-void lago_set_splat_rows(int on, int tx, int ty, int cz, int mx, int my, int mz, int nthreads, int vpl) {
-    lago::g_rows_on = on;
-    lago::g_rows_cfg[0] = tx; lago::g_rows_cfg[1] = ty; lago::g_rows_cfg[2] = cz;
-    lago::g_rows_cfg[3] = mx; lago::g_rows_cfg[4] = my; lago::g_rows_cfg[5] = mz;
-    lago::g_rows_nt = nthreads;
-    lago::g_rows_vpl = vpl;
+// sheared-window float32 splat: on/off, tile TX TY TZ (0 = auto), margins, threads per workgroup.  Speed only.
+void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
+    lago::g_shear_on = on;
+    lago::g_shear_cfg[0] = tx; lago::g_shear_cfg[1] = ty; lago::g_shear_cfg[2] = tz;
+    lago::g_shear_cfg[3] = mx; lago::g_shear_cfg[4] = my; lago::g_shear_cfg[5] = mz;
+    lago::g_shear_nt = nthreads;
 }
 void lago_set_splat_tile(int tx, int ty, int tz, int ex, int ey, int ez, int nthreads) {
     lago::g_tile_cfg[0] = tx; lago::g_tile_cfg[1] = ty; lago::g_tile_cfg[2] = tz;

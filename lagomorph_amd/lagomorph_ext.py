@@ -69,7 +69,7 @@ _lib.lago_set_debug.argtypes = [_int]
 _lib.lago_set_splat_mode.argtypes = [_int]
 _lib.lago_set_splat_tile.argtypes = [_int] * 7
 _lib.lago_set_vector_kernels.argtypes = [_int]
-_lib.lago_set_splat_rows.argtypes = [_int] * 9
+_lib.lago_set_splat_shear.argtypes = [_int] * 8
 _lib.lago_set_fluid_xpass.argtypes = [_int]
 _lib.lago_set_gather_mode.argtypes = [_int]
 _lib.lago_set_gather_tile.argtypes = [_int] * 7
@@ -144,9 +144,9 @@ def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
     _lib.lago_set_splat_tile(int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
 
 
-def set_splat_rows(on=1, tx=4, ty=8, cz=0, mx=1, my=1, mz=4, nthreads=512, vpl=2):
-    """Row-mapped float32 splat (csrc/splat.hip: splat_rows_kernel): on/off and its tile.  Speed only."""
-    _lib.lago_set_splat_rows(int(on), int(tx), int(ty), int(cz), int(mx), int(my), int(mz), int(nthreads), int(vpl))
+def set_splat_shear(on=1, tx=4, ty=8, tz=0, mx=1, my=1, mz=4, nthreads=1024):
+    """Sheared-window float32 splat (csrc/splat.hip: splat_shear_kernel): on/off and its tile.  Speed only."""
+    _lib.lago_set_splat_shear(int(on), int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
 
 
 def set_vector_kernels(on):

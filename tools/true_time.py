@@ -36,13 +36,13 @@ def b2b(fn, reps=30, warm=5):
 cases = {
     "interp_forward": lambda: ext.interp_forward(I, u, 1.0),
     "interp_backward general (d_I + d_u)": (0, lambda: ext.interp_backward(go, I, u, 1.0, True, True)),
-    "interp_backward rows (d_I + d_u)": (1, lambda: ext.interp_backward(go, I, u, 1.0, True, True)),
+    "interp_backward sheared (d_I + d_u)": (1, lambda: ext.interp_backward(go, I, u, 1.0, True, True)),
     "interp_backward general (d_I)": (0, lambda: ext.interp_backward(go, I, u, 1.0, True, False)),
-    "interp_backward rows (d_I)": (1, lambda: ext.interp_backward(go, I, u, 1.0, True, False)),
+    "interp_backward sheared (d_I)": (1, lambda: ext.interp_backward(go, I, u, 1.0, True, False)),
 }
 for name, fn in cases.items():
     if isinstance(fn, tuple):
-        ext.set_splat_rows(fn[0], tx=4, ty=8, nthreads=512, vpl=4)
+        ext.set_splat_shear(fn[0])
         fn = fn[1]
     per_call, _ = time_op(fn, reps=20, warm=3)
     print(f"{name:40s} per-call events {per_call*1e3:7.1f} us   back-to-back {b2b(fn)*1e3:7.1f} us")
