@@ -61,13 +61,6 @@ int lago_get_splat_mode(void);
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
 /* 1 (default): use the slab-unrolled 3D gather kernels (two voxels per lane) when the shape allows; 0: one-voxel-per-lane kernels only. */
 void lago_set_vector_kernels(int on);
-/* 0 (default): direct gathers from global memory; 1: 3D interp_forward / compose / ad_star stage the
- * sampled image in LDS tile by tile (float32, volumes of at least one 8 x 8 x 64 tile) -- slower than
- * the direct kernels on smooth fields on MI355X, kept as an option.  Results are bit-identical. */
-void lago_set_gather_mode(int mode);
-/* Tuning hook for the LDS-staged gathers: tile TX TY TZ, window margins MX MY MZ, threads per
- * workgroup (256 / 512 / 1024).  Default 8 8 64 1 1 1 1024.  Affects speed only, never results. */
-void lago_set_gather_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
  * (nx in {64,128,256}, ny in {32..256}, nz in {64..256}, powers of two, ny*nz <= 2^15); 1: rocFFT 2D (y, z)
  * plan + fused x-axis pass (nx in {64,128,256}); 0: rocFFT 3D plan + operator kernel.  A mode falls back

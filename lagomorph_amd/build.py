@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblagomorph_hip.so")
-SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip", "gtile.hip"]
+SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3",

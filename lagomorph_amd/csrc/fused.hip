@@ -10,10 +10,6 @@
 
 namespace lago {
 
-template <typename R>
-int gather_tiled(int op, R *out, const R *img, const R *u, double ds, double dt, int nc, int64_t nn, const Geom &g,
-                 bool bc, hipStream_t s);  // gtile.hip
-
 template <typename R, int DIM>
 __global__ __launch_bounds__(kBlock) void compose_kernel(R *__restrict__ out, const R *__restrict__ u,
                                                          const R *__restrict__ v, double ds, double dt, Geom g) {
@@ -120,10 +116,6 @@ static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, in
     if (g.nblocks == 0) return LAGO_OK;
     if (!out || !u || !v) return fail_invalid("compose: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (dim == 3 && g_interp_vec) {
-        const int rc = gather_tiled<R>(1, out, v, u, ds, dt, 3, nn, g, false, s);
-        if (rc <= 0) return rc ? rc : finish_launch(s, "compose");
-    }
     constexpr int U = 2;
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
@@ -315,10 +307,6 @@ static int ad_star_impl(R *out, const R *phi, const R *m, int dim, int64_t nn, i
     if (nx <= 1 || ny <= 1 || (dim == 3 && nz <= 1))
         return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
     hipStream_t s = (hipStream_t)stream;
-    if (dim == 3 && g_interp_vec) {
-        const int rc = gather_tiled<R>(2, out, m, phi, 1.0, 1.0, 3, nn, g, false, s);
-        if (rc <= 0) return rc ? rc : finish_launch(s, "ad_star");
-    }
     constexpr int U = 2;
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);

@@ -9,13 +9,6 @@
 
 namespace lago {
 
-// gtile.hip: LDS-staged gathers (op 0 = interp, 1 = compose, 2 = ad_star); returns 1 when the shape
-// is left to the direct kernels
-template <typename R>
-int gather_tiled(int op, R *out, const R *img, const R *u, double ds, double dt, int nc, int64_t nn, const Geom &g,
-                 bool bc, hipStream_t s);
-
-
 // ------------------------------------------------------------------ forward
 
 template <typename R, int DIM, bool BC>
@@ -216,10 +209,6 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
     if (g.nblocks == 0 || nc == 0) return LAGO_OK;  // empty batch / no channels: nothing to write
     if (!out || !I || !u) return fail_invalid("interp_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (dim == 3 && g_interp_vec) {
-        const int rc = gather_tiled<R>(0, out, I, u, dt, 1.0, (int)nc, nn, g, bc != 0, s);
-        if (rc <= 0) return rc ? rc : finish_launch(s, "interp_forward");
-    }
     constexpr int U = 2;
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);

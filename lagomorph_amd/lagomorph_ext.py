@@ -71,8 +71,6 @@ _lib.lago_set_splat_tile.argtypes = [_int] * 7
 _lib.lago_set_vector_kernels.argtypes = [_int]
 _lib.lago_set_splat_shear.argtypes = [_int] * 8
 _lib.lago_set_fluid_xpass.argtypes = [_int]
-_lib.lago_set_gather_mode.argtypes = [_int]
-_lib.lago_set_gather_tile.argtypes = [_int] * 7
 
 
 def _suffix(t):
@@ -152,16 +150,6 @@ def set_splat_shear(on=1, tx=4, ty=8, tz=0, mx=1, my=1, mz=4, nthreads=1024):
 def set_vector_kernels(on):
     """1 (default): slab-unrolled 3D gather kernels (two voxels per lane) where shapes allow; 0: one-voxel-per-lane kernels only."""
     _lib.lago_set_vector_kernels(1 if on else 0)
-
-
-def set_gather_mode(mode):
-    """0 (default): direct gathers; 1: LDS-staged gather kernels for 3D interp_forward / compose / ad_star
-    (bit-identical; slower on smooth fields, see csrc/gtile.hip)."""
-    _lib.lago_set_gather_mode(int(mode))
-
-
-def set_gather_tile(tx, ty, tz, mx, my, mz, nthreads):
-    _lib.lago_set_gather_tile(int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
 
 
 def set_fluid_mode(mode):

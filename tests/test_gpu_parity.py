@@ -531,46 +531,6 @@ def test_ad_star_rejects_bad_arguments(ext):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("sp", [(8, 8, 64), (17, 19, 70), (24, 16, 130), (9, 40, 66)])
-@pytest.mark.parametrize("kind", ["smooth", "wild"])
-def test_lds_staged_gathers_bit_exact(ext, dtype, sp, kind):
-    """interp_forward / compose / ad_star through the LDS-staged tile kernels (several tile and thread
-    configurations, windows the samples stay inside of and windows they leave) == the direct kernels
-    == the oracle, bit for bit."""
-    rng = np.random.default_rng(hash((sp, kind)) % 2**31)
-    if kind == "smooth":
-        u = (1.5 * np.sin(np.arange(np.prod((2, 3) + sp)).reshape((2, 3) + sp) * 0.003) + 0.4).astype(
-            np.float32 if dtype == torch.float32 else np.float64)
-    else:
-        u = _disp(rng, 2, sp, dtype)
-    v = rnd(rng, (2, 3) + sp, dtype)
-    I = rnd(rng, (2, 2) + sp, dtype)
-    I1 = I[:1].copy()
-    ud, vd, Id, I1d = dev(u), dev(v), dev(I), dev(I1)
-    k = u.dtype.type
-    want = {
-        "interp": orc.interp_forward(I, u, 0.9),
-        "interp_bc": orc.interp_forward(I1, u, 1.0),
-        "compose": k(-0.1) * u + k(1.0) * orc.interp_forward(v, u, -0.1),
-        "ad_star": orc.jacobian_times_vectorfield_forward(u, orc.interp_forward(v, u, 1.0), True, False),
-    }
-    try:
-        for cfg in (None, (8, 8, 64, 2, 2, 2, 1024), (8, 8, 64, 0, 0, 0, 512), (4, 8, 64, 1, 1, 1, 256), (8, 16, 32, 3, 3, 3, 1024)):
-            if cfg is None:
-                ext.set_gather_mode(0)
-            else:
-                ext.set_gather_mode(1)
-                ext.set_gather_tile(*cfg)
-            assert_bits(ext.interp_forward(Id, ud, 0.9), want["interp"], f"interp {cfg}")
-            assert_bits(ext.interp_forward(I1d, ud, 1.0), want["interp_bc"], f"interp broadcast {cfg}")
-            assert_bits(ext.compose(ud, vd, -0.1, 1.0), want["compose"], f"compose {cfg}")
-            assert_bits(ext.Ad_star(ud, vd), want["ad_star"], f"ad_star {cfg}")
-    finally:
-        ext.set_gather_mode(0)
-        ext.set_gather_tile(8, 8, 64, 1, 1, 1, 1024)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp", [(5, 6, 7), (2, 2, 2), (4, 3, 64), (9, 5, 70), (7, 9), (2, 2), (3, 130)])
 def test_fused_small_ad_star_bit_exact(ext, dtype, sp):
     """ad^*(v, m) in one kernel == jtv(v, m, transpose) - jtv_adjoint(m, v), bit for bit (oracle and
