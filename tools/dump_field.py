@@ -9,7 +9,7 @@ import torch
 from bench import gaussian_blur
 
 dev = torch.device("cuda")
-S, B = 128, 8
+S, B = 128, int(sys.argv[2]) if len(sys.argv) > 2 else 8
 g = torch.Generator(device=dev).manual_seed(1234)
 I = gaussian_blur(torch.randn((B, 1, S, S, S), device=dev, generator=g), 2.0)
 u = gaussian_blur(torch.randn((B, 3, S, S, S), device=dev, generator=g), 8.0)
