@@ -142,11 +142,27 @@ int lago_compose_f64(double *out, const double *u, const double *v, double ds, d
  * (/root/reference/lagomorph/adjrep.py:86-97), which the reference evaluates as interp_forward
  * followed by jacobian_times_vectorfield_forward(displacement = true).  phiinv, m, out:
  * (nn, dim, sp); out may not alias an input.  Bit-identical to the two-call sequence (the
- * resampled momentum is rounded where that sequence stores it). */
-int lago_Ad_star_f32(float *out, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
-                     int64_t nz, void *stream);
-int lago_Ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx,
+ * resampled momentum is rounded where that sequence stores it).  mphi (nullable, like m): when given, the
+ * resampled momentum m o (id + phiinv) -- the interp_forward output of the two-call sequence -- is stored
+ * there as well, so that a backward pass need not recompute it. */
+int lago_Ad_star_f32(float *out, float *mphi, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx,
                      int64_t ny, int64_t nz, void *stream);
+int lago_Ad_star_f64(double *out, double *mphi, const double *phiinv, const double *m, int dim, int64_t nn,
+                     int64_t nx, int64_t ny, int64_t nz, void *stream);
+
+/* interp_backward with a start value for d_u (the fused backward forms of compose and Ad_star; d_I exactly as
+ * lago_interp_backward).  The reference kernel owns d_u[n, d, x] in one thread and sums the channels' terms in
+ * ascending order starting from zero (cuda/interp.cu:185-244); here the sum starts from
+ *   u_mode 0: zero (identical to lago_interp_backward with need_u),
+ *   u_mode 1: the contents of d_u on entry (d_u += ...: the `d_v.add_(d_u)` of a chain rule, without the extra pass),
+ *   u_mode 2: addgo * grad_out[n, d, x] (needs nc == dim: the `ds * grad` term of compose's backward).
+ * d_u is always produced (need_u is implied). */
+int lago_interp_backward_fused_f32(float *d_I, float *d_u, const float *grad_out, const float *I, const float *u,
+                                   double dt, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz,
+                                   int broadcast_I, int need_I, int u_mode, double addgo, void *stream);
+int lago_interp_backward_fused_f64(double *d_I, double *d_u, const double *grad_out, const double *I, const double *u,
+                                   double dt, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz,
+                                   int broadcast_I, int need_I, int u_mode, double addgo, void *stream);
 
 /* ad_star (the infinitesimal coadjoint action): out = (Dv)^T m - sum_d D_d^T (v_d m) -- adjrep.ad_star
  * (/root/reference/lagomorph/adjrep.py:69-83), which the reference evaluates as

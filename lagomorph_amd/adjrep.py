@@ -13,21 +13,30 @@ USE_FUSED_AD_STAR = True
 
 class AdStarFunction(torch.autograd.Function):
     """(D phiinv + I) (m o (id + phiinv)) as ONE kernel (csrc/fused.hip), bit-identical to the
-    two-call sequence of adjrep.py:86-97.  The backward recomputes the resampled momentum and is the
-    chain of the two reference backward kernels."""
+    two-call sequence of adjrep.py:86-97.  When a gradient is wanted the kernel also stores the resampled
+    momentum (12 bytes per voxel of the 288 GB instead of a 36-byte-per-voxel recomputation in the backward);
+    the backward is the chain of the two reference backward kernels, the second one adding its displacement
+    gradient straight onto the first one's (lago_interp_backward_fused: no separate add pass)."""
 
     @staticmethod
     def forward(ctx, phiinv, m):
-        ctx.save_for_backward(phiinv, m)
-        return lagomorph_ext.Ad_star(phiinv.contiguous(), m.contiguous())
+        phiinv, m = phiinv.contiguous(), m.contiguous()
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            out, mphiinv = lagomorph_ext.Ad_star(phiinv, m, save_resampled=True)
+            ctx.save_for_backward(phiinv, m, mphiinv)
+            return out
+        return lagomorph_ext.Ad_star(phiinv, m)
 
     @staticmethod
     def backward(ctx, gradout):
-        phiinv, m = ctx.saved_tensors
-        phiinv, m, gradout = phiinv.contiguous(), m.contiguous(), gradout.contiguous()
+        phiinv, m, mphiinv = ctx.saved_tensors
+        gradout = gradout.contiguous()
         need_phi, need_m = ctx.needs_input_grad
-        mphiinv = lagomorph_ext.interp_forward(m, phiinv, 1.0)
         d_v, d_w = lagomorph_ext.jacobian_times_vectorfield_backward(gradout, phiinv, mphiinv, True, False, need_phi, True)
+        if need_phi and hasattr(lagomorph_ext, "interp_backward_fused"):
+            # d_phi = d_v + d_u, the second term accumulated onto the first inside the splat kernel
+            d_m, d_phi = lagomorph_ext.interp_backward_fused(d_w, m, phiinv, 1.0, need_m, d_u=d_v)
+            return d_phi, d_m if need_m else None
         d_m, d_u = lagomorph_ext.interp_backward(d_w, m, phiinv, 1.0, need_m, need_phi)
         return d_v.add_(d_u) if need_phi else None, d_m if need_m else None
 

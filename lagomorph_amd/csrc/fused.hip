@@ -153,8 +153,8 @@ __device__ __forceinline__ R cdiff(const R *__restrict__ f, int plus, int minus)
 }
 
 template <typename R, int DIM>
-__global__ __launch_bounds__(kBlock) void ad_star_kernel(R *__restrict__ out, const R *__restrict__ phi,
-                                                         const R *__restrict__ m, Geom g) {
+__global__ __launch_bounds__(kBlock) void ad_star_kernel(R *__restrict__ out, R *__restrict__ mphi,
+                                                         const R *__restrict__ phi, const R *__restrict__ m, Geom g) {
     const Vox vx = locate(g);
     if (!vx.valid) return;
     const size_t nv = g.nvox;
@@ -189,6 +189,10 @@ __global__ __launch_bounds__(kBlock) void ad_star_kernel(R *__restrict__ out, co
             minus[d] = P[d] > 0 ? -St[d] : 0;
         }
     }
+    if (mphi) {  // the resampled momentum, kept for the backward pass (what interp_forward would have stored)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) mphi[(size_t)vx.n * DIM * nv + (size_t)d * nv + vx.s] = wv[d];
+    }
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
         R gq[DIM];
@@ -205,9 +209,9 @@ __global__ __launch_bounds__(kBlock) void ad_star_kernel(R *__restrict__ out, co
 
 // Unrolled 3D variant: U slabs of 256 consecutive voxels per workgroup, one voxel of each per lane.
 template <typename R, int U>
-__global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__ out, const R *__restrict__ phi,
-                                                                 const R *__restrict__ m, Geom g, uint32_t nbx_u,
-                                                                 uint32_t nblocks_u) {
+__global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__ out, R *__restrict__ mphi,
+                                                                 const R *__restrict__ phi, const R *__restrict__ m,
+                                                                 Geom g, uint32_t nbx_u, uint32_t nblocks_u) {
     const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
     const uint32_t n = Lb / nbx_u;  // uniform: scalar division
     const uint32_t bx = Lb - n * nbx_u;
@@ -262,6 +266,14 @@ __global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__
 #pragma unroll
         for (int e = 0; e < U; ++e) wv[d][e] = L[e].value(mn + (size_t)d * nv);
     }
+    if (mphi) {  // the resampled momentum, kept for the backward pass (what interp_forward would have stored)
+        R *mo = mphi + (size_t)n * 3 * nv;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e = 0; e < U; ++e)
+                if (ok[e]) mo[(size_t)d * nv + s[e]] = wv[d][e];
+    }
     // keep the gather phase and the three stencil phases apart: hoisting the 72 stencil loads above
     // the lerps doubled the register count (201 VGPRs, 2 waves/SIMD) for no gain in overlap
     __builtin_amdgcn_sched_barrier(0);
@@ -296,14 +308,15 @@ __global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__
 }
 
 template <typename R>
-static int ad_star_impl(R *out, const R *phi, const R *m, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz,
-                        void *stream) {
+static int ad_star_impl(R *out, R *mphi, const R *phi, const R *m, int dim, int64_t nn, int64_t nx, int64_t ny,
+                        int64_t nz, void *stream) {
     if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional fields are supported");
     Geom g;
     if (!make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("ad_star: bad extent");
     if (g.nblocks == 0) return LAGO_OK;
     if (!out || !phi || !m) return fail_invalid("ad_star: null pointer");
-    if (out == phi || out == m) return fail_invalid("ad_star: out may not alias an input");
+    if (out == phi || out == m || (mphi && (mphi == phi || mphi == m || mphi == out)))
+        return fail_invalid("ad_star: outputs may not alias an input or each other");
     if (nx <= 1 || ny <= 1 || (dim == 3 && nz <= 1))
         return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
     hipStream_t s = (hipStream_t)stream;
@@ -312,15 +325,15 @@ static int ad_star_impl(R *out, const R *phi, const R *m, int dim, int64_t nn, i
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
         if (nb < (1ull << 31)) {
-            hipLaunchKernelGGL((ad_star3_unroll_kernel<R, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, phi, m, g,
+            hipLaunchKernelGGL((ad_star3_unroll_kernel<R, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, mphi, phi, m, g,
                                nbx_u, (uint32_t)nb);
             return finish_launch(s, "ad_star");
         }
     }
     if (dim == 3)
-        hipLaunchKernelGGL((ad_star_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, phi, m, g);
+        hipLaunchKernelGGL((ad_star_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, mphi, phi, m, g);
     else
-        hipLaunchKernelGGL((ad_star_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, out, phi, m, g);
+        hipLaunchKernelGGL((ad_star_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, out, mphi, phi, m, g);
     return finish_launch(s, "ad_star");
 }
 
@@ -335,12 +348,12 @@ int lago_compose_f64(double *out, const double *u, const double *v, double ds, d
                      int64_t nx, int64_t ny, int64_t nz, void *stream) {
     return lago::compose_impl<double>(out, u, v, ds, dt, dim, nn, nx, ny, nz, stream);
 }
-int lago_Ad_star_f32(float *out, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx, int64_t ny,
-                     int64_t nz, void *stream) {
-    return lago::ad_star_impl<float>(out, phiinv, m, dim, nn, nx, ny, nz, stream);
+int lago_Ad_star_f32(float *out, float *mphi, const float *phiinv, const float *m, int dim, int64_t nn, int64_t nx,
+                     int64_t ny, int64_t nz, void *stream) {
+    return lago::ad_star_impl<float>(out, mphi, phiinv, m, dim, nn, nx, ny, nz, stream);
 }
-int lago_Ad_star_f64(double *out, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx, int64_t ny,
-                     int64_t nz, void *stream) {
-    return lago::ad_star_impl<double>(out, phiinv, m, dim, nn, nx, ny, nz, stream);
+int lago_Ad_star_f64(double *out, double *mphi, const double *phiinv, const double *m, int dim, int64_t nn, int64_t nx,
+                     int64_t ny, int64_t nz, void *stream) {
+    return lago::ad_star_impl<double>(out, mphi, phiinv, m, dim, nn, nx, ny, nz, stream);
 }
 }

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restric
 template <typename R, int DIM, bool BC, bool NEED_I, bool NEED_U>
 __global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I, R *__restrict__ d_u,
                                                             const R *__restrict__ go, const R *__restrict__ I,
-                                                            const R *__restrict__ u, double dt, int nc, Geom g) {
+                                                            const R *__restrict__ u, double dt, int nc, Geom g,
+                                                            int umode, R addgo) {
     const Vox v = locate(g);
     if (!v.valid) return;
     const size_t nv = g.nvox;
@@ -112,6 +113,13 @@ __global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I,
     const R *In = BC ? I : I + (size_t)v.n * nc * nv;
     R *dIn = BC ? d_I : d_I + (size_t)v.n * nc * nv;
     const R *gon = go + (size_t)v.n * nc * nv + v.s;
+    // start value of the thread-owned d_u sum: zero (the reference), the caller's d_u, or addgo * grad_out[component]
+    R u0[3] = {(R)0, (R)0, (R)0};
+    if (NEED_U && umode) {
+        const R *dup = d_u + (size_t)v.n * DIM * nv + v.s;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) u0[d] = umode == 1 ? dup[(size_t)d * nv] : addgo * gon[(size_t)d * nv];
+    }
     if (DIM == 3) {
         R hx = sample_pos<R>(v.i, dt, un[0]);
         R hy = sample_pos<R>(v.j, dt, un[nv]);
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I,
         Lerp3<R> L;
         if (NEED_I) S.setup(hx, hy, hz, g.nx, g.ny, g.nz);
         if (NEED_U) L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
-        R ax = 0, ay = 0, az = 0;
+        R ax = u0[0], ay = u0[1], az = u0[2];
         for (int c = 0; c < nc; ++c) {
             R diff = gon[(size_t)c * nv];
             if (NEED_I) {
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I,
         Lerp2<R> L;
         if (NEED_I) S.setup(hx, hy, g.ny, g.nz);
         if (NEED_U) L.setup(hx, hy, g.ny, g.nz);
-        R ax = 0, ay = 0;
+        R ax = u0[0], ay = u0[1];
         for (int c = 0; c < nc; ++c) {
             R diff = gon[(size_t)c * nv];
             if (NEED_I) {
@@ -240,10 +248,10 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
 
 template <typename R, int DIM, bool BC>
 static void launch_bwd(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, const Geom &g,
-                       bool need_I, bool need_u, hipStream_t s) {
+                       bool need_I, bool need_u, int umode, double addgo, hipStream_t s) {
 #define LAUNCH(NI, NU)                                                                                          \
     hipLaunchKernelGGL((interp_bwd_kernel<R, DIM, BC, NI, NU>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, d_u, \
-                       go, I, u, dt, nc, g)
+                       go, I, u, dt, nc, g, umode, (R)addgo)
     if (need_I && need_u) LAUNCH(true, true);
     else if (need_I) LAUNCH(true, false);
     else if (need_u) LAUNCH(false, true);
@@ -252,14 +260,17 @@ static void launch_bwd(R *d_I, R *d_u, const R *go, const R *I, const R *u, doub
 
 template <typename R>
 int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
-                        const Geom &g, bool bc, bool need_u, hipStream_t s);  // splat.hip
+                        const Geom &g, bool bc, bool need_u, int umode, double addgo, hipStream_t s);  // splat.hip
 
 template <typename R>
 static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int dim,
                                 int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc, int need_I,
-                                int need_u, void *stream) {
+                                int need_u, void *stream, int umode = 0, double addgo = 0.0) {
     if (dim != 2 && dim != 3)
         return fail_invalid("Only two- and three-dimensional interpolation is supported");
+    if (umode < 0 || umode > 2 || (umode == 2 && nc != dim))
+        return fail_invalid("interp_backward_fused: u_mode must be 0, 1 or 2 (2 needs as many channels as dimensions)");
+    if (umode && !need_u) return fail_invalid("interp_backward_fused: u_mode != 0 needs need_u");
     Geom g;
     if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("interp_backward: bad extent");
     hipStream_t s = (hipStream_t)stream;
@@ -271,19 +282,19 @@ static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R
     if (nI) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
     if (!need_u && nu) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
     if (g.nblocks == 0 || nc == 0 || !(need_I || need_u)) {
-        if (need_u && nu) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
+        if (need_u && nu && umode != 1) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
         return finish_launch(s, "interp_backward");
     }
     if (dim == 3 && need_I && g_splat_mode >= 1) {
-        int rc = interp_backward_lds<R>(d_I, d_u, go, I, u, dt, (int)nc, nn, g, bc != 0, need_u != 0, s);
+        int rc = interp_backward_lds<R>(d_I, d_u, go, I, u, dt, (int)nc, nn, g, bc != 0, need_u != 0, umode, addgo, s);
         if (rc != 1) return rc;  // 1 = shape not supported by the tiled kernel, fall through
     }
     if (dim == 3) {
-        if (bc) launch_bwd<R, 3, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
-        else launch_bwd<R, 3, false>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
+        if (bc) launch_bwd<R, 3, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, umode, addgo, s);
+        else launch_bwd<R, 3, false>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, umode, addgo, s);
     } else {
-        if (bc) launch_bwd<R, 2, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
-        else launch_bwd<R, 2, false>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, s);
+        if (bc) launch_bwd<R, 2, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, umode, addgo, s);
+        else launch_bwd<R, 2, false>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, umode, addgo, s);
     }
     return finish_launch(s, "interp_backward");
 }
@@ -316,6 +327,12 @@ extern "C" {
                                   int need_I, int need_u, void *stream) {                                         \
         return lago::interp_backward_impl<REAL>(d_I, d_u, go, I, u, dt, dim, nn, nc, nx, ny, nz, bc, need_I,      \
                                                 need_u, stream);                                                  \
+    }                                                                                                              \
+    int lago_interp_backward_fused##SUF(REAL *d_I, REAL *d_u, const REAL *go, const REAL *I, const REAL *u,       \
+                                        double dt, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny,       \
+                                        int64_t nz, int bc, int need_I, int u_mode, double addgo, void *stream) { \
+        return lago::interp_backward_impl<REAL>(d_I, d_u, go, I, u, dt, dim, nn, nc, nx, ny, nz, bc, need_I, 1,   \
+                                                stream, u_mode, addgo);                                           \
     }                                                                                                              \
     int lago_interp_hessian_diagonal_image##SUF(REAL *out, const REAL *u, double dt, int64_t nI, int64_t nn,      \
                                                 int64_t nc, int64_t nx, int64_t ny, void *stream) {               \

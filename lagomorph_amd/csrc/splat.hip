@@ -45,6 +45,10 @@ enum { POS_DISP_UNIT = 3,  // POS_DISP with dt == +-1 in float: positions are on
 struct PosArgs {
     const void *u, *A, *T;
     double dt, O[3], S[3];
+    // how d_u starts (fused backward forms, include/lagomorph_hip.h lago_interp_backward_fused): 0 from zero (the
+    // reference), 1 from the caller's d_u contents, 2 from addgo * grad_out[component] (needs nc == 3)
+    int umode;
+    double addgo;
 };
 
 struct TileGeom {
@@ -247,6 +251,12 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
             hy[e] = sample_pos_t<R, MODE == POS_DISP_UNIT>(vj, dt, un[sv[e] + nv]);
             hz[e] = sample_pos_t<R, MODE == POS_DISP_UNIT>(vk, dt, un[sv[e] + 2 * nv]);
             dux[e] = duy[e] = duz[e] = (R)0;
+            if (pa.umode == 1) {
+                dux[e] = dun[sv[e]]; duy[e] = dun[sv[e] + nv]; duz[e] = dun[sv[e] + 2 * nv];
+            } else if (pa.umode == 2) {
+                const R ag = (R)pa.addgo;
+                dux[e] = ag * gon[sv[e]]; duy[e] = ag * gon[snv + sv[e]]; duz[e] = ag * gon[2 * snv + sv[e]];
+            }
         }
         Lerp3<R, false> Lq[VPL];  // gather geometry: once per voxel, reused by every channel (nz >= 2: host)
 #pragma unroll
@@ -315,10 +325,17 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                     uz[e] = un[sv[e] + 2 * nv];
                 }
                 gv[e] = gc[sv[e]];
-                if (NEED_U && c > 0) {
-                    dux[e] = dun[sv[e]];
-                    duy[e] = dun[sv[e] + nv];
-                    duz[e] = dun[sv[e] + 2 * nv];
+                if (NEED_U) {
+                    if (c > 0 || pa.umode == 1) {
+                        dux[e] = dun[sv[e]];
+                        duy[e] = dun[sv[e] + nv];
+                        duz[e] = dun[sv[e] + 2 * nv];
+                    } else if (pa.umode == 2) {
+                        const R ag = (R)pa.addgo;
+                        dux[e] = ag * gon[sv[e]]; duy[e] = ag * gon[snv + sv[e]]; duz[e] = ag * gon[2 * snv + sv[e]];
+                    } else {
+                        dux[e] = duy[e] = duz[e] = (R)0;
+                    }
                 }
             }
 #pragma unroll
@@ -340,9 +357,9 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
                     R gx, gy, gz;
                     Lq.grad(Ic, gx, gy, gz);
                     diff = (R)((double)diff * dt);  // cuda/interp.cu:230
-                    dun[sv[e]] = lg_fma(gx, diff, c == 0 ? (R)0 : dux[e]);
-                    dun[sv[e] + nv] = lg_fma(gy, diff, c == 0 ? (R)0 : duy[e]);
-                    dun[sv[e] + 2 * nv] = lg_fma(gz, diff, c == 0 ? (R)0 : duz[e]);
+                    dun[sv[e]] = lg_fma(gx, diff, dux[e]);
+                    dun[sv[e] + nv] = lg_fma(gy, diff, duy[e]);
+                    dun[sv[e] + 2 * nv] = lg_fma(gz, diff, duz[e]);
                 }
             }
         }
@@ -393,7 +410,8 @@ __device__ __forceinline__ float shear_pos(int base, double dt, float u) {
 template <int NT, bool NEED_U, bool UNIT, bool BC>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat_shear_kernel(float *__restrict__ d_I, float *__restrict__ d_u,
                                                          const float *__restrict__ go, const float *__restrict__ I,
-                                                         const float *__restrict__ u, double dt, int nc, ShearGeom sg) {
+                                                         const float *__restrict__ u, double dt, int nc, ShearGeom sg,
+                                                         int umode, float addgo) {
     extern __shared__ __align__(16) unsigned char lago_smem[];
     double *win = reinterpret_cast<double *>(lago_smem);
     int2 *org = reinterpret_cast<int2 *>(lago_smem + (size_t)sg.win_cells * 8);  // (x, y) origin per z segment
@@ -541,10 +559,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
                 }
                 // cuda/interp.cu:230: (Real)((double)diff * dt); for dt = +-1 that is +-diff exactly
                 const float diff = UNIT ? (float)dt * gv : (float)((double)gv * dt);
-                // ascending channel order, as the reference's thread-owned accumulation
-                dun[sv] = lg_fma(gx, diff, c > 0 ? dun[sv] : 0.f);
-                dun[sv + nv] = lg_fma(gy, diff, c > 0 ? dun[sv + nv] : 0.f);
-                dun[sv + 2 * (size_t)nv] = lg_fma(gz, diff, c > 0 ? dun[sv + 2 * (size_t)nv] : 0.f);
+                // ascending channel order, as the reference's thread-owned accumulation; the start value is zero
+                // for the reference operator, the caller's d_u or addgo * grad_out for the fused backward forms
+                float ix = 0.f, iy = 0.f, iz = 0.f;
+                if (c > 0 || umode == 1) {
+                    ix = dun[sv]; iy = dun[sv + nv]; iz = dun[sv + 2 * (size_t)nv];
+                } else if (umode == 2) {
+                    ix = addgo * gon[sv]; iy = addgo * gon[sv + nv]; iz = addgo * gon[sv + 2 * (size_t)nv];
+                }
+                dun[sv] = lg_fma(gx, diff, ix);
+                dun[sv + nv] = lg_fma(gy, diff, iy);
+                dun[sv + 2 * (size_t)nv] = lg_fma(gz, diff, iz);
             }
         }
         __syncthreads();
@@ -625,7 +650,7 @@ static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem) {
 
 template <int NT>
 static hipError_t launch_shear(float *d_I, float *d_u, const float *go, const float *I, const float *u, double dt, int nc,
-                               const ShearGeom &sg, size_t smem, bool bc, bool need_u, hipStream_t s) {
+                               const ShearGeom &sg, size_t smem, bool bc, bool need_u, int umode, float addgo, hipStream_t s) {
     const bool unit = unit_dt<float>(dt);
 #define LAGO_SHEAR(NU, UN, B)                                                                                     \
     do {                                                                                                          \
@@ -635,7 +660,7 @@ static hipError_t launch_shear(float *d_I, float *d_u, const float *go, const fl
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
             if (e != hipSuccess) return e;                                                                        \
         }                                                                                                         \
-        hipLaunchKernelGGL(k, dim3(sg.total), dim3(NT), smem, s, d_I, d_u, go, I, u, dt, nc, sg);                 \
+        hipLaunchKernelGGL(k, dim3(sg.total), dim3(NT), smem, s, d_I, d_u, go, I, u, dt, nc, sg, umode, addgo);   \
     } while (0)
     if (need_u) {
         if (unit) { if (bc) LAGO_SHEAR(true, true, true); else LAGO_SHEAR(true, true, false); }
@@ -651,15 +676,15 @@ static hipError_t launch_shear(float *d_I, float *d_u, const float *go, const fl
 // float32 displacement splat through the sheared-window kernel; returns 1 when the shape is left to the
 // general tiled kernel.
 static int interp_backward_shear(float *d_I, float *d_u, const float *go, const float *I, const float *u, double dt,
-                                 int nc, int64_t nn, const Geom &g, bool bc, bool need_u, hipStream_t s) {
+                                 int nc, int64_t nn, const Geom &g, bool bc, bool need_u, int umode, float addgo, hipStream_t s) {
     if (!g_shear_on) return 1;
     ShearGeom sg;
     size_t smem;
     if (!make_shear(sg, g, nn, smem)) return 1;
     hipError_t e;
-    if (g_shear_nt >= 1024) e = launch_shear<1024>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, s);
-    else if (g_shear_nt >= 512) e = launch_shear<512>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, s);
-    else e = launch_shear<256>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, s);
+    if (g_shear_nt >= 1024) e = launch_shear<1024>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
+    else if (g_shear_nt >= 512) e = launch_shear<512>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
+    else e = launch_shear<256>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
     if (e != hipSuccess) return fail_hip(e, "interp_backward (sheared-window splat)");
     return finish_launch(s, "interp_backward (sheared-window splat)");
 }
@@ -770,7 +795,7 @@ static hipError_t by_threads(R *d_I, R *d_u, const R *go, const R *I, const PosA
 // The caller has already zeroed d_I (and d_u when it is not needed).
 template <typename R>
 int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
-                        const Geom &g, bool bc, bool need_u, hipStream_t s) {
+                        const Geom &g, bool bc, bool need_u, int umode, double addgo, hipStream_t s) {
     constexpr int V = 4;
     const bool vec = g_interp_vec != 0;
     TileGeom tg;
@@ -780,7 +805,7 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     if constexpr (sizeof(R) == 4) {
         if (vec && !(g_splat_mc && need_u && nc > 1)) {
             const int rc = interp_backward_shear((float *)d_I, (float *)d_u, (const float *)go, (const float *)I,
-                                                 (const float *)u, dt, nc, nn, g, bc, need_u, s);
+                                                 (const float *)u, dt, nc, nn, g, bc, need_u, umode, (float)addgo, s);
             if (rc != 1) return rc;
         }
     }
@@ -788,6 +813,8 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     PosArgs pa{};
     pa.u = u;
     pa.dt = dt;
+    pa.umode = umode;
+    pa.addgo = addgo;
     hipError_t e;
     const bool unit = unit_dt<R>(dt);
     // several channels with d_u wanted: the single-pass multi-channel form when one workgroup pass
@@ -864,9 +891,9 @@ int regrid_splat_lds(R *d_I, const R *go, int64_t nplanes, const Geom &g, const 
 }
 
 template int interp_backward_lds<float>(float *, float *, const float *, const float *, const float *, double, int,
-                                        int64_t, const Geom &, bool, bool, hipStream_t);
+                                        int64_t, const Geom &, bool, bool, int, double, hipStream_t);
 template int interp_backward_lds<double>(double *, double *, const double *, const double *, const double *, double,
-                                         int, int64_t, const Geom &, bool, bool, hipStream_t);
+                                         int, int64_t, const Geom &, bool, bool, int, double, hipStream_t);
 template int affine_splat_lds<float>(float *, const float *, const float *, const float *, int, int64_t, const Geom &,
                                      bool, hipStream_t);
 template int affine_splat_lds<double>(double *, const double *, const double *, const double *, int, int64_t,

@@ -62,10 +62,15 @@ class ComposeFunction(torch.autograd.Function):
     def backward(ctx, gradout):
         u, v = ctx.saved_tensors
         gradout = gradout.contiguous()
+        need_u, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_u and ctx.dt == 1.0 and hasattr(lagomorph_ext, "interp_backward_fused"):
+            # d_u = (D_u interp)^T grad + ds * grad in one kernel (the sum of each voxel's d_u starts from ds * grad)
+            d_v, d_u = lagomorph_ext.interp_backward_fused(gradout, v.contiguous(), u.contiguous(), ctx.ds, need_v,
+                                                           addgo=ctx.ds)
+            return d_u, d_v if need_v else None, None, None
         gi = gradout if ctx.dt == 1.0 else ctx.dt * gradout  # gradient reaching the interp output
-        d_v, d_u = lagomorph_ext.interp_backward(gi, v.contiguous(), u.contiguous(), ctx.ds,
-                                                 ctx.needs_input_grad[1], ctx.needs_input_grad[0])
-        if ctx.needs_input_grad[0]:
+        d_v, d_u = lagomorph_ext.interp_backward(gi, v.contiguous(), u.contiguous(), ctx.ds, need_v, need_u)
+        if need_u:
             d_u.add_(gradout, alpha=ctx.ds)  # d_u is a fresh tensor owned by this call
         return d_u, d_v, None, None
 

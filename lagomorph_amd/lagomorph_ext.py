@@ -51,7 +51,9 @@ _SIGS = {
     "lago_regrid_forward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
-    "lago_Ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
+    "lago_Ad_star": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
+    "lago_interp_backward_fused": [_vp, _vp, _vp, _vp, _vp, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _dbl,
+                                   _vp],
     "lago_ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_fluid_metric": [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64,
                           _i64, _i64, _vp],
@@ -423,9 +425,48 @@ def compose(u, v, ds=1.0, dt=1.0):
     return out
 
 
-def Ad_star(phiinv, m):
+def interp_backward_fused(grad_out, I, u, dt, need_I, d_u=None, addgo=None):
+    """interp_backward whose d_u sum starts from the contents of `d_u` (given: accumulated in place and returned)
+    or from addgo * grad_out (needs as many channels as dimensions) instead of zero -- the chain-rule additions of
+    compose's and Ad_star's backward without their extra passes.  Returns [d_I, d_u].  Not part of the reference's
+    extension surface (include/lagomorph_hip.h: lago_interp_backward_fused)."""
+    _check_input(grad_out, "grad_out")
+    _check_input(I, "I")
+    _check_input(u, "u")
+    _same(I, u, grad_out)
+    dim, nx, ny, nz = _spatial(I)
+    if dim not in (2, 3):
+        raise RuntimeError("Only two- and three-dimensional interpolation is supported")
+    nn = max(u.size(0), I.size(0))
+    bc = I.size(0) < nn
+    if (bc and I.size(0) != 1) or u.size(0) != nn:
+        raise RuntimeError("interp_backward: batch sizes of I and u are incompatible")
+    if (tuple(grad_out.shape) != (nn, I.size(1)) + tuple(I.shape[2:]) or u.dim() != I.dim() or u.size(1) != dim
+            or tuple(u.shape[2:]) != tuple(I.shape[2:])):
+        raise RuntimeError("interp_backward: grad_out / I / u shapes are inconsistent")
+    if (d_u is None) == (addgo is None):
+        raise RuntimeError("interp_backward_fused: give exactly one of d_u (accumulate) and addgo")
+    if d_u is not None:
+        _check_input(d_u, "d_u")
+        _same(u, d_u)
+        if d_u.shape != u.shape:
+            raise RuntimeError("interp_backward_fused: d_u must have the shape of u")
+        mode, ag = 1, 0.0
+    else:
+        if I.size(1) != dim:
+            raise RuntimeError("interp_backward_fused: addgo needs as many channels as dimensions")
+        d_u = torch.empty_like(u)
+        mode, ag = 2, float(addgo)
+    d_I = torch.empty_like(I)
+    _call("lago_interp_backward_fused", I, _ptr(d_I), _ptr(d_u), _ptr(grad_out), _ptr(I), _ptr(u), float(dt), dim, nn,
+          I.size(1), nx, ny, nz, int(bc), int(bool(need_I)), mode, ag)
+    return [d_I, d_u]
+
+
+def Ad_star(phiinv, m, save_resampled=False):
     """Fused adjrep.Ad_star (adjrep.py:86-97): jacobian_times_vectorfield(phiinv, interp(m, phiinv),
-    displacement=True) in one kernel.  Not part of the reference's extension surface."""
+    displacement=True) in one kernel.  Not part of the reference's extension surface.  With save_resampled the
+    resampled momentum interp(m, phiinv) is returned as well: (out, mphiinv)."""
     _check_input(phiinv, "phiinv")
     _check_input(m, "m")
     _same(phiinv, m)
@@ -435,8 +476,9 @@ def Ad_star(phiinv, m):
     if phiinv.shape != m.shape or m.size(1) != dim:
         raise RuntimeError("Ad_star: phiinv and m must be vector fields of the same shape")
     out = torch.empty_like(m)
-    _call("lago_Ad_star", m, _ptr(out), _ptr(phiinv), _ptr(m), dim, m.size(0), nx, ny, nz)
-    return out
+    mphi = torch.empty_like(m) if save_resampled else None
+    _call("lago_Ad_star", m, _ptr(out), _ptr(mphi), _ptr(phiinv), _ptr(m), dim, m.size(0), nx, ny, nz)
+    return (out, mphi) if save_resampled else out
 
 
 def ad_star(v, m):

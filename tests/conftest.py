@@ -61,6 +61,7 @@ def oracle_ext(monkeypatch):
         "fluid_operator", "affine_interp_forward", "affine_interp_backward", "regrid_forward", "regrid_backward",
     ):
         monkeypatch.setattr(mod, name, getattr(ext, name))
+    monkeypatch.delattr(mod, "interp_backward_fused")
     monkeypatch.delattr(mod, "fluid_metric")  # the host mirror then takes its rfft / fluid_operator / irfft form
     monkeypatch.delattr(mod, "Ad_star")
     monkeypatch.delattr(mod, "ad_star")       # ... and Ad_star its interp + jacobian_times_vectorfield form

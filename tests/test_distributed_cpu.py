@@ -22,6 +22,7 @@ def _patch_oracle():
                  "jacobian_times_vectorfield_backward", "jacobian_times_vectorfield_adjoint_forward",
                  "jacobian_times_vectorfield_adjoint_backward", "fluid_operator", "regrid_forward", "regrid_backward"):
         setattr(lm.lagomorph_ext, name, getattr(o, name))
+    delattr(lm.lagomorph_ext, "interp_backward_fused")
     delattr(lm.lagomorph_ext, "fluid_metric")
     delattr(lm.lagomorph_ext, "Ad_star")
     delattr(lm.lagomorph_ext, "ad_star")

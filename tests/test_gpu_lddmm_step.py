@@ -26,7 +26,7 @@ class oracle_backend:
         for n in ORACLE_NAMES:
             self.saved[n] = getattr(lm.lagomorph_ext, n)
             setattr(lm.lagomorph_ext, n, getattr(o, n))
-        for n in ("fluid_metric", "Ad_star", "ad_star"):
+        for n in ("fluid_metric", "Ad_star", "ad_star", "interp_backward_fused"):
             self.removed[n] = getattr(lm.lagomorph_ext, n)
             delattr(lm.lagomorph_ext, n)
         return lm

@@ -605,3 +605,76 @@ def test_interp_backward_rejects_bad_broadcast(ext):
         ext.interp_backward(go, I, u, 1.0, True, True)
     with pytest.raises(RuntimeError, match="inconsistent"):
         ext.interp_backward(go, I[:1], torch.zeros((3, 3, 4, 4, 5), device="cuda"), 1.0, True, True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(6, 5, 8), (7, 9), (4, 3, 70), (12, 10, 40), (3, 4, 1)])
+@pytest.mark.parametrize("dt", [1.0, -0.3])
+def test_interp_backward_fused_start_values(ext, dtype, sp, dt):
+    """lago_interp_backward_fused: d_I is that of interp_backward; d_u is the reference's thread-owned sum started
+    from the caller's d_u (u_mode 1) or from addgo * grad_out (u_mode 2) instead of zero.  With a zero start it is the
+    reference operator bit for bit; otherwise it equals `start + d_u` to rounding (one summation order differs)."""
+    rng = np.random.default_rng(hash((sp, dt)) % 2**31)
+    d = len(sp)
+    u = _disp(rng, 2, sp, dtype)
+    for nc, bc in ((d, False), (1, False), (2, True)):
+        I = rnd(rng, (1 if bc else 2, nc) + sp, dtype)
+        go = rnd(rng, (2, nc) + sp, dtype)
+        oI, ou = orc.interp_backward(go, I, u, dt, True, True)
+        start = rnd(rng, (2, d) + sp, dtype)
+        # accumulate onto zeros == the reference operator, bit for bit
+        dI0, du0 = ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, True, d_u=torch.zeros_like(dev(u)))
+        assert_bits(du0, ou, "fused, zero start")
+        assert_close(dI0, oI, dtype, "fused d_I", mult=4.0)
+        dI1, du1 = ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, True, d_u=dev(start))
+        scale = np.abs(ou).max() + np.abs(start).max()
+        assert_close(du1, start.astype(np.float64) + ou, dtype, "fused, accumulate", scale=scale, mult=4.0)
+        assert_close(dI1, oI, dtype, "fused d_I (accumulate)", mult=4.0)
+        if nc == d:
+            _, du2 = ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, False, addgo=0.37)
+            k = go.dtype.type
+            assert_close(du2, (k(0.37) * go).astype(np.float64) + ou, dtype, "fused, addgo",
+                         scale=np.abs(ou).max() + np.abs(go).max(), mult=4.0)
+    with pytest.raises(RuntimeError, match="exactly one"):
+        ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, True)
+    with pytest.raises(RuntimeError, match="as many channels"):
+        ext.interp_backward_fused(dev(rnd(rng, (2, d + 1) + sp, dtype)), dev(rnd(rng, (2, d + 1) + sp, dtype)), dev(u), dt, True, addgo=1.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(5, 6, 7), (7, 9), (4, 3, 64), (20, 12, 40)])
+def test_ad_star_saves_the_resampled_momentum(ext, dtype, sp):
+    """Ad_star(save_resampled=True) also returns interp_forward(m, phiinv), bit for bit, and the same product."""
+    rng = np.random.default_rng(hash(sp) % 2**31)
+    d = len(sp)
+    phi = _disp(rng, 2, sp, dtype)
+    m = rnd(rng, (2, d) + sp, dtype)
+    for vec in (1, 0):
+        ext.set_vector_kernels(vec)
+        try:
+            out, mphi = ext.Ad_star(dev(phi), dev(m), save_resampled=True)
+            plain = ext.Ad_star(dev(phi), dev(m))
+        finally:
+            ext.set_vector_kernels(1)
+        assert_bits(mphi, orc.interp_forward(m, phi, 1.0), "resampled momentum")
+        assert torch.equal(out, plain)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(6, 5, 8), (7, 9), (10, 12, 40)])
+def test_fused_compose_backward_matches_unfused(ext, dtype, sp):
+    """ComposeFunction.backward (one splat kernel whose d_u sum starts from ds * grad) == autograd through
+    ds*u + dt*interp(v, u, ds)."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(6)
+    d = len(sp)
+    u0, v0 = dev(0.8 * rnd(rng, (2, d) + sp, dtype)), dev(rnd(rng, (2, d) + sp, dtype))
+    go = dev(rnd(rng, (2, d) + sp, dtype))
+    for ds, dt in ((-0.2, 1.0), (1.0, 1.0), (0.5, -0.7)):
+        a, b = u0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+        lm.compose(a, b, ds=ds, dt=dt).backward(go)
+        p, q = u0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+        (ds * p + dt * lm.interp(q, p, dt=ds)).backward(go)
+        assert_close(a.grad, host(p.grad), dtype, f"compose d_u ds={ds} dt={dt}", mult=4.0)
+        assert_close(b.grad, host(q.grad), dtype, f"compose d_v ds={ds} dt={dt}", mult=4.0)
