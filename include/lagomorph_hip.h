@@ -62,7 +62,8 @@ void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nth
 /* 1 (default): use the slab-unrolled 3D gather kernels (two voxels per lane) when the shape allows; 0: one-voxel-per-lane kernels only. */
 void lago_set_vector_kernels(int on);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
- * (nx in {64,128,256}, ny in {32..256}, nz in {64..256}, powers of two, ny*nz <= 2^15); 1: rocFFT 2D (y, z)
+ * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
+ * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z)
  * plan + fused x-axis pass (nx in {64,128,256}); 0: rocFFT 3D plan + operator kernel.  A mode falls back
  * to the next lower one for shapes it does not support.  Results agree to rounding. */
 void lago_set_fluid_xpass(int mode);

@@ -1,4 +1,4 @@
-// FluidMetric sharp/flat as three LDS-tiled passes (float32, 3D, power-of-two extents), gfx950.
+// FluidMetric sharp/flat as three LDS-tiled passes (float32, 3D, extents 2^a, 3*2^a, 5*2^a), gfx950.
 // The transforms and the per-frequency operator are in fft_lds.hpp (host-verifiable phase
 // functions); this file holds the kernels around them and the launch logic.
 //
@@ -13,12 +13,24 @@
 
 namespace lago {
 
-// threads per plane: 1024 once a plane has at least 2048 float4 (two per thread)
-constexpr int zy_threads(int logny, int lognz) { return logny + lognz >= 13 ? 1024 : 512; }
+// transform length -> its factorisation R * 2^L2 (fft_lds.hpp)
+template <int N> struct SzOf;
+template <> struct SzOf<32> { using T = fl::Sz<1, 5>; };
+template <> struct SzOf<48> { using T = fl::Sz<3, 4>; };
+template <> struct SzOf<64> { using T = fl::Sz<1, 6>; };
+template <> struct SzOf<80> { using T = fl::Sz<5, 4>; };
+template <> struct SzOf<96> { using T = fl::Sz<3, 5>; };
+template <> struct SzOf<128> { using T = fl::Sz<1, 7>; };
+template <> struct SzOf<160> { using T = fl::Sz<5, 5>; };
+template <> struct SzOf<192> { using T = fl::Sz<3, 6>; };
+template <> struct SzOf<256> { using T = fl::Sz<1, 8>; };
 
-template <int LOGNY, int LOGNZ>
-__global__ __launch_bounds__(zy_threads(LOGNY, LOGNZ)) void zy_forward_kernel(fl::ZYArgs a) {
-    using K = fl::ZY<LOGNY, LOGNZ, zy_threads(LOGNY, LOGNZ)>;
+template <int NY, int NZ>
+using ZYK = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T>;
+
+template <int NY, int NZ>
+__global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_kernel(fl::ZYArgs a) {
+    using K = ZYK<NY, NZ>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
     const size_t p = blockIdx.x;
@@ -31,9 +43,9 @@ __global__ __launch_bounds__(zy_threads(LOGNY, LOGNZ)) void zy_forward_kernel(fl
     }
 }
 
-template <int LOGNY, int LOGNZ>
-__global__ __launch_bounds__(zy_threads(LOGNY, LOGNZ)) void zy_inverse_kernel(fl::ZYArgs a) {
-    using K = fl::ZY<LOGNY, LOGNZ, zy_threads(LOGNY, LOGNZ)>;
+template <int NY, int NZ>
+__global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_kernel(fl::ZYArgs a) {
+    using K = ZYK<NY, NZ>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
     const size_t p = blockIdx.x;
@@ -46,9 +58,9 @@ __global__ __launch_bounds__(zy_threads(LOGNY, LOGNZ)) void zy_inverse_kernel(fl
     }
 }
 
-template <int LOGNX, bool INV>
+template <int NX, bool INV>
 __global__ __launch_bounds__(256) void fluid_xpass2_kernel(fl::XArgs a) {
-    using K = fl::XPass<LOGNX, INV, 256>;
+    using K = fl::XPass<typename SzOf<NX>::T, INV, 256>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *buf = reinterpret_cast<float2 *>(lago_smem), *tw = buf + 3 * K::NX * K::KCP;
     const uint32_t blk = xcd_swizzle(blockIdx.x, a.total);
@@ -70,15 +82,25 @@ __global__ __launch_bounds__(256) void fluid_xpass2_kernel(fl::XArgs a) {
 
 // ---- host side ---------------------------------------------------------------------------------
 
-static int ilog2(int64_t v) {
-    int l = 0;
-    while ((1ll << l) < v) ++l;
-    return (1ll << l) == v ? l : -1;
-}
+// (ny, nz) planes the zy passes are instantiated for: every pair of {64, 96, 128, 160, 192} (160^3 is the volume of
+// BASELINE configs[4]), plus the power-of-two shapes of round 1 with ny = 32 / 256 or nz = 256.  The plane
+// ny * (nz/2 + 1) complex must fit the 160 KB of LDS together with the lcm(ny, nz)-entry twiddle table.
+#define LAGO_ZY_SHAPES(X)                                                                              \
+    X(64, 64) X(64, 96) X(64, 128) X(64, 160) X(64, 192) X(96, 64) X(96, 96) X(96, 128) X(96, 160) X(96, 192)      \
+    X(128, 64) X(128, 96) X(128, 128) X(128, 160) X(128, 192) X(160, 64) X(160, 96) X(160, 128) X(160, 160) X(160, 192) \
+    X(192, 64) X(192, 96) X(192, 128) X(192, 160) X(192, 192)                                          \
+    X(32, 64) X(32, 128) X(32, 256) X(64, 256) X(128, 256) X(256, 64) X(256, 128)
+#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256)
 
 bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz) {
-    const int lx = ilog2(nx), ly = ilog2(ny), lz = ilog2(nz);
-    return lx >= 6 && lx <= 8 && ly >= 5 && ly <= 8 && lz >= 6 && lz <= 8 && ly + lz <= 15;
+    bool okx = false, okyz = false;
+#define X(N) okx = okx || nx == N;
+    LAGO_X_SIZES(X)
+#undef X
+#define X(NY, NZ) okyz = okyz || (ny == NY && nz == NZ);
+    LAGO_ZY_SHAPES(X)
+#undef X
+    return okx && okyz;
 }
 
 template <typename Kern>
@@ -88,60 +110,56 @@ static hipError_t allow_smem(Kern k, size_t smem) {
                                (int)smem);
 }
 
-template <int LY, int LZ>
+template <int NY, int NZ>
 static hipError_t zy_launch(const fl::ZYArgs &a, bool inverse, hipStream_t s) {
-    constexpr int NT = zy_threads(LY, LZ);
-    using K = fl::ZY<LY, LZ, NT>;
+    using K = ZYK<NY, NZ>;
+    static_assert(K::SMEM <= 160 * 1024, "plane does not fit the LDS");
     if (inverse) {
-        auto k = zy_inverse_kernel<LY, LZ>;
+        auto k = zy_inverse_kernel<NY, NZ>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
+        hipLaunchKernelGGL(k, dim3(a.total), dim3(K::THREADS), K::SMEM, s, a);
     } else {
-        auto k = zy_forward_kernel<LY, LZ>;
+        auto k = zy_forward_kernel<NY, NZ>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
+        hipLaunchKernelGGL(k, dim3(a.total), dim3(K::THREADS), K::SMEM, s, a);
     }
     return hipSuccess;
 }
 
-template <int LY>
-static hipError_t zy_by_z(int lz, const fl::ZYArgs &a, bool inverse, hipStream_t s) {
-    if (lz == 6) return zy_launch<LY, 6>(a, inverse, s);
-    if (lz == 7) return zy_launch<LY, 7>(a, inverse, s);
-    if constexpr (LY <= 7) {
-        if (lz == 8) return zy_launch<LY, 8>(a, inverse, s);
-    }
+static hipError_t zy_dispatch(int64_t ny, int64_t nz, const fl::ZYArgs &a, bool inverse, hipStream_t s) {
+#define X(NY, NZ) \
+    if (ny == NY && nz == NZ) return zy_launch<NY, NZ>(a, inverse, s);
+    LAGO_ZY_SHAPES(X)
+#undef X
     return hipErrorInvalidValue;
 }
 
-static hipError_t zy_dispatch(int ly, int lz, const fl::ZYArgs &a, bool inverse, hipStream_t s) {
-    switch (ly) {
-        case 5: return zy_by_z<5>(lz, a, inverse, s);
-        case 6: return zy_by_z<6>(lz, a, inverse, s);
-        case 7: return zy_by_z<7>(lz, a, inverse, s);
-        case 8: return zy_by_z<8>(lz, a, inverse, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-template <int LX>
+template <int NX>
 static hipError_t xpass2_launch(const fl::XArgs &a, bool inverse, hipStream_t s) {
     if (inverse) {
-        using K = fl::XPass<LX, true, 256>;
-        auto k = fluid_xpass2_kernel<LX, true>;
+        using K = fl::XPass<typename SzOf<NX>::T, true, 256>;
+        auto k = fluid_xpass2_kernel<NX, true>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(a.total), dim3(256), K::SMEM, s, a);
     } else {
-        using K = fl::XPass<LX, false, 256>;
-        auto k = fluid_xpass2_kernel<LX, false>;
+        using K = fl::XPass<typename SzOf<NX>::T, false, 256>;
+        auto k = fluid_xpass2_kernel<NX, false>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(a.total), dim3(256), K::SMEM, s, a);
     }
     return hipSuccess;
+}
+
+static hipError_t xpass2_dispatch(int64_t nx, const fl::XArgs &a, bool inverse, hipStream_t s) {
+#define X(N) \
+    if (nx == N) return xpass2_launch<N>(a, inverse, s);
+    LAGO_X_SIZES(X)
+#undef X
+    return hipErrorInvalidValue;
 }
 
 int g_xpass_ipw = 2;  // batch items per x-pass workgroup
@@ -151,7 +169,6 @@ int g_native_stage_mask = 7;  // profiling only: bit 0 zy forward, bit 1 x pass,
 // with split = 1).  work: nn*3*nx*ny*(nz/2+1) complex.
 int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
                         int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s) {
-    const int lx = ilog2(nx), ly = ilog2(ny), lz = ilog2(nz);
     const int64_t nzh = nz / 2, planes = nn * 3 * nx;
     const int64_t items = ny * (nzh / 16) + ny / 16;
     if (planes >= (1ll << 31) || nn * items >= (1ll << 31)) return fail_invalid("fluid_metric: batch too large");
@@ -175,15 +192,11 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     xa.ipw = g_xpass_ipw > 0 ? g_xpass_ipw : 1;
     xa.total = (uint32_t)((nn + xa.ipw - 1) / xa.ipw * items);
     hipError_t e = hipSuccess;
-    if (g_native_stage_mask & 1) e = zy_dispatch(ly, lz, za, false, s);
+    if (g_native_stage_mask & 1) e = zy_dispatch(ny, nz, za, false, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy forward)");
-    if (g_native_stage_mask & 2) {
-        if (lx == 6) e = xpass2_launch<6>(xa, inverse != 0, s);
-        else if (lx == 7) e = xpass2_launch<7>(xa, inverse != 0, s);
-        else e = xpass2_launch<8>(xa, inverse != 0, s);
-    }
+    if (g_native_stage_mask & 2) e = xpass2_dispatch(nx, xa, inverse != 0, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (x pass)");
-    if (g_native_stage_mask & 4) e = zy_dispatch(ly, lz, za, true, s);
+    if (g_native_stage_mask & 4) e = zy_dispatch(ny, nz, za, true, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy inverse)");
     return finish_launch(s, "fluid_metric");
 }

@@ -1,4 +1,4 @@
-// LDS-resident FFT building blocks for the fluid metric (float32, power-of-two extents), gfx950.
+// LDS-resident FFT building blocks for the fluid metric (float32, extents 2^a, 3*2^a, 5*2^a), gfx950.
 //
 // FluidMetricOperator.forward of the reference (/root/reference/lagomorph/metric.py:11-19) is
 // rfftn -> per-frequency 3x3 operator (cuda/metric.cu:163-305) -> irfftn.  Here it is three passes
@@ -19,9 +19,11 @@
 // stride stream at the speed of contiguous memory, while the 520 B rows of the usual
 // nz/2+1 layout cost 3x on the write side (partial cache lines).
 //
-// All transforms are radix-2 decimation-in-frequency forward (natural -> bit-reversed order)
-// and decimation-in-time inverse (bit-reversed -> natural), three levels at a time in
-// registers; bit-reversed positions are undone for free when a tile is read from / written to LDS.
+// All transforms are decimation-in-frequency forward (natural -> digit-reversed order) and
+// decimation-in-time inverse (digit-reversed -> natural): one radix-3 or radix-5 level for the
+// lengths 3*2^a / 5*2^a (96, 160, 192: the 160^3 volumes of BASELINE configs[4]), then radix-2 levels
+// three at a time in registers; the permuted positions are undone for free when a tile is read from /
+// written to LDS.
 //
 // Every phase between two workgroup barriers is a function of (phase, thread id) only, so the
 // same code runs on the host with a loop over thread ids (tests/native/fft_emul.hip): the
@@ -41,7 +43,7 @@ LAGO_HD float2 cmul(float2 a, float2 b) {
 LAGO_HD float2 cmulc(float2 a, float2 b) {  // a * conj(b)
     return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
 }
-LAGO_HD int brev(int v, int bits) { return (int)(__builtin_bitreverse32((uint32_t)v) >> (32 - bits)); }
+LAGO_HD int brev(int v, int bits) { return bits ? (int)(__builtin_bitreverse32((uint32_t)v) >> (32 - bits)) : 0; }
 
 LAGO_HD float2 twiddle(int t, int m) {  // exp(-2 pi i t / m)
 #ifdef __HIP_DEVICE_COMPILE__
@@ -54,6 +56,31 @@ LAGO_HD float2 twiddle(int t, int m) {  // exp(-2 pi i t / m)
 #endif
 }
 
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
+
+// A transform length N = R * 2^L2 with R in {1, 3, 5} (64, 96, 128, 160, 192, 256, ...).
+// Forward = decimation in frequency: one radix-R level (R > 1), then the radix-2 levels of the R sub-transforms of
+// 2^L2 points, three at a time in registers.  Frequency k = R*k2 + k1 ends up at position k1*2^L2 + bitrev(k2):
+// the order is never undone in memory, readers and writers of a tile permute for free.  Inverse = the same data
+// flow backwards (decimation in time, conjugated twiddles).
+template <int R_, int L2_>
+struct Sz {
+    static constexpr int R = R_, L2 = L2_, M = 1 << L2_, N = R_ * (1 << L2_);
+    static_assert(R_ == 1 || R_ == 3 || R_ == 5, "radix 1, 3 or 5 times a power of two");
+};
+template <class S>
+LAGO_HD int pos_of(int k) {  // position of frequency k after the forward transform
+    if (S::R == 1) return brev(k, S::L2);
+    return (k % S::R) * S::M + brev(k / S::R, S::L2);
+}
+template <class S>
+LAGO_HD int freq_at(int p) {  // frequency held at position p
+    if (S::R == 1) return brev(p, S::L2);
+    return S::R * brev(p & (S::M - 1), S::L2) + (p >> S::L2);
+}
+
 // radix-2 levels are grouped three at a time, from the largest half down
 constexpr int stage_top(int logn, int g) {
     int top = logn - 1;
@@ -64,33 +91,38 @@ constexpr int stage_s(int logn, int g) {
     const int top = stage_top(logn, g);
     return top < 0 ? 0 : (top + 1 >= 3 ? 3 : top + 1);
 }
-constexpr int stage_count(int logn) { return (logn + 2) / 3; }
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int stage_count2(int logn) { return (logn + 2) / 3; }
+template <class S>
+constexpr int stage_count() { return (S::R > 1 ? 1 : 0) + stage_count2(S::L2); }
 
-// A family of NB * 2^LOGNL transforms of 2^LOGN points in LDS: element i of transform (b, lane)
-// is buf[b*BS + i*ES + lane*LS].  tw[t] = exp(-2 pi i t / 2^LOGM), t < 2^(LOGM-1), LOGM >= LOGN.
-template <int LOGN_, int ES_, int LS_, int LOGNL_, int NB_, int BS_, int LOGM_, int NT_>
+// A family of NB * NL transforms of S::N points in LDS: element i of transform (b, lane) is
+// buf[b*BS + i*ES + lane*LS].  tw[t] = exp(-2 pi i t / LTW), 0 <= t < LTW, with S::N dividing LTW.
+template <class S_, int ES_, int LS_, int NL_, int NB_, int BS_, int LTW_, int NT_>
 struct Xf {
-    static constexpr int LOGN = LOGN_, ES = ES_, LS = LS_, LOGNL = LOGNL_, NB = NB_, BS = BS_, LOGM = LOGM_, NT = NT_;
+    using S = S_;
+    static constexpr int ES = ES_, LS = LS_, NL = NL_, NB = NB_, BS = BS_, LTW = LTW_, NT = NT_;
+    static_assert(LTW_ % S_::N == 0, "the twiddle table must hold the N-th roots of unity");
 };
 
-// Stage G of transform family X: S = stage_s radix-2 levels (halves 2^TOP .. 2^(TOP-S+1)) on
-// 2^S elements spaced 2^(TOP-S+1) apart, in registers.  FWD: decimation in frequency; !FWD:
-// decimation in time with conjugated twiddles (same data flow backwards).
+// Radix-2 stage G of the 2^L2-point sub-transforms of family X: S = stage_s levels (halves 2^TOP .. 2^(TOP-S+1)) on
+// 2^S elements spaced 2^(TOP-S+1) apart, in registers.  FWD: decimation in frequency; !FWD: decimation in time
+// with conjugated twiddles.
 template <class X, int G, bool FWD>
-LAGO_HD void radix_stage(float2 *buf, const float2 *tw, int tid) {
-    constexpr int TOP = stage_top(X::LOGN, G), S = stage_s(X::LOGN, G);
+LAGO_HD void radix2_stage(float2 *buf, const float2 *tw, int tid) {
+    using Sq = typename X::S;
+    constexpr int TOP = stage_top(Sq::L2, G), S = stage_s(Sq::L2, G);
     if constexpr (S > 0) {
-        constexpr int N = 1 << X::LOGN, R = 1 << S, LH = TOP - S + 1, H = 1 << LH, NL = 1 << X::LOGNL;
-        constexpr int PER = N / R, ITEMS = X::NB * PER * NL;
+        constexpr int M = Sq::M, R = 1 << S, LH = TOP - S + 1, H = 1 << LH;
+        constexpr int PER = M / R, ITEMS = X::NB * Sq::R * PER * X::NL;
         for (int w = tid; w < ITEMS; w += X::NT) {
-            const int lane = w & (NL - 1);
-            const int q = w >> X::LOGNL;
+            const int lane = w % X::NL;
+            const int q = w / X::NL;
             const int gidx = q & (PER - 1);
-            const int b = q / PER;
+            const int bsub = q / PER;                      // (block, sub-transform)
+            const int b = bsub / Sq::R, k1 = bsub % Sq::R;
             const int low = gidx & (H - 1);
             const int i = ((gidx >> LH) << (LH + S)) | low;
-            float2 *p = buf + b * X::BS + i * X::ES + lane * X::LS;
+            float2 *p = buf + b * X::BS + (k1 * M + i) * X::ES + lane * X::LS;
             float2 v[R];
 #pragma unroll
             for (int m = 0; m < R; ++m) v[m] = p[m * H * X::ES];
@@ -103,7 +135,7 @@ LAGO_HD void radix_stage(float2 *buf, const float2 *tw, int tid) {
                 for (int m = 0; m < R; ++m) {
                     if (m & hm) continue;
                     const int jj = low + (m & (hm - 1)) * H;
-                    const float2 wv = tw[(jj << (X::LOGN - 1 - lhalf)) << (X::LOGM - X::LOGN)];
+                    const float2 wv = tw[jj * (X::LTW >> (lhalf + 1))];   // exp(-2 pi i jj / 2^(lhalf+1))
                     const float2 a = v[m];
                     if (FWD) {
                         const float2 bb = v[m + hm];
@@ -122,15 +154,78 @@ LAGO_HD void radix_stage(float2 *buf, const float2 *tw, int tid) {
     }
 }
 
-// stage number `g` of the forward transform / of the inverse transform (which runs the groups in
-// reverse order); g is a constant after unrolling
+// R-point DFT of v[0..R) in place; SGN = -1 forward (exp(-2 pi i r k / R)), +1 inverse
+template <int R, int SGN>
+LAGO_HD void dft_small(float2 *v) {
+    if constexpr (R == 3) {
+        const float s = 0.86602540378443864676f;  // sin(2 pi / 3)
+        const float2 a = make_float2(v[1].x + v[2].x, v[1].y + v[2].y), d = make_float2(v[1].x - v[2].x, v[1].y - v[2].y);
+        const float2 c = make_float2(fmaf(-0.5f, a.x, v[0].x), fmaf(-0.5f, a.y, v[0].y));
+        const float2 j = SGN < 0 ? make_float2(s * d.y, -s * d.x) : make_float2(-s * d.y, s * d.x);  // -+ i s d
+        v[0] = make_float2(v[0].x + a.x, v[0].y + a.y);
+        v[1] = make_float2(c.x + j.x, c.y + j.y);
+        v[2] = make_float2(c.x - j.x, c.y - j.y);
+    } else if constexpr (R == 5) {
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;   // cos(2 pi/5), cos(4 pi/5)
+        const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;    // sin(2 pi/5), sin(4 pi/5)
+        const float2 a1 = make_float2(v[1].x + v[4].x, v[1].y + v[4].y), b1 = make_float2(v[1].x - v[4].x, v[1].y - v[4].y);
+        const float2 a2 = make_float2(v[2].x + v[3].x, v[2].y + v[3].y), b2 = make_float2(v[2].x - v[3].x, v[2].y - v[3].y);
+        const float2 e1 = make_float2(fmaf(c2, a2.x, fmaf(c1, a1.x, v[0].x)), fmaf(c2, a2.y, fmaf(c1, a1.y, v[0].y)));
+        const float2 e2 = make_float2(fmaf(c1, a2.x, fmaf(c2, a1.x, v[0].x)), fmaf(c1, a2.y, fmaf(c2, a1.y, v[0].y)));
+        const float2 o1 = make_float2(fmaf(s2, b2.x, s1 * b1.x), fmaf(s2, b2.y, s1 * b1.y));
+        const float2 o2 = make_float2(fmaf(-s1, b2.x, s2 * b1.x), fmaf(-s1, b2.y, s2 * b1.y));
+        // forward: y_k = e -+ i o  (k = 1, 2 take -i o; k = 4, 3 take +i o); inverse: the signs swap
+        const float2 j1 = SGN < 0 ? make_float2(o1.y, -o1.x) : make_float2(-o1.y, o1.x);
+        const float2 j2 = SGN < 0 ? make_float2(o2.y, -o2.x) : make_float2(-o2.y, o2.x);
+        v[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+        v[1] = make_float2(e1.x + j1.x, e1.y + j1.y);
+        v[4] = make_float2(e1.x - j1.x, e1.y - j1.y);
+        v[2] = make_float2(e2.x + j2.x, e2.y + j2.y);
+        v[3] = make_float2(e2.x - j2.x, e2.y - j2.y);
+    }
+}
+
+// The radix-R level: x[m + M r] -> y[k1][m] = (sum_r x[m + M r] W_R^(r k1)) W_N^(m k1), stored at k1*M + m
+// (forward); the inverse undoes it.
+template <class X, bool FWD>
+LAGO_HD void radixR_stage(float2 *buf, const float2 *tw, int tid) {
+    using Sq = typename X::S;
+    if constexpr (Sq::R > 1) {
+        constexpr int R = Sq::R, M = Sq::M, ITEMS = X::NB * M * X::NL, TWS = X::LTW / Sq::N;
+        for (int w = tid; w < ITEMS; w += X::NT) {
+            const int lane = w % X::NL;
+            const int q = w / X::NL;
+            const int m = q & (M - 1), b = q >> Sq::L2;
+            float2 *p = buf + b * X::BS + m * X::ES + lane * X::LS;
+            float2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = p[r * M * X::ES];
+            if (FWD) {
+                dft_small<R, -1>(v);
+#pragma unroll
+                for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul(v[k1], tw[m * k1 * TWS]);
+            } else {
+#pragma unroll
+                for (int k1 = 1; k1 < R; ++k1) v[k1] = cmulc(v[k1], tw[m * k1 * TWS]);
+                dft_small<R, +1>(v);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) p[r * M * X::ES] = v[r];
+        }
+    }
+}
+
+// stage number `g` of the forward transform / of the inverse transform (which runs the stages in reverse order);
+// g is a constant after unrolling
 template <class X, bool FWD>
 LAGO_HD void run_stage(int g, float2 *buf, const float2 *tw, int tid) {
-    constexpr int G = stage_count(X::LOGN);
+    using Sq = typename X::S;
+    constexpr int G = stage_count<Sq>(), HASR = Sq::R > 1 ? 1 : 0;
     const int gg = FWD ? g : G - 1 - g;
-    if (gg == 0) radix_stage<X, 0, FWD>(buf, tw, tid);
-    else if (gg == 1) radix_stage<X, 1, FWD>(buf, tw, tid);
-    else radix_stage<X, 2, FWD>(buf, tw, tid);
+    if (HASR && gg == 0) radixR_stage<X, FWD>(buf, tw, tid);
+    else if (gg - HASR == 0) radix2_stage<X, 0, FWD>(buf, tw, tid);
+    else if (gg - HASR == 1) radix2_stage<X, 1, FWD>(buf, tw, tid);
+    else radix2_stage<X, 2, FWD>(buf, tw, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,15 +273,15 @@ struct XArgs {
     uint32_t total;             // ceil(nn / ipw) * items_per_n workgroups
 };
 
-template <int LOGNX, bool INV, int NT = 256>
+template <class SX, bool INV, int NT = 256>
 struct XPass {
-    static constexpr int NX = 1 << LOGNX, KL = 16, KCP = KL + 1;  // odd row pitch spreads rows over banks
-    using T = Xf<LOGNX, KCP, 1, 4, 3, NX * KCP, LOGNX, NT>;
-    static constexpr int G = stage_count(LOGNX);
+    static constexpr int NX = SX::N, KL = 16, KCP = KL + 1;  // odd row pitch spreads rows over banks
+    using T = Xf<SX, KCP, 1, KL, 3, NX * KCP, NX, NT>;
+    static constexpr int G = stage_count<SX>();
     static constexpr int NPH = 2 * G + 3;  // load | G forward stages | operator | G inverse stages | store
     static constexpr int ROWS_IT = NT / 8, KLD = 3 * NX / ROWS_IT;  // float4 loads: 8 lanes per 16-bin row
     static constexpr int RG = NT / KL, NOP = NX / RG;               // operator: NOP bins per thread
-    static constexpr size_t SMEM = (size_t)(3 * NX * KCP + NX / 2) * sizeof(float2);
+    static constexpr size_t SMEM = (size_t)(3 * NX * KCP + NX) * sizeof(float2);
     static_assert(3 * NX % ROWS_IT == 0 && NX % RG == 0, "tile does not divide over the threads");
 
     struct Block {  // workgroup-uniform
@@ -222,7 +317,7 @@ struct XPass {
                               bool first = true) {
         if (ph == 0) {
             if (first)
-                for (int t = tid; t < NX / 2; t += NT) tw[t] = twiddle(t, NX);
+                for (int t = tid; t < NX; t += NT) tw[t] = twiddle(t, NX);
             const int rg = tid >> 3, l8 = tid & 7;
             float4 v[KLD];
 #pragma unroll
@@ -233,7 +328,7 @@ struct XPass {
 #pragma unroll
             for (int i = 0; i < NOP; ++i) {
                 if (!first) break;
-                const float *t = b.tb + (size_t)brev(row0 + i * RG, LOGNX) * b.tks + kc * 6;
+                const float *t = b.tb + (size_t)freq_at<SX>(row0 + i * RG) * b.tks + kc * 6;
 #pragma unroll
                 for (int e = 0; e < 3; ++e) {
                     const float2 c2 = *reinterpret_cast<const float2 *>(t + 2 * e);
@@ -250,7 +345,7 @@ struct XPass {
         } else if (ph <= G) {
             run_stage<T, true>(ph - 1, buf, tw, tid);
         } else if (ph == G + 1) {
-            // position p of the x axis holds kx = bitrev(p) after the forward stages
+            // position p of the x axis holds kx = freq_at(p) after the forward stages
             const int kc = tid & (KL - 1), row0 = tid / KL;
 #pragma unroll
             for (int i = 0; i < NOP; ++i) {
@@ -286,30 +381,40 @@ struct ZYArgs {
     uint32_t total;
 };
 
-template <int LOGNY, int LOGNZ, int NT = 512>
+// threads per plane: the largest multiple of 64 up to 1024 that divides the plane's float4 count and leaves
+// every thread at least two of them
+constexpr int zy_threads(int ny, int nzh) {
+    const int f4 = ny * nzh / 2;
+    for (int nt = 1024; nt >= 64; nt -= 64)
+        if (f4 % nt == 0 && f4 / nt >= 2) return nt;
+    return 64;
+}
+
+template <class SY, class SZH, int NT = zy_threads(SY::N, SZH::N)>
 struct ZY {
-    static constexpr int NY = 1 << LOGNY, NZ = 1 << LOGNZ, LOGZH = LOGNZ - 1, NZH = 1 << LOGZH, PZ = NZH + 1;
-    static constexpr int LOGM = cmax(LOGNY, LOGNZ), M = 1 << LOGM;
-    using TZ = Xf<LOGZH, 1, PZ, LOGNY, 1, 0, LOGM, NT>;   // along z, lanes over y
-    using TY = Xf<LOGNY, PZ, 1, LOGZH, 1, 0, LOGM, NT>;   // along y, lanes over kz
-    static constexpr int GZ = stage_count(LOGZH), GY = stage_count(LOGNY);
+    static constexpr int NY = SY::N, NZH = SZH::N, NZ = 2 * NZH, PZ = NZH + 1;
+    static constexpr int LTW = clcm(NY, NZ);   // one table of LTW-th roots serves both axes and the real-FFT split
+    using TZ = Xf<SZH, 1, PZ, NY, 1, 0, LTW, NT>;   // along z, lanes over y
+    using TY = Xf<SY, PZ, 1, NZH, 1, 0, LTW, NT>;   // along y, lanes over kz
+    static constexpr int GZ = stage_count<SZH>(), GY = stage_count<SY>();
     static constexpr int NPH = GZ + GY + 4;  // load | stages | split | stages | unpack | store   (mirrored for the inverse)
     static constexpr int KV = NY * NZH / 2 / NT;  // float4 (two complex) per thread per plane
-    static constexpr size_t SMEM = (size_t)(NY * PZ + M / 2) * sizeof(float2);
-    static_assert(KV >= 1 && (NY * NZH / 2) % NT == 0, "plane does not divide over the threads");
+    static constexpr size_t SMEM = (size_t)(NY * PZ + LTW) * sizeof(float2);
+    static constexpr int THREADS = NT;
+    static_assert(KV >= 1 && (NY * NZH / 2) % NT == 0 && NZH % 2 == 0, "plane does not divide over the threads");
 
     // -- forward: real plane -> main[ky][kz], nyq[ky]
     LAGO_HD static void fwd_phase(int ph, int tid, const float *in, float2 *mainp, float2 *nyqp, float2 *P,
                                   float2 *tw) {
         if (ph == 0) {
-            for (int t = tid; t < M / 2; t += NT) tw[t] = twiddle(t, M);
+            for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
             // a row of NZ reals is NZH complex z[j] = (x[2j], x[2j+1]) as it lies in memory
             float4 v[KV];
 #pragma unroll
             for (int k = 0; k < KV; ++k) v[k] = reinterpret_cast<const float4 *>(in)[tid + k * NT];
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
-                const int e = (tid + k * NT) * 2, y = e >> LOGZH, j = e & (NZH - 1);
+                const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
                 P[y * PZ + j] = make_float2(v[k].x, v[k].y);
                 P[y * PZ + j + 1] = make_float2(v[k].z, v[k].w);
             }
@@ -318,23 +423,23 @@ struct ZY {
         } else if (ph == GZ + 1) {
             // split the half-length transform Z into the real transform X (k = 0 .. NZH):
             // X[k] = E + w^k O, conj X[NZH-k] = E - w^k O, E = (Z[k] + conj Z[NZH-k])/2,
-            // O = -i (Z[k] - conj Z[NZH-k])/2, w = exp(-2 pi i / NZ).  Z[k] sits at column bitrev(k).
+            // O = -i (Z[k] - conj Z[NZH-k])/2, w = exp(-2 pi i / NZ).  Z[k] sits at column pos_of(k).
             // X[0] and X[NZH] are real: they share column 0 as (X[0], X[NZH]).
             for (int w = tid; w < (NZH / 2 + 1) * NY; w += NT) {
-                const int y = w & (NY - 1), k = w >> LOGNY;
+                const int y = w % NY, k = w / NY;
                 float2 *row = P + y * PZ;
                 if (k == 0) {
                     const float2 z = row[0];
                     row[0] = make_float2(z.x + z.y, z.x - z.y);
                 } else if (k == NZH / 2) {
-                    float2 *p = row + brev(k, LOGZH);
+                    float2 *p = row + pos_of<SZH>(k);
                     *p = make_float2(p->x, -p->y);
                 } else {
-                    float2 *pk = row + brev(k, LOGZH), *pm = row + brev(NZH - k, LOGZH);
+                    float2 *pk = row + pos_of<SZH>(k), *pm = row + pos_of<SZH>(NZH - k);
                     const float2 zk = *pk, zm = *pm;
                     const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
                     const float2 D = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-                    const float2 wO = cmul(make_float2(D.y, -D.x), tw[k << (LOGM - LOGNZ)]);
+                    const float2 wO = cmul(make_float2(D.y, -D.x), tw[k * (LTW / NZ)]);
                     *pk = make_float2(E.x + wO.x, E.y + wO.y);
                     *pm = make_float2(E.x - wO.x, -(E.y - wO.y));
                 }
@@ -344,9 +449,9 @@ struct ZY {
         } else if (ph == GZ + GY + 2) {
             // column 0 carried A + iB with A = X[0](y), B = X[NZH](y) both real: separate their
             // transforms FA(ky) = (P(ky) + conj P(-ky))/2, FB(ky) = -i (P(ky) - conj P(-ky))/2.
-            // FA stays in column 0, FB goes to the spare column NZH.  Row ky sits at bitrev(ky).
+            // FA stays in column 0, FB goes to the spare column NZH.  Row ky sits at pos_of(ky).
             for (int ky = tid; ky <= NY / 2; ky += NT) {
-                float2 *pk = P + brev(ky, LOGNY) * PZ, *pm = P + brev((NY - ky) & (NY - 1), LOGNY) * PZ;
+                float2 *pk = P + pos_of<SY>(ky) * PZ, *pm = P + pos_of<SY>((NY - ky) % NY) * PZ;
                 const float2 a = pk[0], b = pm[0];
                 const float2 FA = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
                 const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
@@ -359,12 +464,12 @@ struct ZY {
         } else {
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
-                const int e = (tid + k * NT) * 2, ky = e >> LOGZH, kz = e & (NZH - 1);
-                const float2 *row = P + brev(ky, LOGNY) * PZ;
-                const float2 a = row[brev(kz, LOGZH)], c = row[brev(kz + 1, LOGZH)];
+                const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
+                const float2 *row = P + pos_of<SY>(ky) * PZ;
+                const float2 a = row[pos_of<SZH>(kz)], c = row[pos_of<SZH>(kz + 1)];
                 reinterpret_cast<float4 *>(mainp)[tid + k * NT] = make_float4(a.x, a.y, c.x, c.y);
             }
-            for (int ky = tid; ky < NY; ky += NT) nyqp[ky] = P[brev(ky, LOGNY) * PZ + NZH];
+            for (int ky = tid; ky < NY; ky += NT) nyqp[ky] = P[pos_of<SY>(ky) * PZ + NZH];
         }
     }
 
@@ -372,21 +477,21 @@ struct ZY {
     LAGO_HD static void inv_phase(int ph, int tid, float *out, const float2 *mainp, const float2 *nyqp, float2 *P,
                                   float2 *tw) {
         if (ph == 0) {
-            for (int t = tid; t < M / 2; t += NT) tw[t] = twiddle(t, M);
+            for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
             float4 v[KV];
 #pragma unroll
             for (int k = 0; k < KV; ++k) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
-                const int e = (tid + k * NT) * 2, ky = e >> LOGZH, kz = e & (NZH - 1);
-                float2 *row = P + brev(ky, LOGNY) * PZ;
+                const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
+                float2 *row = P + pos_of<SY>(ky) * PZ;
                 float2 a = make_float2(v[k].x, v[k].y);
                 if (kz == 0) {  // pack FA + i FB: the inverse y transform then returns (X[0](y), X[NZH](y))
                     const float2 fb = nyqp[ky];
                     a = make_float2(a.x - fb.y, a.y + fb.x);
                 }
-                row[brev(kz, LOGZH)] = a;
-                row[brev(kz + 1, LOGZH)] = make_float2(v[k].z, v[k].w);
+                row[pos_of<SZH>(kz)] = a;
+                row[pos_of<SZH>(kz + 1)] = make_float2(v[k].z, v[k].w);
             }
         } else if (ph <= GY) {
             run_stage<TY, false>(ph - 1, P, tw, tid);
@@ -395,19 +500,19 @@ struct ZY {
             // real inverse): 2E = X[k] + conj X[NZH-k], 2O = (X[k] - conj X[NZH-k]) conj(w^k),
             // Z[k] = 2E + i 2O, Z[NZH-k] = conj(2E) + i conj(2O)
             for (int w = tid; w < (NZH / 2 + 1) * NY; w += NT) {
-                const int y = w & (NY - 1), k = w >> LOGNY;
+                const int y = w % NY, k = w / NY;
                 float2 *row = P + y * PZ;
                 if (k == 0) {
                     const float2 x = row[0];
                     row[0] = make_float2(x.x + x.y, x.x - x.y);
                 } else if (k == NZH / 2) {
-                    float2 *p = row + brev(k, LOGZH);
+                    float2 *p = row + pos_of<SZH>(k);
                     *p = make_float2(2.0f * p->x, -2.0f * p->y);
                 } else {
-                    float2 *pk = row + brev(k, LOGZH), *pm = row + brev(NZH - k, LOGZH);
+                    float2 *pk = row + pos_of<SZH>(k), *pm = row + pos_of<SZH>(NZH - k);
                     const float2 xk = *pk, xm = *pm;
                     const float2 E = make_float2(xk.x + xm.x, xk.y - xm.y);
-                    const float2 O = cmulc(make_float2(xk.x - xm.x, xk.y + xm.y), tw[k << (LOGM - LOGNZ)]);
+                    const float2 O = cmulc(make_float2(xk.x - xm.x, xk.y + xm.y), tw[k * (LTW / NZ)]);
                     *pk = make_float2(E.x - O.y, E.y + O.x);
                     *pm = make_float2(E.x + O.y, O.x - E.y);
                 }
@@ -417,7 +522,7 @@ struct ZY {
         } else if (ph == GY + GZ + 2) {
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
-                const int e = (tid + k * NT) * 2, y = e >> LOGZH, j = e & (NZH - 1);
+                const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
                 const float2 a = P[y * PZ + j], c = P[y * PZ + j + 1];
                 reinterpret_cast<float4 *>(out)[tid + k * NT] = make_float4(a.x, a.y, c.x, c.y);
             }

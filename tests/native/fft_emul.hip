@@ -48,11 +48,12 @@ static void op_double(const float *c, cd &X, cd &Y, cd &Z) {
     }
 }
 
-template <int LX, int LY, int LZ, bool INV>
+template <class SX, class SY, class SZH, bool INV>
 static int run_case() {
-    constexpr int NX = 1 << LX, NY = 1 << LY, NZ = 1 << LZ, NZH = NZ / 2, NZC = NZH + 1, NN = 2;
-    using Zy = ZY<LY, LZ, 512>;
-    using Xp = XPass<LX, INV, 256>;
+    constexpr int NX = SX::N, NY = SY::N, NZH = SZH::N, NZ = 2 * NZH, NZC = NZH + 1, NN = 2;
+    using Zy = ZY<SY, SZH>;
+    using Xp = XPass<SX, INV, 256>;
+    constexpr int ZT = Zy::THREADS;
     const size_t plane = (size_t)NY * NZ, nplanes = (size_t)NN * 3 * NX;
     std::vector<float> m(nplanes * plane), out(nplanes * plane, 0.f);
     for (auto &v : m) v = (float)frand();
@@ -83,7 +84,7 @@ static int run_case() {
     for (size_t p = 0; p < nplanes; ++p) {
         float2 *P = lds.data(), *tw = P + NY * Zy::PZ;
         for (int ph = 0; ph < Zy::NPH; ++ph)
-            for (int tid = 0; tid < 512; ++tid)
+            for (int tid = 0; tid < ZT; ++tid)
                 Zy::fwd_phase(ph, tid, m.data() + p * plane, mainb + p * NY * NZH, nyqb + p * NY, P, tw);
     }
     // check the spectrum of plane-wise 2D transforms against the DFT (first batch item, component 1)
@@ -119,7 +120,7 @@ static int run_case() {
     for (size_t p = 0; p < nplanes; ++p) {
         float2 *P = lds.data(), *tw = P + NY * Zy::PZ;
         for (int ph = 0; ph < Zy::NPH_INV; ++ph)
-            for (int tid = 0; tid < 512; ++tid)
+            for (int tid = 0; tid < ZT; ++tid)
                 Zy::inv_phase(ph, tid, out.data() + p * plane, mainb + p * NY * NZH, nyqb + p * NY, P, tw);
     }
     // reference: full complex 3D DFT in double, operator on every bin, inverse DFT
@@ -160,10 +161,15 @@ static int run_case() {
 
 int main() {
     int bad = 0;
-    bad += run_case<6, 5, 6, false>();
-    bad += run_case<6, 6, 7, true>();
-    bad += run_case<7, 5, 6, true>();
-    bad += run_case<6, 7, 6, false>();
+    // powers of two
+    bad += run_case<Sz<1, 6>, Sz<1, 5>, Sz<1, 5>, false>();   // 64 x 32 x 64
+    bad += run_case<Sz<1, 6>, Sz<1, 6>, Sz<1, 6>, true>();    // 64 x 64 x 128
+    bad += run_case<Sz<1, 7>, Sz<1, 5>, Sz<1, 5>, true>();    // 128 x 32 x 64
+    // radix 3 and 5 times a power of two (96 = 3*32, 160 = 5*32; half lengths 48 = 3*16, 80 = 5*16)
+    bad += run_case<Sz<3, 5>, Sz<1, 5>, Sz<3, 4>, false>();   // 96 x 32 x 96
+    bad += run_case<Sz<5, 5>, Sz<1, 5>, Sz<5, 4>, true>();    // 160 x 32 x 160
+    bad += run_case<Sz<1, 6>, Sz<5, 5>, Sz<1, 5>, false>();   // 64 x 160 x 64
+    bad += run_case<Sz<1, 6>, Sz<3, 5>, Sz<5, 4>, true>();    // 64 x 96 x 160
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }

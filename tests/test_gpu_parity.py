@@ -385,11 +385,12 @@ def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
 
 
 @pytest.mark.parametrize("sp", [(64, 6, 10), (128, 5, 12), (64, 64, 64), (256, 4, 6), (128, 7, 130),
-                                (64, 32, 64), (128, 64, 128), (64, 128, 256), (256, 32, 64), (64, 256, 64)])
+                                (64, 32, 64), (128, 64, 128), (64, 128, 256), (256, 32, 64), (64, 256, 64),
+                                (160, 160, 160), (96, 64, 160), (160, 96, 192), (192, 160, 96), (64, 192, 192)])
 @pytest.mark.parametrize("inverse", [True, False])
 def test_fused_fluid_metric_paths(ext, sp, inverse):
     """float32 3D: the three implementations of FluidMetric sharp/flat -- (2) three LDS-tiled FFT
-    passes without rocFFT (power-of-two extents), (1) 2D rocFFT + fused (x-FFT, operator, inverse
+    passes without rocFFT (extents 2^a, 3*2^a, 5*2^a: 160^3 is BASELINE configs[4]), (1) 2D rocFFT + fused (x-FFT, operator, inverse
     x-FFT) kernel (power-of-two nx), (0) plain 3D hipFFT + operator kernel -- against each other
     and against the oracle (numpy FFT).  Shapes a mode does not support fall through to the next."""
     import lagomorph_amd as lm
