@@ -151,8 +151,9 @@ int lago_Ad_star_f32(float *out, float *mphi, const float *phiinv, const float *
 int lago_Ad_star_f64(double *out, double *mphi, const double *phiinv, const double *m, int dim, int64_t nn,
                      int64_t nx, int64_t ny, int64_t nz, void *stream);
 
-/* interp_backward with a start value for d_u (the fused backward forms of compose and Ad_star; d_I exactly as
- * lago_interp_backward).  The reference kernel owns d_u[n, d, x] in one thread and sums the channels' terms in
+/* interp_backward with start values (the fused backward forms of compose, Ad_star and expmap).  i_mode 0: d_I is
+ * zeroed and receives the splat, exactly as lago_interp_backward; i_mode 1 (needs need_I): the splat is ADDED onto
+ * the contents of d_I (a gradient accumulated over several calls, e.g. d/d m0 over the Euler steps of expmap).  The reference kernel owns d_u[n, d, x] in one thread and sums the channels' terms in
  * ascending order starting from zero (cuda/interp.cu:185-244); here the sum starts from
  *   u_mode 0: zero (identical to lago_interp_backward with need_u),
  *   u_mode 1: the contents of d_u on entry (d_u += ...: the `d_v.add_(d_u)` of a chain rule, without the extra pass),
@@ -160,10 +161,19 @@ int lago_Ad_star_f64(double *out, double *mphi, const double *phiinv, const doub
  * d_u is always produced (need_u is implied). */
 int lago_interp_backward_fused_f32(float *d_I, float *d_u, const float *grad_out, const float *I, const float *u,
                                    double dt, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz,
-                                   int broadcast_I, int need_I, int u_mode, double addgo, void *stream);
+                                   int broadcast_I, int need_I, int i_mode, int u_mode, double addgo, void *stream);
 int lago_interp_backward_fused_f64(double *d_I, double *d_u, const double *grad_out, const double *I, const double *u,
                                    double dt, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz,
-                                   int broadcast_I, int need_I, int u_mode, double addgo, void *stream);
+                                   int broadcast_I, int need_I, int i_mode, int u_mode, double addgo, void *stream);
+
+/* jacobian_times_vectorfield_backward (lago_jtv_backward) whose d_v is added onto the contents of d_v when acc_v is
+ * non-zero (d_w is always overwritten): the chain-rule sum of expmap's reverse sweep without a separate add pass. */
+int lago_jtv_backward_acc_f32(float *d_v, float *d_w, const float *grad_out, const float *v, const float *w,
+                              int displacement, int transpose, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny,
+                              int64_t nz, int acc_v, void *stream);
+int lago_jtv_backward_acc_f64(double *d_v, double *d_w, const double *grad_out, const double *v, const double *w,
+                              int displacement, int transpose, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny,
+                              int64_t nz, int acc_v, void *stream);
 
 /* ad_star (the infinitesimal coadjoint action): out = (Dv)^T m - sum_d D_d^T (v_d m) -- adjrep.ad_star
  * (/root/reference/lagomorph/adjrep.py:69-83), which the reference evaluates as

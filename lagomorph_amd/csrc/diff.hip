@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void jtv_fwd_kernel(R *__restrict__ out, co
 template <typename R, int DIM, bool DISP, bool TRANS>
 __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R *__restrict__ d_w,
                                                          const R *__restrict__ go, const R *__restrict__ v,
-                                                         const R *__restrict__ w, int nc, Geom g) {
+                                                         const R *__restrict__ w, int nc, Geom g, int acc_v) {
     const Vox vx = locate(g);
     if (!vx.valid) return;
     const size_t nv = g.nvox;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
 #pragma unroll
             for (int d = 0; d < DIM; ++d)
                 acc = acc + st.dTv(W[c].c0, W[c].p[d], W[c].m[d], G[d].c0, G[d].p[d], G[d].m[d], d);
-            dvn[(size_t)c * nv] = acc;
+            dvn[(size_t)c * nv] = acc_v ? dvn[(size_t)c * nv] + acc : acc;
         }
     } else {
         R dw[DIM];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
             R acc = 0;
 #pragma unroll
             for (int d = 0; d < DIM; ++d) acc = acc + st.dTv(W[d].c0, W[d].p[d], W[d].m[d], G.c0, G.p[d], G.m[d], d);
-            dvn[(size_t)c * nv] = acc;
+            dvn[(size_t)c * nv] = acc_v ? dvn[(size_t)c * nv] + acc : acc;
         }
 #pragma unroll
         for (int d = 0; d < DIM; ++d) dwn[(size_t)d * nv] = dw[d];
@@ -317,7 +317,7 @@ static int jtv_forward_impl(R *out, const R *v, const R *w, int disp, int trans,
 
 template <typename R>
 static int jtv_backward_impl(R *d_v, R *d_w, const R *go, const R *v, const R *w, int disp, int trans, int dim,
-                             int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, void *stream) {
+                             int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, void *stream, int acc_v = 0) {
     if (dim != 2 && dim != 3)
         return fail_invalid("Only two- and three-dimensional jacobian times vectorfield is supported");
     if (thin(dim, nx, ny, nz)) return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
@@ -336,7 +336,7 @@ static int jtv_backward_impl(R *d_v, R *d_w, const R *go, const R *v, const R *w
     }
 #define LAUNCH(D, DS, TR)                                                                                       \
     hipLaunchKernelGGL((jtv_bwd_kernel<R, D, DS, TR>), dim3(g.nblocks), dim3(kBlock), 0, s, d_v, d_w, go, v, w, \
-                       (int)nc, g)
+                       (int)nc, g, acc_v)
     if (dim == 3) BY_FLAGS(3); else BY_FLAGS(2);
 #undef LAUNCH
 #undef BY_FLAGS
@@ -419,6 +419,12 @@ extern "C" {
                                       int64_t nx, int64_t ny, int64_t nz, void *stream) {                          \
         return lago::jtv_adjoint_forward_impl<REAL>(out, z, w, dim, nn, nc, nx, ny, nz, stream);                   \
     }                                                                                                               \
+    int lago_jtv_backward_acc##SUF(REAL *d_v, REAL *d_w, const REAL *go, const REAL *v, const REAL *w,             \
+                                   int displacement, int transpose, int dim, int64_t nn, int64_t nc, int64_t nx,   \
+                                   int64_t ny, int64_t nz, int acc_v, void *stream) {                              \
+        return lago::jtv_backward_impl<REAL>(d_v, d_w, go, v, w, displacement, transpose, dim, nn, nc, nx, ny, nz, \
+                                             stream, acc_v);                                                       \
+    }                                                                                                              \
     int lago_jtv_adjoint_backward##SUF(REAL *d_v, REAL *d_w, const REAL *go, const REAL *v, const REAL *w,         \
                                        int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {    \
         return lago::jtv_adjoint_backward_impl<REAL>(d_v, d_w, go, v, w, dim, nn, nx, ny, nz, stream);             \

@@ -381,14 +381,9 @@ struct ZYArgs {
     uint32_t total;
 };
 
-// threads per plane: the largest multiple of 64 up to 1024 that divides the plane's float4 count and leaves
-// every thread at least two of them
-constexpr int zy_threads(int ny, int nzh) {
-    const int f4 = ny * nzh / 2;
-    for (int nt = 1024; nt >= 64; nt -= 64)
-        if (f4 % nt == 0 && f4 / nt >= 2) return nt;
-    return 64;
-}
+// threads per plane: 1024 once a plane has at least 2048 float4 (two per thread), else 512; the load / store phases
+// guard the last pass when the plane does not divide (160 x 80 / 2 = 6400 float4 over 1024 threads)
+constexpr int zy_threads(int ny, int nzh) { return ny * nzh / 2 >= 2048 ? 1024 : 512; }
 
 template <class SY, class SZH, int NT = zy_threads(SY::N, SZH::N)>
 struct ZY {
@@ -398,10 +393,11 @@ struct ZY {
     using TY = Xf<SY, PZ, 1, NZH, 1, 0, LTW, NT>;   // along y, lanes over kz
     static constexpr int GZ = stage_count<SZH>(), GY = stage_count<SY>();
     static constexpr int NPH = GZ + GY + 4;  // load | stages | split | stages | unpack | store   (mirrored for the inverse)
-    static constexpr int KV = NY * NZH / 2 / NT;  // float4 (two complex) per thread per plane
+    static constexpr int F4 = NY * NZH / 2;        // float4 (two complex) per plane
+    static constexpr int KV = (F4 + NT - 1) / NT;  // ... per thread (the last pass is guarded)
     static constexpr size_t SMEM = (size_t)(NY * PZ + LTW) * sizeof(float2);
     static constexpr int THREADS = NT;
-    static_assert(KV >= 1 && (NY * NZH / 2) % NT == 0 && NZH % 2 == 0, "plane does not divide over the threads");
+    static_assert(KV >= 1 && NZH % 2 == 0, "rows must hold whole float4");
 
     // -- forward: real plane -> main[ky][kz], nyq[ky]
     LAGO_HD static void fwd_phase(int ph, int tid, const float *in, float2 *mainp, float2 *nyqp, float2 *P,
@@ -411,9 +407,11 @@ struct ZY {
             // a row of NZ reals is NZH complex z[j] = (x[2j], x[2j+1]) as it lies in memory
             float4 v[KV];
 #pragma unroll
-            for (int k = 0; k < KV; ++k) v[k] = reinterpret_cast<const float4 *>(in)[tid + k * NT];
+            for (int k = 0; k < KV; ++k)
+                if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(in)[tid + k * NT];
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
+                if (tid + k * NT >= F4) continue;
                 const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
                 P[y * PZ + j] = make_float2(v[k].x, v[k].y);
                 P[y * PZ + j + 1] = make_float2(v[k].z, v[k].w);
@@ -464,6 +462,7 @@ struct ZY {
         } else {
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
+                if (tid + k * NT >= F4) continue;
                 const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
                 const float2 *row = P + pos_of<SY>(ky) * PZ;
                 const float2 a = row[pos_of<SZH>(kz)], c = row[pos_of<SZH>(kz + 1)];
@@ -480,9 +479,11 @@ struct ZY {
             for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
             float4 v[KV];
 #pragma unroll
-            for (int k = 0; k < KV; ++k) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
+            for (int k = 0; k < KV; ++k)
+                if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
+                if (tid + k * NT >= F4) continue;
                 const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
                 float2 *row = P + pos_of<SY>(ky) * PZ;
                 float2 a = make_float2(v[k].x, v[k].y);
@@ -522,6 +523,7 @@ struct ZY {
         } else if (ph == GY + GZ + 2) {
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
+                if (tid + k * NT >= F4) continue;
                 const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
                 const float2 a = P[y * PZ + j], c = P[y * PZ + j + 1];
                 reinterpret_cast<float4 *>(out)[tid + k * NT] = make_float4(a.x, a.y, c.x, c.y);

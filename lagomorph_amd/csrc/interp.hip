@@ -265,7 +265,7 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
 template <typename R>
 static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int dim,
                                 int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int bc, int need_I,
-                                int need_u, void *stream, int umode = 0, double addgo = 0.0) {
+                                int need_u, void *stream, int umode = 0, double addgo = 0.0, int imode = 0) {
     if (dim != 2 && dim != 3)
         return fail_invalid("Only two- and three-dimensional interpolation is supported");
     if (umode < 0 || umode > 2 || (umode == 2 && nc != dim))
@@ -278,8 +278,10 @@ static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R
     const size_t nu = (size_t)nn * dim * g.nvox;
     if ((nI && !d_I) || (nu && !d_u) || (nu && nc && (!go || !I || !u)))
         return fail_invalid("interp_backward: null pointer");
-    // d_I is a scatter target (or unused): zero it.  d_u is fully overwritten when needed.
-    if (nI) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
+    // d_I is a scatter target (or unused): zero it -- unless the caller asked for the splat to be added onto its
+    // contents (imode 1).  d_u is fully overwritten when needed.
+    if (imode < 0 || imode > 1 || (imode == 1 && !need_I)) return fail_invalid("interp_backward_fused: bad i_mode");
+    if (nI && imode == 0) LAGO_HIP_TRY(hipMemsetAsync(d_I, 0, nI * sizeof(R), s));
     if (!need_u && nu) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
     if (g.nblocks == 0 || nc == 0 || !(need_I || need_u)) {
         if (need_u && nu && umode != 1) LAGO_HIP_TRY(hipMemsetAsync(d_u, 0, nu * sizeof(R), s));
@@ -330,9 +332,10 @@ extern "C" {
     }                                                                                                              \
     int lago_interp_backward_fused##SUF(REAL *d_I, REAL *d_u, const REAL *go, const REAL *I, const REAL *u,       \
                                         double dt, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny,       \
-                                        int64_t nz, int bc, int need_I, int u_mode, double addgo, void *stream) { \
+                                        int64_t nz, int bc, int need_I, int i_mode, int u_mode, double addgo,     \
+                                        void *stream) {                                                           \
         return lago::interp_backward_impl<REAL>(d_I, d_u, go, I, u, dt, dim, nn, nc, nx, ny, nz, bc, need_I, 1,   \
-                                                stream, u_mode, addgo);                                           \
+                                                stream, u_mode, addgo, i_mode);                                   \
     }                                                                                                              \
     int lago_interp_hessian_diagonal_image##SUF(REAL *out, const REAL *u, double dt, int64_t nI, int64_t nn,      \
                                                 int64_t nc, int64_t nx, int64_t ny, void *stream) {               \

@@ -52,8 +52,9 @@ _SIGS = {
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_Ad_star": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
-    "lago_interp_backward_fused": [_vp, _vp, _vp, _vp, _vp, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _dbl,
-                                   _vp],
+    "lago_interp_backward_fused": [_vp, _vp, _vp, _vp, _vp, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int,
+                                   _dbl, _vp],
+    "lago_jtv_backward_acc": [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp],
     "lago_ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_fluid_metric": [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64,
                           _i64, _i64, _vp],
@@ -244,8 +245,9 @@ def jacobian_times_vectorfield_forward(g, v, displacement, transpose):
     return out
 
 
-def jacobian_times_vectorfield_backward(grad_out, v, w, displacement, transpose, need_v, need_w):
-    """cuda/diff.cu:475-540 (need_v / need_w are ignored there: both gradients are always computed)."""
+def jacobian_times_vectorfield_backward(grad_out, v, w, displacement, transpose, need_v, need_w, d_v=None):
+    """cuda/diff.cu:475-540 (need_v / need_w are ignored there: both gradients are always computed).  Beyond the
+    reference: with `d_v` given, the gradient is added onto it in place (lago_jtv_backward_acc)."""
     _check_jtv(v, w)
     _check_jtv(v, grad_out)
     grad_out, v, w = grad_out.contiguous(), v.contiguous(), w.contiguous()
@@ -256,7 +258,16 @@ def jacobian_times_vectorfield_backward(grad_out, v, w, displacement, transpose,
         raise RuntimeError("arguments must have same batch size dimension")
     if w.size(1) != dim or tuple(w.shape[2:]) != tuple(v.shape[2:]) or grad_out.shape != v.shape:
         raise RuntimeError("vector field is of wrong dimension")
-    d_v, d_w = torch.empty_like(v), torch.empty_like(w)
+    d_w = torch.empty_like(w)
+    if d_v is not None:
+        _check_input(d_v, "d_v")
+        _same(v, d_v)
+        if d_v.shape != v.shape:
+            raise RuntimeError("jacobian_times_vectorfield_backward: d_v must have the shape of v")
+        _call("lago_jtv_backward_acc", v, _ptr(d_v), _ptr(d_w), _ptr(grad_out), _ptr(v), _ptr(w), int(bool(displacement)),
+              int(bool(transpose)), dim, v.size(0), v.size(1), nx, ny, nz, 1)
+        return [d_v, d_w]
+    d_v = torch.empty_like(v)
     _call("lago_jtv_backward", v, _ptr(d_v), _ptr(d_w), _ptr(grad_out), _ptr(v), _ptr(w), int(bool(displacement)),
           int(bool(transpose)), dim, v.size(0), v.size(1), nx, ny, nz)
     return [d_v, d_w]
@@ -425,11 +436,12 @@ def compose(u, v, ds=1.0, dt=1.0):
     return out
 
 
-def interp_backward_fused(grad_out, I, u, dt, need_I, d_u=None, addgo=None):
+def interp_backward_fused(grad_out, I, u, dt, need_I, d_u=None, addgo=None, d_I=None):
     """interp_backward whose d_u sum starts from the contents of `d_u` (given: accumulated in place and returned)
     or from addgo * grad_out (needs as many channels as dimensions) instead of zero -- the chain-rule additions of
-    compose's and Ad_star's backward without their extra passes.  Returns [d_I, d_u].  Not part of the reference's
-    extension surface (include/lagomorph_hip.h: lago_interp_backward_fused)."""
+    compose's and Ad_star's backward without their extra passes; with `d_I` given the splat is added onto it
+    instead of onto zeros.  Returns [d_I, d_u].  Not part of the reference's extension surface
+    (include/lagomorph_hip.h: lago_interp_backward_fused)."""
     _check_input(grad_out, "grad_out")
     _check_input(I, "I")
     _check_input(u, "u")
@@ -457,9 +469,17 @@ def interp_backward_fused(grad_out, I, u, dt, need_I, d_u=None, addgo=None):
             raise RuntimeError("interp_backward_fused: addgo needs as many channels as dimensions")
         d_u = torch.empty_like(u)
         mode, ag = 2, float(addgo)
-    d_I = torch.empty_like(I)
+    imode = 0
+    if d_I is not None:
+        _check_input(d_I, "d_I")
+        _same(I, d_I)
+        if d_I.shape != I.shape or not need_I:
+            raise RuntimeError("interp_backward_fused: d_I must have the shape of I (and need_I be set)")
+        imode = 1
+    else:
+        d_I = torch.empty_like(I)
     _call("lago_interp_backward_fused", I, _ptr(d_I), _ptr(d_u), _ptr(grad_out), _ptr(I), _ptr(u), float(dt), dim, nn,
-          I.size(1), nx, ny, nz, int(bc), int(bool(need_I)), mode, ag)
+          I.size(1), nx, ny, nz, int(bc), int(bool(need_I)), imode, mode, ag)
     return [d_I, d_u]
 
 

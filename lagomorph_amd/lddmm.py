@@ -9,9 +9,11 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import adjrep, deform
+from . import adjrep, deform, lagomorph_ext
 from .affine import regrid
 from .metric import FluidMetric
+
+USE_FUSED_EXPMAP = True
 
 
 def expmap_advect(metric, m, T=1.0, num_steps=10, phiinv=None):
@@ -38,6 +40,67 @@ def EPDiff_step(metric, m0, dt, phiinv, mommask=None):
     return deform.compose_disp_vel(phiinv, v, dt=-dt)
 
 
+class ExpmapFunction(torch.autograd.Function):
+    """The whole Euler integration of `expmap` as ONE autograd node with a hand-written reverse sweep.
+
+    Forward: the loop of `EPDiff_step` (lddmm.py:39-44, :73-105) through the fused kernels, keeping per step
+    phi_k, v_k and the resampled momentum m0 o (id + phi_k) -- the tensors autograd would keep as well.
+    Backward, for k = N-1 .. 0 with G = dL/dphi_{k+1}:
+        (d_phi_k, d_v_k) = compose^T: splat of G at x + ds v_k, and (D_u interp)^T G + ds G      (one kernel)
+        d_m_k            = sharp(d_v_k)                                        (the operator is self-adjoint)
+        d_phi_k         += jtv_backward(d_m_k; phi_k, m0 o (id + phi_k))        (added in place), giving d_w
+        d_m0            += splat of d_w at x + phi_k;   d_phi_k += (D_u interp)^T d_w            (one kernel)
+    Every chain-rule sum happens inside a kernel (lago_interp_backward_fused, lago_jtv_backward_acc): the thirteen
+    elementwise add passes and nine memsets per five-step shoot that autograd's own accumulation costs (6.6 % + 1.7 %
+    of the 160^3 atlas step, profiles/r02_atlas160_kernel_stats.md) are gone.  Same kernels and formulas as
+    differentiating the loop, so the gradients agree to the rounding of the summation order."""
+
+    @staticmethod
+    def forward(ctx, metric, m0, phiinv, dt, num_steps):
+        m0 = m0.contiguous()
+        phi = torch.zeros_like(m0) if phiinv is None else phiinv.contiguous()
+        keep = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        steps = []
+        for _ in range(num_steps):
+            if keep:
+                m, mphi = lagomorph_ext.Ad_star(phi, m0, save_resampled=True)
+            else:
+                m, mphi = lagomorph_ext.Ad_star(phi, m0), None
+            v = metric.sharp(m)
+            del m
+            nxt = lagomorph_ext.compose(v, phi, -dt, 1.0)
+            if keep:
+                steps.append((phi, v, mphi))
+            phi = nxt
+        ctx.metric, ctx.dt, ctx.steps, ctx.m0 = metric, dt, steps, m0
+        return phi
+
+    @staticmethod
+    def backward(ctx, G):
+        metric, dt, m0 = ctx.metric, ctx.dt, ctx.m0
+        need_m, need_phi = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        G = G.contiguous()
+        d_m0 = torch.zeros_like(m0)
+        for phi, v, mphi in reversed(ctx.steps):
+            d_phi, d_v = lagomorph_ext.interp_backward_fused(G, phi, v, -dt, True, addgo=-dt)
+            d_m = metric.sharp(d_v)
+            del d_v
+            d_phi, d_w = lagomorph_ext.jacobian_times_vectorfield_backward(d_m, phi, mphi, True, False, True, True,
+                                                                            d_v=d_phi)
+            del d_m
+            _, G = lagomorph_ext.interp_backward_fused(d_w, m0, phi, 1.0, True, d_u=d_phi, d_I=d_m0)
+        ctx.steps = None
+        return None, d_m0 if need_m else None, G if need_phi else None, None, None
+
+
+def _fused_expmap_ok(metric, m0, phiinv, mommask):
+    return (USE_FUSED_EXPMAP and mommask is None and isinstance(metric, FluidMetric) and m0.is_cuda
+            and m0.size(1) == m0.dim() - 2 and m0.dtype in (torch.float32, torch.float64)
+            and (phiinv is None or (phiinv.shape == m0.shape and phiinv.dtype == m0.dtype))
+            and all(hasattr(lagomorph_ext, n) for n in ("Ad_star", "compose", "interp_backward_fused"))
+            and torch.is_grad_enabled() and (m0.requires_grad or (phiinv is not None and phiinv.requires_grad)))
+
+
 def expmap(metric, m0, T=1.0, num_steps=10, phiinv=None, mommask=None, checkpoints=False):
     """Exponential map: returns the displacement of phi^-1 (lddmm.py:73-105).
 
@@ -50,6 +113,8 @@ def expmap(metric, m0, T=1.0, num_steps=10, phiinv=None, mommask=None, checkpoin
     if checkpoints:
         raise NotImplementedError("expmap(checkpoints=...) is broken in the reference and not provided")
     dt = T / num_steps
+    if num_steps > 0 and _fused_expmap_ok(metric, m0, phiinv, mommask):
+        return ExpmapFunction.apply(metric, m0, phiinv, dt, num_steps)
     for _ in range(num_steps):
         phiinv = EPDiff_step(metric, m0, dt, phiinv, mommask=mommask)
     return phiinv

@@ -163,3 +163,39 @@ def test_lddmm_step_160cubed_float32_vs_float64_and_directional_derivative():
     an = float((gm64 * d.double()).sum())
     # observed: 7.7e-5 relative (central differences, eps = 1e-3, on a loss that is not quadratic along d)
     assert abs(fd - an) <= 5e-4 * max(abs(an), abs(fd)), (fd, an)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("sp", [(12, 14, 40), (20, 24), (6, 5, 7)])
+def test_expmap_reverse_sweep_equals_autograd_through_the_loop(sp, dtype, tol):
+    """ExpmapFunction (one autograd node, hand-written reverse sweep with every chain-rule sum inside a kernel) against
+    autograd through the loop of EPDiff_step: same displacement bit for bit, gradients with respect to the momentum and
+    to a given initial phi^-1 to the rounding of the summation order."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import lddmm
+
+    rng = np.random.default_rng(17)
+    d = len(sp)
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    m0 = torch.from_numpy(smooth_np(rng, (2, d) + sp, 1.5)).to(dtype).cuda()
+    m0 = (m0 * (1.5 / met.sharp(m0).abs().max())).contiguous()
+    p0 = torch.from_numpy(0.3 * smooth_np(rng, (2, d) + sp, 1.5)).to(dtype).cuda().contiguous()
+    go = torch.from_numpy(rng.standard_normal((2, d) + sp)).to(dtype).cuda()
+    res = {}
+    for fused in (True, False):
+        lddmm.USE_FUSED_EXPMAP = fused
+        try:
+            a, b = m0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+            h = lm.expmap(met, a, num_steps=4, phiinv=b)
+            assert (type(h.grad_fn).__name__ == "ExpmapFunctionBackward") == fused
+            h.backward(go)
+            res[fused] = (h.detach(), a.grad, b.grad)
+        finally:
+            lddmm.USE_FUSED_EXPMAP = True
+    assert torch.equal(res[True][0], res[False][0])
+    for i, name in ((1, "d_m0"), (2, "d_phiinv")):
+        err = float((res[True][i] - res[False][i]).abs().max() / res[False][i].abs().max())
+        assert err <= tol, (name, err)
+    # no gradient wanted: the plain loop, nothing kept
+    with torch.no_grad():
+        assert torch.equal(lm.expmap(met, m0, num_steps=4, phiinv=p0), res[True][0])
