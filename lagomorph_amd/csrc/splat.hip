@@ -407,7 +407,10 @@ __device__ __forceinline__ float shear_pos(int base, double dt, float u) {
 }
 
 // (<= 80 SGPRs and <= 64 VGPRs: two 1024-thread workgroups per CU, 32 waves; at 81+ SGPRs the CU admits only one)
-template <int NT, bool NEED_U, bool UNIT, bool BC>
+// VPL = 0: rolled loop over the tile's voxels, d_u read-modify-written per channel.  VPL > 0 (several channels with
+// d_u wanted, tile covered by VPL passes of the workgroup): the passes are unrolled and each voxel's d_u stays in
+// registers over the channel loop -- 12 instead of 12 + 24 (C - 1) bytes per voxel of d_u traffic.
+template <int NT, bool NEED_U, bool UNIT, bool BC, int VPL = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat_shear_kernel(float *__restrict__ d_I, float *__restrict__ d_u,
                                                          const float *__restrict__ go, const float *__restrict__ I,
                                                          const float *__restrict__ u, double dt, int nc, ShearGeom sg,
@@ -461,6 +464,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
     const uint32_t gxB = (uint32_t)ny * nz * 4u, gyB = (uint32_t)nz * 4u;              // grid strides in bytes
     const uint32_t wxu1 = (uint32_t)(WX - 1), wyu1 = (uint32_t)(WY - 1), wezu = (uint32_t)wez;
 
+    constexpr int NV = VPL > 0 ? VPL : 1;
+    float rux[NV], ruy[NV], ruz[NV];   // VPL > 0: the d_u sums of this thread's voxels
     for (int c = 0; c < nc; ++c) {
         for (uint32_t f = threadIdx.x; f < sg.win_cells; f += NT) win[f] = 0.0;
         __syncthreads();
@@ -468,7 +473,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
         const float *gc = gon + (size_t)c * nv;
         const BufRsrc rdI = make_rsrc(dIn + (size_t)c * nv, planeB);
         const BufRsrc rI = make_rsrc(Ic, planeB);
-        for (uint32_t tt = threadIdx.x; tt < sg.tile_vox; tt += NT) {
+#pragma unroll
+        for (int it = 0; it < (VPL > 0 ? VPL : (int)((sg.tile_vox + NT - 1) / NT)); ++it) {
+            uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+            if (VPL > 0) {
+                // the unrolled passes stay one after the other and recompute their geometry per channel: hoisting it
+                // out of the channel loop (it does not depend on c) or every pass's loads to the top costs 128 VGPRs
+                // and spills -- and with them the second workgroup of the CU
+                asm volatile("" : "+v"(tt)::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tt >= sg.tile_vox) break;
             const uint32_t a = sg.d_TyTz.div(tt);
             const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
             const uint32_t b = sg.d_Tz.div(rr);
@@ -562,14 +577,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
                 // ascending channel order, as the reference's thread-owned accumulation; the start value is zero
                 // for the reference operator, the caller's d_u or addgo * grad_out for the fused backward forms
                 float ix = 0.f, iy = 0.f, iz = 0.f;
-                if (c > 0 || umode == 1) {
+                if (VPL > 0 && c > 0) {
+                    ix = rux[it % NV]; iy = ruy[it % NV]; iz = ruz[it % NV];
+                } else if (c > 0 || umode == 1) {
                     ix = dun[sv]; iy = dun[sv + nv]; iz = dun[sv + 2 * (size_t)nv];
                 } else if (umode == 2) {
                     ix = addgo * gon[sv]; iy = addgo * gon[sv + nv]; iz = addgo * gon[sv + 2 * (size_t)nv];
                 }
-                dun[sv] = lg_fma(gx, diff, ix);
-                dun[sv + nv] = lg_fma(gy, diff, iy);
-                dun[sv + 2 * (size_t)nv] = lg_fma(gz, diff, iz);
+                ix = lg_fma(gx, diff, ix);
+                iy = lg_fma(gy, diff, iy);
+                iz = lg_fma(gz, diff, iz);
+                if (VPL > 0 && c + 1 < nc) {
+                    rux[it % NV] = ix; ruy[it % NV] = iy; ruz[it % NV] = iz;
+                } else {
+                    dun[sv] = ix; dun[sv + nv] = iy; dun[sv + 2 * (size_t)nv] = iz;
+                }
             }
         }
         __syncthreads();
@@ -598,7 +620,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
 }
 
 static int g_shear_cfg[6] = {4, 8, 0, 1, 1, 4};  // TX TY TZ(0 = auto) margins MX MY MZ
-static int g_shear_nt = 1024, g_shear_on = 1;
+static int g_shear_nt = 1024, g_shear_on = 1, g_shear_mc = 1;
 
 static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem) {
     int TX = g_shear_cfg[0], TY = g_shear_cfg[1], TZ = g_shear_cfg[2];
@@ -652,9 +674,15 @@ template <int NT>
 static hipError_t launch_shear(float *d_I, float *d_u, const float *go, const float *I, const float *u, double dt, int nc,
                                const ShearGeom &sg, size_t smem, bool bc, bool need_u, int umode, float addgo, hipStream_t s) {
     const bool unit = unit_dt<float>(dt);
+    // several channels with d_u wanted: keep d_u in registers when the workgroup covers the tile in at most 4 passes
+    const int passes = (int)((sg.tile_vox + NT - 1) / NT);
+    const bool mc = need_u && nc > 1 && passes <= 4 && g_shear_mc;
 #define LAGO_SHEAR(NU, UN, B)                                                                                     \
     do {                                                                                                          \
-        auto k = splat_shear_kernel<NT, NU, UN, B>;                                                               \
+        auto k = !mc ? splat_shear_kernel<NT, NU, UN, B, 0>                                                       \
+                     : (passes <= 1 ? splat_shear_kernel<NT, NU, UN, B, (NU ? 1 : 0)>                             \
+                        : passes <= 2 ? splat_shear_kernel<NT, NU, UN, B, (NU ? 2 : 0)>                           \
+                                      : splat_shear_kernel<NT, NU, UN, B, (NU ? 4 : 0)>);                         \
         if (smem > 64 * 1024) {                                                                                   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
@@ -803,7 +831,7 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     int nt;
     if (g.nz < 2) return 1;  // thin volumes take the plain kernel
     if constexpr (sizeof(R) == 4) {
-        if (vec && !(g_splat_mc && need_u && nc > 1)) {
+        if (vec) {
             const int rc = interp_backward_shear((float *)d_I, (float *)d_u, (const float *)go, (const float *)I,
                                                  (const float *)u, dt, nc, nn, g, bc, need_u, umode, (float)addgo, s);
             if (rc != 1) return rc;
@@ -910,6 +938,7 @@ extern "C" {
 // Affects speed only, never results.
 void lago_debug_splat_mc(int on) { lago::g_splat_mc = on; }
 // sheared-window float32 splat: on/off, tile TX TY TZ (0 = auto), margins, threads per workgroup.  Speed only.
+void lago_debug_splat_shear_mc(int on) { lago::g_shear_mc = on; }
 void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
     lago::g_shear_on = on;
     lago::g_shear_cfg[0] = tx; lago::g_shear_cfg[1] = ty; lago::g_shear_cfg[2] = tz;
