@@ -141,6 +141,18 @@ def micro_interp_splat(ext, dev, size, batch=8):
         r["pair_frac_of_hbm_peak"] = r["pair_GBps"] / HBM_PEAK_GBPS
         r["pair_Gvoxel_per_s"] = V / pair / 1e6
         res[label] = r
+    # HBM bytes per launch of the two kernels from the PMC passes over tools/run_micro.py (same workload, same batch)
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic_micro.json")
+    if os.path.exists(tpath) and size == 128 and batch == 8:
+        t = json.load(open(tpath))
+        pick = lambda prefix: next((rec["traffic_bytes"] for name, rec in t.items() if name.startswith(prefix)), None)
+        res["traffic"] = {
+            "source": "profiles/r02_traffic_micro.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, tools/run_micro.py)",
+            "interp_forward": {"kernel": "interp_fwd3_unroll_kernel<float,false,2,true>", "bytes": pick("lago::interp_fwd3_unroll_kernel<float, false"),
+                               "algorithmic_bytes": 20.0 * V},
+            "interp_backward": {"kernel": "splat_shear_kernel<1024,true,true,false,0>", "bytes": pick("lago::splat_shear_kernel<1024, true, true, false, 0>"),
+                                "algorithmic_bytes": 36.0 * V},
+        }
     return res
 
 
@@ -595,7 +607,7 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
             # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
             traffic, tsrc = None, None
-            for tname in ("r02_traffic.json", "r01_traffic.json"):
+            for tname in ("r02_traffic_expmap.json", "r01_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and B == 32 and S == 128:
                     for name, rec in json.load(open(tpath)).items():
