@@ -1,7 +1,9 @@
 """Golden fixtures produced by the REFERENCE's own Python layers (tools/gen_golden_from_reference.py
 ran /root/reference/lagomorph/{deform,diff,metric,adjrep,lddmm,affine}.py over the CPU oracle):
 the host mirror must reproduce them -- exactly on the oracle backend (same extension underneath, so
-any difference is a difference in the Python layer), within fp tolerance through the HIP kernels."""
+any difference is a difference in the Python layer), within north_star's 1e-5 x max |reference| (1e-11 in float64)
+through the HIP kernels: no multipliers; the largest error observed on MI355X is 0.12 of that bound (`sym`,
+float32; profiles/r02_tolerances_golden.json)."""
 import os
 
 import numpy as np
@@ -31,7 +33,10 @@ def T(lm, key, requires_grad=False):
     return t.requires_grad_(True) if requires_grad else t
 
 
-def check(lm, got, key, tag, mult=1.0):
+OBSERVED = {}
+
+
+def check(lm, got, key, tag):
     want = G[key]
     got = got.detach().cpu().numpy()
     assert got.shape == want.shape, key
@@ -41,7 +46,14 @@ def check(lm, got, key, tag, mult=1.0):
     else:
         tol = (1e-5 if tag == "f32" else 1e-11) * mult
         scale = max(np.abs(want).max(), 1e-30)
-        assert np.abs(got.astype(np.float64) - want).max() <= tol * scale, f"{key}: {np.abs(got - want).max():.3e} vs {scale:.3e}"
+        err = np.abs(got.astype(np.float64) - want).max()
+        name = key.split("_", 2)[2] + " " + tag
+        OBSERVED[name] = max(OBSERVED.get(name, 0.0), err / ((1e-5 if tag == "f32" else 1e-11) * scale))
+        out = os.environ.get("LAGO_TOL_REPORT_GOLDEN")
+        if out:
+            import json
+            json.dump(dict(sorted(OBSERVED.items())), open(out, "w"), indent=1)
+        assert err <= tol * scale, f"{key}: {err:.3e} vs {scale:.3e} (allowed {mult} x 1e-5)"
 
 
 @pytest.mark.parametrize("dim,tag", CASES)
@@ -54,8 +66,8 @@ def test_operator_wrappers(lm, dim, tag):
         y = lm.interp(I, u, dt=0.7)
         y.backward(go)
         check(lm, y, k + f"interp_bc{bc}", tag)
-        check(lm, I.grad, k + f"interp_bc{bc}_dI", tag, mult=8)
-        check(lm, u.grad, k + f"interp_bc{bc}_du", tag, mult=8)
+        check(lm, I.grad, k + f"interp_bc{bc}_dI", tag)
+        check(lm, u.grad, k + f"interp_bc{bc}_du", tag)
     a, b = T(lm, k + "u", True), T(lm, k + "m", True)
     y = lm.jacobian_times_vectorfield(a, b)
     y.backward(v)
@@ -78,9 +90,9 @@ def test_fluid_metric_and_luts(lm, dim, tag):
     s = met.sharp(x)
     s.backward(v)
     # sharp amplifies by up to 1/gamma^2 = 1e4: rocFFT vs pocketfft rounding is relative to that scale
-    check(lm, s, k + "sharp", tag, mult=20)
-    check(lm, x.grad, k + "sharp_grad", tag, mult=20)
-    check(lm, met.flat(T(lm, k + "m")), k + "flat", tag, mult=20)
+    check(lm, s, k + "sharp", tag)
+    check(lm, x.grad, k + "sharp_grad", tag)
+    check(lm, met.flat(T(lm, k + "m")), k + "flat", tag)
     for d in range(dim):
         assert np.array_equal(met.luts["cos"][d].cpu().numpy(), G[k + f"lut_cos{d}"])
         assert np.array_equal(met.luts["sin"][d].cpu().numpy(), G[k + f"lut_sin{d}"])
@@ -92,13 +104,13 @@ def test_adjoint_representation_and_compositions(lm, dim, tag):
     u, m, v = T(lm, k + "u"), T(lm, k + "m"), T(lm, k + "v")
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     small = 0.3 * u
-    check(lm, lm.ad(u, m), k + "ad", tag, mult=4)
-    check(lm, lm.ad_star(u, m), k + "ad_star", tag, mult=4)
-    check(lm, lm.Ad_star(small, m), k + "Ad_star", tag, mult=4)
-    check(lm, lm.ad_dagger(u, m, met), k + "ad_dagger", tag, mult=50)
-    check(lm, lm.Ad_dagger(small, m, met), k + "Ad_dagger", tag, mult=50)
-    check(lm, lm.sym(u, m, met), k + "sym", tag, mult=50)
-    check(lm, lm.sym_dagger(u, m, met), k + "sym_dagger", tag, mult=50)
+    check(lm, lm.ad(u, m), k + "ad", tag)
+    check(lm, lm.ad_star(u, m), k + "ad_star", tag)
+    check(lm, lm.Ad_star(small, m), k + "Ad_star", tag)
+    check(lm, lm.ad_dagger(u, m, met), k + "ad_dagger", tag)
+    check(lm, lm.Ad_dagger(small, m, met), k + "Ad_dagger", tag)
+    check(lm, lm.sym(u, m, met), k + "sym", tag)
+    check(lm, lm.sym_dagger(u, m, met), k + "sym_dagger", tag)
     check(lm, lm.compose(u, v, ds=0.5, dt=-0.25), k + "compose", tag)
     check(lm, lm.compose_disp_vel(u, v, dt=-0.1), k + "compose_disp_vel", tag)
     check(lm, lm.compose_vel_disp(v, u, dt=0.2), k + "compose_vel_disp", tag)
@@ -112,11 +124,11 @@ def test_shooting(lm, dim, tag):
     m0 = (0.002 * m).clone().requires_grad_(True)
     h = lm.expmap(met2, m0, num_steps=4)
     h.backward(v)
-    check(lm, h, k + "expmap4", tag, mult=50)
-    check(lm, m0.grad, k + "expmap4_grad", tag, mult=200)
-    check(lm, lm.expmap_advect(met2, 0.002 * m, num_steps=3), k + "expmap_advect3", tag, mult=50)
-    check(lm, lm.EPDiff_step(met2, 0.002 * m, 0.1, 0.2 * (0.3 * u)), k + "EPDiff_step", tag, mult=50)
-    check(lm, lm.expmap(met2, 0.002 * m, num_steps=2, mommask=T(lm, k + "mask")), k + "expmap2_masked", tag, mult=50)
+    check(lm, h, k + "expmap4", tag)
+    check(lm, m0.grad, k + "expmap4_grad", tag)
+    check(lm, lm.expmap_advect(met2, 0.002 * m, num_steps=3), k + "expmap_advect3", tag)
+    check(lm, lm.EPDiff_step(met2, 0.002 * m, 0.1, 0.2 * (0.3 * u)), k + "EPDiff_step", tag)
+    check(lm, lm.expmap(met2, 0.002 * m, num_steps=2, mommask=T(lm, k + "mask")), k + "expmap2_masked", tag)
 
 
 @pytest.mark.parametrize("dim,tag", CASES)
@@ -126,15 +138,15 @@ def test_affine_and_regrid(lm, dim, tag):
     y = lm.affine_interp(I, A, Tt)
     y.backward(go)
     check(lm, y, k + "affine", tag)
-    check(lm, I.grad, k + "affine_dI", tag, mult=8)
-    check(lm, A.grad, k + "affine_dA", tag, mult=64)
-    check(lm, Tt.grad, k + "affine_dT", tag, mult=64)
+    check(lm, I.grad, k + "affine_dI", tag)
+    check(lm, A.grad, k + "affine_dA", tag)
+    check(lm, Tt.grad, k + "affine_dT", tag)
     u = T(lm, k + "u", True)
     newshape = tuple(s + 3 for s in u.shape[2:])
     y = lm.regrid(u, shape=newshape, displacement=True)
     y.backward(T(lm, k + "regrid_disp_go"))
     check(lm, y, k + "regrid_disp", tag)
-    check(lm, u.grad, k + "regrid_disp_grad", tag, mult=8)
+    check(lm, u.grad, k + "regrid_disp_grad", tag)
     check(lm, lm.regrid(T(lm, k + "I"), shape=newshape), k + "regrid_plain", tag)
     Ainv, Tinv = lm.affine_inverse(T(lm, k + "A").cpu(), T(lm, k + "T").cpu())
     assert np.allclose(Ainv.numpy(), G[k + "Ainv"], rtol=1e-5 if tag == "f32" else 1e-12, atol=1e-6 if tag == "f32" else 1e-13)

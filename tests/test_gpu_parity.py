@@ -3,6 +3,10 @@ seeded inputs.  Bit-exact wherever no atomic is involved (the library is built w
 -ffp-contract=off and follows the reference's expression order); tolerance-based for
 scatter-add results, whose summation order is unspecified in the reference too.
 """
+import json
+import os
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -13,7 +17,9 @@ from oracle import lago_oracle as orc
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.float32, torch.float64]
-# fp32 tolerance from BASELINE.json north_star: <=1e-5 relative for interp/metric outputs
+# fp32 tolerance from BASELINE.json north_star: <=1e-5 relative for interp/metric outputs.  Every tolerance-based
+# comparison of this file uses exactly this bound (no multipliers): the largest error observed on MI355X is 0.58 of it
+# (affine d_I, float32; profiles/r02_tolerances.json lists every comparison), 0.016 of the float64 bound.
 RTOL = {torch.float32: 1e-5, torch.float64: 1e-12}
 
 
@@ -22,7 +28,10 @@ def ext():
     import lagomorph_amd
 
     lagomorph_amd.set_debug_mode(True)
-    return lagomorph_amd.lagomorph_ext
+    yield lagomorph_amd.lagomorph_ext
+    out = os.environ.get("LAGO_TOL_REPORT")
+    if out:  # observed errors of this run, in units of the north_star tolerance
+        json.dump(dict(sorted(OBSERVED.items())), open(out, "w"), indent=1)
 
 
 def rnd(rng, shape, dtype, scale=1.0):
@@ -46,12 +55,20 @@ def assert_bits(got, want, what):
         raise AssertionError(f"{what}: not bit-identical, max abs diff {d.max():.3e} at {np.unravel_index(d.argmax(), d.shape)}")
 
 
-def assert_close(got, want, dtype, what, scale=None, mult=1.0):
+OBSERVED = {}  # what -> largest observed error in units of RTOL * scale (tools/tolerance_report.py prints it)
+
+
+def assert_close(got, want, dtype, what, scale=None):
+    """|got - want| <= mult * RTOL[dtype] * scale, scale = max |want| unless given.  RTOL is north_star's 1e-5 for
+    float32 (1e-12 for float64); `mult` > 1 only where a measured, documented reason exists."""
     got, want = host(got).astype(np.float64), np.asarray(want).astype(np.float64)
     assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
     ref = np.abs(want).max() if scale is None else scale
     err = np.abs(got - want).max() if got.size else 0.0
-    assert err <= mult * RTOL[dtype] * max(ref, 1e-30), f"{what}: max err {err:.3e} vs scale {ref:.3e}"
+    units = err / (RTOL[dtype] * max(ref, 1e-30))
+    key = re.sub(r"[\(\[].*$", "", what).strip() + (" f32" if dtype == torch.float32 else " f64")
+    OBSERVED[key] = max(OBSERVED.get(key, 0.0), units)
+    assert units <= mult, f"{what}: max err {err:.3e} = {units:.2f} x {RTOL[dtype]:.0e} x scale {ref:.3e} (allowed {mult})"
 
 
 SHAPES3 = [(5, 6, 7), (8, 8, 8), (3, 4, 1), (2, 2, 2), (9, 5, 70), (6, 5, 16), (3, 4, 128)]
@@ -95,7 +112,7 @@ def test_interp_backward(ext, dtype, mode, sp, nn, nc, bc):
             dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 0.8, need_I, need_u)
             oI, ou = orc.interp_backward(go, I, u, 0.8, need_I, need_u)
             assert_bits(du, ou, f"d_u (need_I={need_I}, need_u={need_u})")   # thread-owned: exact
-            assert_close(dI, oI, dtype, f"d_I (need_I={need_I}, need_u={need_u})", mult=4.0)  # atomic order
+            assert_close(dI, oI, dtype, f"d_I (need_I={need_I}, need_u={need_u})")  # (summation order of the atomics)
     finally:
         ext.set_splat_mode(1)
 
@@ -121,7 +138,7 @@ def test_tiled_splat_any_tile_config(ext, dtype, tile):
             ext.set_splat_tile(0, 8, 0, 1, 1, 4, 512)  # the library default
             ext.set_splat_mode(1)
         assert_bits(du, ou, f"d_u mode {mode}")
-        assert_close(dI, oI, dtype, f"d_I mode {mode}", mult=4.0)
+        assert_close(dI, oI, dtype, f"d_I mode {mode}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -151,7 +168,7 @@ def test_interp_hessian_diagonal(ext, dtype):
     I = rnd(rng, (2, 3, 9, 8), dtype)
     u = _disp(rng, 2, (9, 8), dtype)
     assert_close(ext.interp_hessian_diagonal_image(dev(I), dev(u), 0.6), orc.interp_hessian_diagonal_image(I, u, 0.6),
-                 dtype, "hessian diagonal", mult=8.0)
+                 dtype, "hessian diagonal")
 
 
 JSHAPES = [(5, 6, 7), (2, 2, 2), (8, 4, 66), (7, 9), (2, 2), (3, 70)]
@@ -233,7 +250,7 @@ def test_fluid_metric_sharp_flat_vs_oracle(ext, dtype, sp):
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     for inv, f in ((True, met.sharp), (False, met.flat)):
         want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inv)
-        assert_close(f(dev(m)), want, dtype, f"fluid inverse={inv}", mult=10.0)
+        assert_close(f(dev(m)), want, dtype, f"fluid inverse={inv}")
     # LUT values: float64 numpy rounded through float32 (metric.py:66-75), bit for bit
     cos, sin = orc.fluid_luts(sp, m.dtype)
     for a, b in zip(met.luts["cos"] + met.luts["sin"], cos + sin):
@@ -256,16 +273,16 @@ def test_affine_interp(ext, dtype, sp, nn, nc, bc):
         oI, oA, oT = orc.affine_interp_backward(go, I, A, T, *needs)
         nvox = float(np.prod(sp)) * nc
         if needs[0]:
-            assert_close(dI, oI, dtype, "affine d_I", mult=4.0)
+            assert_close(dI, oI, dtype, "affine d_I")
         else:
             assert dI.numel() == 0
         # dA/dT are sums over nvox terms; fp32 summation order differs from the reference's tree
         if needs[1]:
-            assert_close(dA, oA, dtype, "affine d_A", scale=np.abs(oA).max() + np.sqrt(nvox) * max(sp), mult=8.0)
+            assert_close(dA, oA, dtype, "affine d_A", scale=np.abs(oA).max() + np.sqrt(nvox) * max(sp))
         else:
             assert dA.numel() == 0
         if needs[2]:
-            assert_close(dT, oT, dtype, "affine d_T", scale=np.abs(oT).max() + np.sqrt(nvox), mult=8.0)
+            assert_close(dT, oT, dtype, "affine d_T", scale=np.abs(oT).max() + np.sqrt(nvox))
         else:
             assert dT.numel() == 0
 
@@ -281,7 +298,7 @@ def test_regrid(ext, dtype, sp, out):
     assert_bits(ext.regrid_forward(dev(I), out, origin, spacing), orc.regrid_forward(I, out, origin, spacing), "regrid forward")
     go = rnd(rng, (2, 3) + out, dtype)
     assert_close(ext.regrid_backward(dev(go), sp, out, origin, spacing), orc.regrid_backward(go, sp, out, origin, spacing),
-                 dtype, "regrid backward", mult=4.0)
+                 dtype, "regrid backward")
 
 
 def test_reference_known_answers_through_hip(ext):
@@ -362,8 +379,8 @@ def test_fused_fluid_metric_matches_three_call_form(ext, dtype, sp, inverse):
     finally:
         lmm.USE_FUSED_FLUID = True
     want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
-    assert_close(fused, want, dtype, "fused fluid metric vs oracle", mult=10.0)
-    assert_close(fused, host(plain), dtype, "fused vs three-call", mult=10.0)
+    assert_close(fused, want, dtype, "fused fluid metric vs oracle")
+    assert_close(fused, host(plain), dtype, "fused vs three-call")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -409,8 +426,8 @@ def test_fused_fluid_metric_paths(ext, sp, inverse):
         ext.set_fluid_mode(2)
     want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
     for mode in (2, 1, 0):
-        assert_close(got[mode], want, torch.float32, f"fluid metric mode {mode} vs oracle", mult=10.0)
-    assert_close(got[2], host(got[0]), torch.float32, "native passes vs plain hipFFT", mult=10.0)
+        assert_close(got[mode], want, torch.float32, f"fluid metric mode {mode} vs oracle")
+    assert_close(got[2], host(got[0]), torch.float32, "native passes vs plain hipFFT")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -439,13 +456,13 @@ def test_affine_backward_tiled_splat(ext, dtype, kind, bc):
     go = rnd(rng, (nn, nc) + sp, dtype)
     dI, dA, dT = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, True, True)
     oI, oA, oT = orc.affine_interp_backward(go, I, A, T, True, True, True)
-    assert_close(dI, oI, dtype, "affine d_I (tiled)", mult=8.0)
+    assert_close(dI, oI, dtype, "affine d_I (tiled)")
     ext.set_splat_mode(0)
     try:
         dI0, _, _ = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, False, False)
     finally:
         ext.set_splat_mode(1)
-    assert_close(dI0, oI, dtype, "affine d_I (global atomics)", mult=8.0)
+    assert_close(dI0, oI, dtype, "affine d_I (global atomics)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -458,13 +475,13 @@ def test_regrid_backward_tiled_splat(ext, dtype, sp, out, scale):
     spacing = [scale * (a - 1) / (b - 1) for a, b in zip(sp, out)]
     go = rnd(rng, (2, 3) + out, dtype)
     want = orc.regrid_backward(go, sp, out, origin, spacing)
-    assert_close(ext.regrid_backward(dev(go), sp, out, origin, spacing), want, dtype, "regrid backward (tiled)", mult=8.0)
+    assert_close(ext.regrid_backward(dev(go), sp, out, origin, spacing), want, dtype, "regrid backward (tiled)")
     ext.set_splat_mode(0)
     try:
         got0 = ext.regrid_backward(dev(go), sp, out, origin, spacing)
     finally:
         ext.set_splat_mode(1)
-    assert_close(got0, want, dtype, "regrid backward (global atomics)", mult=8.0)
+    assert_close(got0, want, dtype, "regrid backward (global atomics)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -514,8 +531,8 @@ def test_fused_ad_star_backward_matches_unfused(ext, dtype, sp):
         finally:
             adjrep.USE_FUSED_AD_STAR = True
     assert torch.equal(grads[True][0], grads[False][0])
-    assert_close(grads[True][1], host(grads[False][1]), dtype, "d_phiinv", mult=4.0)
-    assert_close(grads[True][2], host(grads[False][2]), dtype, "d_m", mult=4.0)
+    assert_close(grads[True][1], host(grads[False][1]), dtype, "d_phiinv")
+    assert_close(grads[True][2], host(grads[False][2]), dtype, "d_m")
 
 
 def test_ad_star_rejects_bad_arguments(ext):
@@ -579,7 +596,7 @@ def test_coefficient_table_cache_is_keyed_on_lut_contents(ext):
         met = lm.FluidMetric([0.1, 0.05, 0.01])  # a fresh metric: fresh LUT tensors, possibly at recycled addresses
         for inv, f in ((True, met.sharp), (False, met.flat)):
             assert_close(f(dev(m)), orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inv), torch.float32,
-                         f"sharp/flat {sp} inverse={inv}", mult=10.0)
+                         f"sharp/flat {sp} inverse={inv}")
         del met
         gc.collect()
         torch.cuda.empty_cache()
@@ -592,7 +609,7 @@ def test_coefficient_table_cache_is_keyed_on_lut_contents(ext):
     n0 = ext.fluid_cache_entries()
     got = ext.fluid_metric(dev(m), True, met.luts["cos"], met.luts["sin"], 0.1, 0.05, 0.01, lut_generation=0)
     assert ext.fluid_cache_entries() == n0
-    assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "uncached", mult=10.0)
+    assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "uncached")
     ext.fluid_cache_clear()
     assert ext.fluid_cache_entries() == 0
 
@@ -626,16 +643,16 @@ def test_interp_backward_fused_start_values(ext, dtype, sp, dt):
         # accumulate onto zeros == the reference operator, bit for bit
         dI0, du0 = ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, True, d_u=torch.zeros_like(dev(u)))
         assert_bits(du0, ou, "fused, zero start")
-        assert_close(dI0, oI, dtype, "fused d_I", mult=4.0)
+        assert_close(dI0, oI, dtype, "fused d_I")
         dI1, du1 = ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, True, d_u=dev(start))
         scale = np.abs(ou).max() + np.abs(start).max()
-        assert_close(du1, start.astype(np.float64) + ou, dtype, "fused, accumulate", scale=scale, mult=4.0)
-        assert_close(dI1, oI, dtype, "fused d_I (accumulate)", mult=4.0)
+        assert_close(du1, start.astype(np.float64) + ou, dtype, "fused, accumulate", scale=scale)
+        assert_close(dI1, oI, dtype, "fused d_I (accumulate)")
         if nc == d:
             _, du2 = ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, False, addgo=0.37)
             k = go.dtype.type
             assert_close(du2, (k(0.37) * go).astype(np.float64) + ou, dtype, "fused, addgo",
-                         scale=np.abs(ou).max() + np.abs(go).max(), mult=4.0)
+                         scale=np.abs(ou).max() + np.abs(go).max())
     with pytest.raises(RuntimeError, match="exactly one"):
         ext.interp_backward_fused(dev(go), dev(I), dev(u), dt, True)
     with pytest.raises(RuntimeError, match="as many channels"):
@@ -677,5 +694,5 @@ def test_fused_compose_backward_matches_unfused(ext, dtype, sp):
         lm.compose(a, b, ds=ds, dt=dt).backward(go)
         p, q = u0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
         (ds * p + dt * lm.interp(q, p, dt=ds)).backward(go)
-        assert_close(a.grad, host(p.grad), dtype, f"compose d_u ds={ds} dt={dt}", mult=4.0)
-        assert_close(b.grad, host(q.grad), dtype, f"compose d_v ds={ds} dt={dt}", mult=4.0)
+        assert_close(a.grad, host(p.grad), dtype, f"compose d_u ds={ds} dt={dt}")
+        assert_close(b.grad, host(q.grad), dtype, f"compose d_v ds={ds} dt={dt}")
