@@ -50,7 +50,11 @@ int lago_abi_version(void);
 const char *lago_version(void);
 const char *lago_last_error(void);
 
-/* Tuning knob for interp_backward: 0 = global float atomics only,
+/* Tuning settings.  All of them are PROCESS-WIDE, stored atomically (they may be changed while other host threads,
+ * e.g. autograd's backward threads, are inside entry points: a call sees the old or the new setting as a whole) and
+ * affect speed only, never which results are produced beyond the rounding differences documented per setting.
+ * The defaults are what the product runs with; the parity tests sweep them. */
+/* interp_backward: 0 = global float atomics only,
  * 1 = LDS-privatised splat with atomic flush (default for 3D f32). */
 void lago_set_splat_mode(int mode);
 int lago_get_splat_mode(void);

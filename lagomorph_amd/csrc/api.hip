@@ -6,9 +6,9 @@
 
 namespace lago {
 
-static int g_debug = 0;
-int g_splat_mode = 1;
-int g_interp_vec = 1;
+static std::atomic<int> g_debug{0};
+std::atomic<int> g_splat_mode{1};
+std::atomic<int> g_interp_vec{1};
 static thread_local char g_err[512] = "";
 
 int fail_invalid(const char *fmt, ...) {

@@ -13,6 +13,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <array>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -27,8 +30,24 @@ constexpr int kBlock = 256;
 int fail_invalid(const char *fmt, ...);
 int fail_hip(hipError_t e, const char *what);
 int finish_launch(hipStream_t s, const char *what);  // hipGetLastError (+ sync in debug mode)
-extern int g_splat_mode;
-extern int g_interp_vec;  // 1: use the vectorised 3D kernels when shapes allow (default)
+// process-wide tuning settings (speed only, never results): atomics, because autograd runs the backward entry
+// points on threads of its own while a host thread may change a setting
+template <int N>
+struct KnobArray {  // array-valued setting: read and written as a whole under a mutex
+    std::mutex mu;
+    std::array<int, N> v;
+    KnobArray(std::array<int, N> init) : v(init) {}
+    std::array<int, N> get() {
+        std::lock_guard<std::mutex> l(mu);
+        return v;
+    }
+    void set(std::array<int, N> nv) {
+        std::lock_guard<std::mutex> l(mu);
+        v = nv;
+    }
+};
+extern std::atomic<int> g_splat_mode;
+extern std::atomic<int> g_interp_vec;  // 1: use the vectorised 3D kernels when shapes allow (default)
 
 #define LAGO_HIP_TRY(expr)                                      \
     do {                                                        \

@@ -41,7 +41,7 @@ int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int6
 // 0: rocFFT 3D plan + operator kernel; 1: rocFFT 2D (y, z) plan + fused x pass (fftx.hip);
 // 2: three LDS-tiled passes, no rocFFT (fft3.hip).  Each falls back to the previous one where the
 // shape is not supported.
-int g_fluid_xpass = 2;
+std::atomic<int> g_fluid_xpass{2};
 
 // Operator coefficient tables (see fftx.hip), cached like the FFT plans: one device buffer per
 // (LUT generation, shape, parameters, direction), filled by a kernel on first use.  The key holds no

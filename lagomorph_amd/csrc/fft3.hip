@@ -162,8 +162,8 @@ static hipError_t xpass2_dispatch(int64_t nx, const fl::XArgs &a, bool inverse, 
     return hipErrorInvalidValue;
 }
 
-int g_xpass_ipw = 2;  // batch items per x-pass workgroup
-int g_native_stage_mask = 7;  // profiling only: bit 0 zy forward, bit 1 x pass, bit 2 zy inverse
+std::atomic<int> g_xpass_ipw{2};  // batch items per x-pass workgroup
+std::atomic<int> g_native_stage_mask{7};  // profiling only: bit 0 zy forward, bit 1 x pass, bit 2 zy inverse
 
 // out = irfftn(operator(rfftn(m))) * scale.  tab: split-layout coefficient table (fluid_coef_launch
 // with split = 1).  work: nn*3*nx*ny*(nz/2+1) complex.
@@ -189,14 +189,15 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     xa.items_per_n = (int)items;
     xa.scale = (float)scale;
     xa.nn = (int)nn;
-    xa.ipw = g_xpass_ipw > 0 ? g_xpass_ipw : 1;
+    const int ipw = g_xpass_ipw, stages = g_native_stage_mask;
+    xa.ipw = ipw > 0 ? ipw : 1;
     xa.total = (uint32_t)((nn + xa.ipw - 1) / xa.ipw * items);
     hipError_t e = hipSuccess;
-    if (g_native_stage_mask & 1) e = zy_dispatch(ny, nz, za, false, s);
+    if (stages & 1) e = zy_dispatch(ny, nz, za, false, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy forward)");
-    if (g_native_stage_mask & 2) e = xpass2_dispatch(nx, xa, inverse != 0, s);
+    if (stages & 2) e = xpass2_dispatch(nx, xa, inverse != 0, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (x pass)");
-    if (g_native_stage_mask & 4) e = zy_dispatch(ny, nz, za, true, s);
+    if (stages & 4) e = zy_dispatch(ny, nz, za, true, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy inverse)");
     return finish_launch(s, "fluid_metric");
 }

@@ -235,7 +235,7 @@ int fluid_coef_launch(float *tab, int inverse, const float *cosX, const float *s
     return finish_launch(s, "fluid_coef");
 }
 
-int g_xpass_dbg = 0;  // profiling only (results are wrong when != 0)
+std::atomic<int> g_xpass_dbg{0};  // profiling only (results are wrong when != 0)
 bool fluid_xpass_supported(int64_t nx) { return nx == 64 || nx == 128 || nx == 256; }
 
 template <int LOGN>
@@ -256,10 +256,10 @@ static hipError_t xpass_launch(float2 *F, const float *tab, int inverse, int64_t
     }
     if (inverse)
         hipLaunchKernelGGL(kinv, dim3((uint32_t)total), dim3(256), smem, s, F, tab, (int)ny, (int)nzc, KC, nchunks, scale,
-                           (uint32_t)total, g_xpass_dbg);
+                           (uint32_t)total, (int)g_xpass_dbg);
     else
         hipLaunchKernelGGL(kfwd, dim3((uint32_t)total), dim3(256), smem, s, F, tab, (int)ny, (int)nzc, KC, nchunks, scale,
-                           (uint32_t)total, g_xpass_dbg);
+                           (uint32_t)total, (int)g_xpass_dbg);
     return hipSuccess;
 }
 

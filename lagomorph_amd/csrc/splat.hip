@@ -66,7 +66,7 @@ struct TileGeom {
 };
 
 // TX TY TZ(0 = auto) window margins MX MY MZ around the probed origin, threads per workgroup
-static int g_tile_cfg[7] = {0, 8, 0, 1, 1, 4, 512};
+static KnobArray<7> g_tile_cfg({0, 8, 0, 1, 1, 4, 512});
 
 __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -619,12 +619,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
     }
 }
 
-static int g_shear_cfg[6] = {4, 8, 0, 1, 1, 4};  // TX TY TZ(0 = auto) margins MX MY MZ
-static int g_shear_nt = 1024, g_shear_on = 1, g_shear_mc = 1;
+static KnobArray<6> g_shear_cfg({4, 8, 0, 1, 1, 4});  // TX TY TZ(0 = auto) margins MX MY MZ
+static std::atomic<int> g_shear_nt{1024}, g_shear_on{1}, g_shear_mc{1};
 
 static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem) {
-    int TX = g_shear_cfg[0], TY = g_shear_cfg[1], TZ = g_shear_cfg[2];
-    const int EX = g_shear_cfg[3], EY = g_shear_cfg[4], EZ = g_shear_cfg[5];
+    const std::array<int, 6> cfg = g_shear_cfg.get();
+    int TX = cfg[0], TY = cfg[1], TZ = cfg[2];
+    const int EX = cfg[3], EY = cfg[4], EZ = cfg[5];
     if (g.nz < 2 || TX < 1 || TY < 1 || EX < 0 || EY < 0 || EZ < 0) return false;
     // strides must fit the 24-bit multiplies
     if ((uint64_t)g.ny * g.nz * 4 >= (1u << 24) || g.nx >= (1 << 23)) return false;
@@ -710,8 +711,9 @@ static int interp_backward_shear(float *d_I, float *d_u, const float *go, const 
     size_t smem;
     if (!make_shear(sg, g, nn, smem)) return 1;
     hipError_t e;
-    if (g_shear_nt >= 1024) e = launch_shear<1024>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
-    else if (g_shear_nt >= 512) e = launch_shear<512>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
+    const int shear_nt = g_shear_nt;
+    if (shear_nt >= 1024) e = launch_shear<1024>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
+    else if (shear_nt >= 512) e = launch_shear<512>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
     else e = launch_shear<256>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
     if (e != hipSuccess) return fail_hip(e, "interp_backward (sheared-window splat)");
     return finish_launch(s, "interp_backward (sheared-window splat)");
@@ -721,7 +723,9 @@ static int interp_backward_shear(float *d_I, float *d_u, const float *go, const 
 // target cells one source step spans along axis d (1 for a displacement field); when given, the
 // tile is shrunk until its image fits the LDS window.
 static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, const double *sc, size_t &smem,
-                       int &nthreads, const int *cfg = g_tile_cfg) {
+                       int &nthreads, const int *cfg_in = nullptr) {
+    const std::array<int, 7> cfg_set = g_tile_cfg.get();
+    const int *cfg = cfg_in ? cfg_in : cfg_set.data();
     int TX = cfg[0], TY = cfg[1], TZ = cfg[2];
     const int EX = cfg[3], EY = cfg[4], EZ = cfg[5];
     nthreads = cfg[6] >= 1024 ? 1024 : (cfg[6] >= 512 ? 512 : 256);
@@ -796,7 +800,7 @@ static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, 
     return true;
 }
 
-int g_splat_mc = 1;  // 1: multi-channel single-pass form of interp_backward where it applies
+std::atomic<int> g_splat_mc{1};  // 1: multi-channel single-pass form of interp_backward where it applies
 
 template <typename R, int MODE, bool BC, bool NEED_U, int NT, int VPL, bool MC = false>
 static hipError_t launch_tiled(R *d_I, R *d_u, const R *go, const R *I, const PosArgs &pa, int nc,
@@ -941,13 +945,10 @@ void lago_debug_splat_mc(int on) { lago::g_splat_mc = on; }
 void lago_debug_splat_shear_mc(int on) { lago::g_shear_mc = on; }
 void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
     lago::g_shear_on = on;
-    lago::g_shear_cfg[0] = tx; lago::g_shear_cfg[1] = ty; lago::g_shear_cfg[2] = tz;
-    lago::g_shear_cfg[3] = mx; lago::g_shear_cfg[4] = my; lago::g_shear_cfg[5] = mz;
+    lago::g_shear_cfg.set({tx, ty, tz, mx, my, mz});
     lago::g_shear_nt = nthreads;
 }
 void lago_set_splat_tile(int tx, int ty, int tz, int ex, int ey, int ez, int nthreads) {
-    lago::g_tile_cfg[0] = tx; lago::g_tile_cfg[1] = ty; lago::g_tile_cfg[2] = tz;
-    lago::g_tile_cfg[3] = ex; lago::g_tile_cfg[4] = ey; lago::g_tile_cfg[5] = ez;
-    lago::g_tile_cfg[6] = nthreads;
+    lago::g_tile_cfg.set({tx, ty, tz, ex, ey, ez, nthreads});
 }
 }
