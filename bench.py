@@ -124,13 +124,14 @@ def micro_interp_splat(ext, dev, size, batch=8):
     V = batch * size ** 3
     res = {"workload": f"interp+splat batch {batch} x 1x{size}^3 fp32 (configs[1])"}
     for label, uu in (("smooth", u), ("rough", 2.0 * torch.randn_like(u))):
-        fwd_med, _ = time_op(lambda: ext.interp_forward(I, uu, 1.0))
+        # (the first ~30 launches after new allocations run 8 % slower than the steady state: warm up past them)
+        fwd_med, _ = time_op(lambda: ext.interp_forward(I, uu, 1.0), reps=30, warm=30)
         r = {"fwd_ms": fwd_med, "fwd_GBps": 20.0 * V / fwd_med / 1e6}
         for mode in (1, 0):
             ext.set_splat_mode(mode)
             # the global-atomics leg is only a comparison figure: few repetitions
             bwd_med, _ = time_op(lambda: ext.interp_backward(go, I, uu, 1.0, True, True),
-                                 reps=20 if mode == 1 else 4, warm=5 if mode == 1 else 1)
+                                 reps=30 if mode == 1 else 4, warm=(30 if label == "smooth" else 5) if mode == 1 else 1)
             tag = "lds" if mode == 1 else "atomics"
             r[f"bwd_{tag}_ms"] = bwd_med
             r[f"bwd_{tag}_GBps"] = 36.0 * V / bwd_med / 1e6
