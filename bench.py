@@ -248,12 +248,14 @@ def micro_atlas_step(lm, dev, size, batch=8):
 
 # Algorithmic bytes per voxel of one lddmm_step with S integration steps (fp32, d = 3, one image channel; every
 # tensor counted once per operator of an ideally fused implementation, SURVEY 8d conventions):
-#   forward  per Euler step: Ad_star 36 + sharp 72.8 + compose 36                                   = 144.8
-#   backward per Euler step: compose^T 60 (go, u, v in; d_u, d_v out) + sharp 72.8 + Ad_star^T 60     = 192.8
+#   forward  per general Euler step: Ad_star 36 + sharp 72.8 + compose 36                              = 144.8
+#   backward per general Euler step: compose^T 60 (go, u, v in; d_u, d_v out) + sharp 72.8 + Ad_star^T 60 = 192.8
+#   the first Euler step (from the identity, closed form phi_1 = -dt sharp(m0), sharp(m0) shared with the
+#         regulariser): 24 forward (v in, phi out), 24 + 36 backward (scale; sum with the regulariser's gradient)  = 84
 #   once: interp(I, h) 16 + its backward 28 (atlas broadcast: I and d_I are 1/B of a voxel each) + mse fwd/bwd 8 + 12
 #         + reg term: sharp 72.8 forward and backward + <v, m> 24 + momentum update 36
 def lddmm_step_alg_bytes_per_voxel(steps):
-    return steps * (144.8 + 192.8) + 16 + 28 + 8 + 12 + 2 * 72.8 + 24 + 36
+    return (steps - 1) * (144.8 + 192.8) + 84 + 16 + 28 + 8 + 12 + 2 * 72.8 + 24 + 36
 
 
 def atlas_leg(lm, dev, world, rank, args):
@@ -553,7 +555,18 @@ def main():
             kt.enabled = False
             ksum = kt.summary()
         hmax = h.abs().max().item()
-        del h
+        # for comparison, untimed region: the same shoot with every Euler step through the general kernels (an explicit
+        # zero phiinv switches off the closed-form first step; same result bit for bit)
+        z = torch.zeros_like(m)
+        lm.expmap(metric, m, num_steps=E, phiinv=z)
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        for _ in range(min(args.steps, 3)):
+            hg = lm.expmap(metric, m, num_steps=E, phiinv=z)
+        torch.cuda.synchronize()
+        t_general = (time.perf_counter() - tg0) / min(args.steps, 3)
+        same_bits = bool(torch.equal(hg, h))
+        del h, hg, z
     elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -576,7 +589,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"lddmm.expmap, {E} Euler steps, global batch {GBATCH} x 3x{S}^3 fp32 sharded {B} per GPU "
-                        "(BASELINE configs[3]); value counts voxels x Euler steps",
+                        "(BASELINE configs[3]); value counts voxels x Euler steps; shooting from the identity, the "
+                        "first Euler step is evaluated in closed form (-dt sharp(m0): the bits EPDiff_step returns)",
+            "all_steps_through_the_general_kernels": {"ms_per_step": 1e3 * t_general, "local_voxel_steps_per_s":
+                                                      B * S ** 3 * E / t_general, "same_bits": same_bits},
             "global_batch": GBATCH, "per_gpu_batch": B, "volume": [S, S, S], "euler_steps": E,
             "parallelism": f"batch-sharded x{world}, no data-path collective in expmap; the atlas step "
                            "(atlas_step below) all-reduces the atlas gradient over RCCL",

@@ -56,12 +56,16 @@ class ExpmapFunction(torch.autograd.Function):
     differentiating the loop, so the gradients agree to the rounding of the summation order."""
 
     @staticmethod
-    def forward(ctx, metric, m0, phiinv, dt, num_steps):
+    def forward(ctx, metric, m0, phiinv, dt, num_steps, v0):
         m0 = m0.contiguous()
-        phi = torch.zeros_like(m0) if phiinv is None else phiinv.contiguous()
-        keep = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        keep = ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[5]
         steps = []
-        for _ in range(num_steps):
+        first = phiinv is None   # shooting from the identity: the first Euler step in closed form (see `expmap`)
+        if first:
+            phi = _first_step(metric, m0, dt, v0)
+        else:
+            phi = phiinv.contiguous()
+        for _ in range(num_steps - 1 if first else num_steps):
             if keep:
                 m, mphi = lagomorph_ext.Ad_star(phi, m0, save_resampled=True)
             else:
@@ -72,15 +76,15 @@ class ExpmapFunction(torch.autograd.Function):
             if keep:
                 steps.append((phi, v, mphi))
             phi = nxt
-        ctx.metric, ctx.dt, ctx.steps, ctx.m0 = metric, dt, steps, m0
+        ctx.metric, ctx.dt, ctx.steps, ctx.m0, ctx.first, ctx.has_v0 = metric, dt, steps, m0, first, v0 is not None
         return phi
 
     @staticmethod
     def backward(ctx, G):
         metric, dt, m0 = ctx.metric, ctx.dt, ctx.m0
-        need_m, need_phi = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_m, need_phi, need_v0 = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[5]
         G = G.contiguous()
-        d_m0 = torch.zeros_like(m0)
+        d_m0 = torch.zeros_like(m0) if (ctx.steps or not ctx.first) else None
         for phi, v, mphi in reversed(ctx.steps):
             d_phi, d_v = lagomorph_ext.interp_backward_fused(G, phi, v, -dt, True, addgo=-dt)
             d_m = metric.sharp(d_v)
@@ -90,32 +94,67 @@ class ExpmapFunction(torch.autograd.Function):
             del d_m
             _, G = lagomorph_ext.interp_backward_fused(d_w, m0, phi, 1.0, True, d_u=d_phi, d_I=d_m0)
         ctx.steps = None
-        return None, d_m0 if need_m else None, G if need_phi else None, None, None
+        d_v0 = None
+        if ctx.first:
+            # phi_1 = -dt sharp(m0): what the general step's kernels return at phi_0 = 0 (the splats are identities,
+            # the position gradients vanish), without running them
+            d_v0 = G * (-dt)
+            if not ctx.has_v0:   # sharp(m0) was computed here: through the (self-adjoint) operator onto d_m0
+                d_m = metric.sharp(d_v0)
+                d_m0 = d_m if d_m0 is None else d_m0.add_(d_m)
+                d_v0 = None
+            elif d_m0 is None:
+                d_m0 = torch.zeros_like(m0)
+            G = None
+        return (None, d_m0 if need_m else None, G if need_phi else None, None, None,
+                d_v0 if (need_v0 and ctx.has_v0) else None)
 
 
-def _fused_expmap_ok(metric, m0, phiinv, mommask):
+def _first_step(metric, m0, dt, v0=None, mommask=None):
+    """The Euler step from the identity in closed form.  With phi^-1 = id (zero displacement) `Ad_star` returns m0
+    itself (the resampling is the identity and the Jacobian of the zero field vanishes: m0 + 0) and
+    `compose_disp_vel(0, v, -dt)` returns 0 + (-dt) v: the same bits as `EPDiff_step` (lddmm.py:39-44) produces
+    through the Ad_star and compose kernels (up to the sign of exact zeros), for finite m0.  v0: sharp(m0) if the
+    caller already has it."""
+    m = m0 if mommask is None else m0 * mommask
+    v = metric.sharp(m) if (v0 is None or mommask is not None) else v0
+    return v * (-dt)
+
+
+def _fused_expmap_ok(metric, m0, phiinv, mommask, v0):
+    grads = m0.requires_grad or (phiinv is not None and phiinv.requires_grad) or (v0 is not None and v0.requires_grad)
     return (USE_FUSED_EXPMAP and mommask is None and isinstance(metric, FluidMetric) and m0.is_cuda
             and m0.size(1) == m0.dim() - 2 and m0.dtype in (torch.float32, torch.float64)
             and (phiinv is None or (phiinv.shape == m0.shape and phiinv.dtype == m0.dtype))
             and all(hasattr(lagomorph_ext, n) for n in ("Ad_star", "compose", "interp_backward_fused"))
-            and torch.is_grad_enabled() and (m0.requires_grad or (phiinv is not None and phiinv.requires_grad)))
+            and torch.is_grad_enabled() and grads)
 
 
-def expmap(metric, m0, T=1.0, num_steps=10, phiinv=None, mommask=None, checkpoints=False):
+def expmap(metric, m0, T=1.0, num_steps=10, phiinv=None, mommask=None, checkpoints=False, v0=None):
     """Exponential map: returns the displacement of phi^-1 (lddmm.py:73-105).
 
     Only ``checkpoints=False`` is supported.  The reference's checkpointed branch is dead
     code (``EPDiffStepsFunction`` swaps dt/phiinv, lddmm.py:56,64; the integer branch
     computes step counts and then integrates nothing, lddmm.py:93-95), so it is rejected
-    here instead of being reproduced."""
-    if phiinv is None:
-        phiinv = torch.zeros_like(m0)
+    here instead of being reproduced.
+
+    When no ``phiinv`` is given the shoot starts at the identity and its first Euler step is evaluated in closed
+    form, phi^-1_1 = -dt sharp(m0) (`_first_step`): the values `EPDiff_step` would return, without its two gather
+    kernels (and, in the backward pass, without their two splats and the Jacobian adjoint).  ``v0`` (not in the
+    reference): sharp(m0) when the caller has computed it already -- `lddmm_step` needs it for its regulariser."""
     if checkpoints:
         raise NotImplementedError("expmap(checkpoints=...) is broken in the reference and not provided")
+    if num_steps <= 0:
+        return torch.zeros_like(m0) if phiinv is None else phiinv
     dt = T / num_steps
-    if num_steps > 0 and _fused_expmap_ok(metric, m0, phiinv, mommask):
-        return ExpmapFunction.apply(metric, m0, phiinv, dt, num_steps)
-    for _ in range(num_steps):
+    if v0 is not None and (phiinv is not None or mommask is not None):
+        v0 = None
+    if _fused_expmap_ok(metric, m0, phiinv, mommask, v0):
+        return ExpmapFunction.apply(metric, m0, phiinv, dt, num_steps, v0)
+    first = phiinv is None
+    if first:
+        phiinv = _first_step(metric, m0, dt, v0, mommask)
+    for _ in range(num_steps - 1 if first else num_steps):
         phiinv = EPDiff_step(metric, m0, dt, phiinv, mommask=mommask)
     return phiinv
 
@@ -136,11 +175,11 @@ def lddmm_step(I, m, img, metric, dataset_size, integration_steps=5, reg_weight=
         m.grad.detach_()
         m.grad.zero_()
     regrid_momenta = tuple(m.shape[2:]) != tuple(I.shape[2:])
-    h = expmap(metric, m, num_steps=integration_steps)
+    v = metric.sharp(m)   # (lddmm.py:309; computed first here: it is also the velocity of the first Euler step)
+    h = expmap(metric, m, num_steps=integration_steps, v0=v)
     if regrid_momenta:  # upscale the deformation to apply to the atlas (lddmm.py:306-307; as coded there,
         h = regrid(h, shape=I.shape[2:])  # without displacement=True: values stay in coarse-grid voxels)
     Idef = deform.interp(I, h)
-    v = metric.sharp(m)
     reg_term = reg_weight * (v * m).sum() / img.numel()
     if regrid_momenta:  # account for downscaling in averaging (lddmm.py:311-312)
         reg_term = reg_term * (I.numel() / v[0, 0, ...].numel())

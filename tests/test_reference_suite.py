@@ -181,6 +181,48 @@ def test_expmap_zero(lm, bs, dim, step):
     assert torch.allclose(m, h)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("masked", TF)
+def test_expmap_first_step_closed_form(lm, dim, dtype, masked):
+    """expmap without a phiinv evaluates the Euler step from the identity as -dt sharp(m0) (lddmm._first_step).  That
+    must be what the reference's loop returns when it is run step by step from an explicit zero displacement
+    (lddmm.py:39-44, :99-104) through the Ad_star and compose kernels: the same displacement bit for bit, and the same
+    gradient with respect to the momentum."""
+    from lagomorph_amd import lddmm
+
+    sp = (9, 10, 11)[:dim] if dim == 3 else (17, 12)
+    met = lm.FluidMetric([0.1, 0.01, 0.01])
+    m0 = torch.randn((2, dim) + sp, dtype=torch.float64, device=lm._test_device)
+    m0 = (m0 * (2.0 / met.sharp(m0).abs().max())).to(dtype)
+    mask = (torch.rand((2, 1) + sp, device=lm._test_device) > 0.3).to(dtype) if masked else None
+    go = torch.randn((2, dim) + sp, dtype=torch.float64, device=lm._test_device).to(dtype)
+    steps = 3
+    a = m0.clone().requires_grad_(True)
+    h = lm.expmap(met, a, num_steps=steps, mommask=mask)
+    h.backward(go)
+    b = m0.clone().requires_grad_(True)
+    phi = torch.zeros_like(m0)
+    for _ in range(steps):
+        phi = lddmm.EPDiff_step(met, b, 1.0 / steps, phi, mommask=mask)
+    phi.backward(go)
+    assert torch.equal(h, phi)
+    scale = float(b.grad.abs().max())
+    assert float((a.grad - b.grad).abs().max()) <= (1e-13 if dtype == torch.float64 else 1e-6) * scale
+    # ... and sharp(m0) handed in by the caller (lddmm_step shares it with its regulariser) changes nothing but the
+    # order of two sums
+    if not masked:
+        c = m0.clone().requires_grad_(True)
+        v0 = met.sharp(c)
+        h2 = lm.expmap(met, c, num_steps=steps, v0=v0)
+        assert torch.equal(h2, h)
+        (h2 * go).sum().add((v0 * c).sum()).backward()
+        d = m0.clone().requires_grad_(True)
+        (lm.expmap(met, d, num_steps=steps) * go).sum().add((met.sharp(d) * d).sum()).backward()
+        scale = float(d.grad.abs().max())
+        assert float((c.grad - d.grad).abs().max()) <= (1e-12 if dtype == torch.float64 else 1e-5) * scale
+
+
 # ---- testing/test_affine.py -------------------------------------------------------------
 
 
