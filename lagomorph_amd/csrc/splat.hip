@@ -619,7 +619,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
     }
 }
 
-static KnobArray<6> g_shear_cfg({4, 8, 0, 1, 1, 4});  // TX TY TZ(0 = auto) margins MX MY MZ
+// TX TY TZ(0 = auto) margins MX MY MZ.  TX is an upper bound: make_shear shrinks it until the float64 window fits
+// 80 KB (8 x 6 -> 5 x 6 x 128 at nz = 128, 8 x 6 x 80 at nz = 160: 3840-voxel tiles).  Measured against 4 x 8
+// (tools/ab_tiles.py, steady state): 1-3 % faster at 128^3 and 160^3, one and three channels.
+static KnobArray<6> g_shear_cfg({8, 6, 0, 1, 1, 4});
 static std::atomic<int> g_shear_nt{1024}, g_shear_on{1}, g_shear_mc{1};
 
 static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem) {

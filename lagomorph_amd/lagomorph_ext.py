@@ -145,7 +145,7 @@ def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
     _lib.lago_set_splat_tile(int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
 
 
-def set_splat_shear(on=1, tx=4, ty=8, tz=0, mx=1, my=1, mz=4, nthreads=1024):
+def set_splat_shear(on=1, tx=8, ty=6, tz=0, mx=1, my=1, mz=4, nthreads=1024):
     """Sheared-window float32 splat (csrc/splat.hip: splat_shear_kernel): on/off and its tile.  Speed only."""
     _lib.lago_set_splat_shear(int(on), int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
 
