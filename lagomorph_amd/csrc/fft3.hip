@@ -8,6 +8,7 @@
 //
 // HBM traffic per call: 6 passes of 4 B/voxel-component (read m, write+read+write+read the
 // spectrum, write out) + the coefficient table, against 14 for rocFFT's 3D plan + operator.
+#include <algorithm>
 #include "common.hpp"
 #include "fft_lds.hpp"
 
@@ -58,6 +59,55 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_kernel(fl::
     }
 }
 
+// Planes whose LDS image leaves room for ONE workgroup per CU only (160 x 160: 104 KB) have nobody to hide their
+// global loads behind: a grid of one persistent workgroup per CU walks the planes and requests plane p + grid into
+// registers (7 float4 per thread) before it transforms plane p.
+template <int NY, int NZ>
+__global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_persist_kernel(fl::ZYArgs a) {
+    using K = ZYK<NY, NZ>;
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
+    K::fill_twiddles(threadIdx.x, tw);
+    float4 v[K::KV];
+    size_t p = blockIdx.x;
+    K::fwd_load(threadIdx.x, a.in + p * (size_t)(K::NY * K::NZ), v);
+    for (; p < a.total; p += gridDim.x) {
+        K::fwd_fill(threadIdx.x, v, P);
+        __syncthreads();
+        if (p + gridDim.x < a.total) K::fwd_load(threadIdx.x, a.in + (p + gridDim.x) * (size_t)(K::NY * K::NZ), v);
+        float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
+#pragma unroll
+        for (int ph = 1; ph < K::NPH; ++ph) {
+            K::fwd_phase(ph, threadIdx.x, nullptr, mainp, nyqp, P, tw);
+            __syncthreads();
+        }
+    }
+}
+
+template <int NY, int NZ>
+__global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_kernel(fl::ZYArgs a) {
+    using K = ZYK<NY, NZ>;
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
+    K::fill_twiddles(threadIdx.x, tw);
+    float4 v[K::KV];
+    float2 fb[K::KV];
+    size_t p = blockIdx.x;
+    K::inv_load(threadIdx.x, a.main_ + p * (size_t)(K::NY * K::NZH), a.nyq + p * (size_t)K::NY, v, fb);
+    for (; p < a.total; p += gridDim.x) {
+        K::inv_fill(threadIdx.x, v, fb, P);
+        __syncthreads();
+        const size_t pn = p + gridDim.x;
+        if (pn < a.total) K::inv_load(threadIdx.x, a.main_ + pn * (size_t)(K::NY * K::NZH), a.nyq + pn * (size_t)K::NY, v, fb);
+        float *out = a.out + p * (size_t)(K::NY * K::NZ);
+#pragma unroll
+        for (int ph = 1; ph < K::NPH_INV; ++ph) {
+            K::inv_phase(ph, threadIdx.x, out, nullptr, nullptr, P, tw);
+            __syncthreads();
+        }
+    }
+}
+
 template <int NX, bool INV>
 __global__ __launch_bounds__(256) void fluid_xpass2_kernel(fl::XArgs a) {
     using K = fl::XPass<typename SzOf<NX>::T, INV, 256>;
@@ -103,6 +153,8 @@ bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz) {
     return okx && okyz;
 }
 
+std::atomic<int> g_zy_persist{1};  // 1: persistent prefetching zy kernels for planes above 80 KB of LDS
+
 template <typename Kern>
 static hipError_t allow_smem(Kern k, size_t smem) {
     if (smem <= 64 * 1024) return hipSuccess;
@@ -114,6 +166,24 @@ template <int NY, int NZ>
 static hipError_t zy_launch(const fl::ZYArgs &a, bool inverse, hipStream_t s) {
     using K = ZYK<NY, NZ>;
     static_assert(K::SMEM <= 160 * 1024, "plane does not fit the LDS");
+    // one workgroup per CU (plane above 80 KB) and the next plane's registers fit beside the transform's (not the
+    // 256-point rows / columns, which spill): persistent grid with register prefetch
+    constexpr bool kPersist = K::SMEM > 80 * 1024 && K::KV <= 8 && NY < 256 && NZ < 256;
+    if constexpr (kPersist) if (g_zy_persist) {
+        const uint32_t grid = std::min<uint32_t>(a.total, 256u);
+        if (inverse) {
+            auto k = zy_inverse_persist_kernel<NY, NZ>;
+            hipError_t e = allow_smem(k, K::SMEM);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(K::THREADS), K::SMEM, s, a);
+        } else {
+            auto k = zy_forward_persist_kernel<NY, NZ>;
+            hipError_t e = allow_smem(k, K::SMEM);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(K::THREADS), K::SMEM, s, a);
+        }
+        return hipSuccess;
+    }
     if (inverse) {
         auto k = zy_inverse_kernel<NY, NZ>;
         hipError_t e = allow_smem(k, K::SMEM);
@@ -162,7 +232,7 @@ static hipError_t xpass2_dispatch(int64_t nx, const fl::XArgs &a, bool inverse, 
     return hipErrorInvalidValue;
 }
 
-std::atomic<int> g_xpass_ipw{2};  // batch items per x-pass workgroup
+std::atomic<int> g_xpass_ipw{0};  // batch items per x-pass workgroup; 0 = by the size of the launch (below)
 std::atomic<int> g_native_stage_mask{7};  // profiling only: bit 0 zy forward, bit 1 x pass, bit 2 zy inverse
 
 // out = irfftn(operator(rfftn(m))) * scale.  tab: split-layout coefficient table (fluid_coef_launch
@@ -189,8 +259,16 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     xa.items_per_n = (int)items;
     xa.scale = (float)scale;
     xa.nn = (int)nn;
-    const int ipw = g_xpass_ipw, stages = g_native_stage_mask;
-    xa.ipw = ipw > 0 ? ipw : 1;
+    int ipw = g_xpass_ipw;
+    const int stages = g_native_stage_mask;
+    if (ipw <= 0) {
+        // two batch items per workgroup halve the reads of the coefficient table (24 B per bin), but only a launch
+        // with several rounds of workgroups to spare can afford workgroups of twice the length: small per-GPU
+        // batches (strong scaling: 4 items per GPU at 8 ranks) keep one item per workgroup
+        const int64_t slots = 256 * std::max<int64_t>(1, (160 * 1024) / (3 * nx * 17 * 8 + 2048));
+        ipw = (nn / 2) * items >= 8 * slots ? 2 : 1;   // (measured: tools/ab_fluid.py)
+    }
+    xa.ipw = ipw;
     xa.total = (uint32_t)((nn + xa.ipw - 1) / xa.ipw * items);
     hipError_t e = hipSuccess;
     if (stages & 1) e = zy_dispatch(ny, nz, za, false, s);
@@ -206,3 +284,4 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
 
 extern "C" void lago_debug_fluid_stage_mask(int m) { lago::g_native_stage_mask = m; }
 extern "C" void lago_debug_xpass_ipw(int n) { lago::g_xpass_ipw = n; }
+extern "C" void lago_debug_zy_persist(int on) { lago::g_zy_persist = on; }

@@ -399,23 +399,57 @@ struct ZY {
     static constexpr int THREADS = NT;
     static_assert(KV >= 1 && NZH % 2 == 0, "rows must hold whole float4");
 
+    LAGO_HD static void fill_twiddles(int tid, float2 *tw) {
+        for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
+    }
+    // phase 0 in two halves -- the plane's global loads into registers, registers into the LDS plane -- so that a
+    // persistent workgroup can request its next plane while it transforms the current one (fft3.hip)
+    LAGO_HD static void fwd_load(int tid, const float *in, float4 (&v)[KV]) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+            if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(in)[tid + k * NT];
+    }
+    LAGO_HD static void fwd_fill(int tid, const float4 (&v)[KV], float2 *P) {
+        // a row of NZ reals is NZH complex z[j] = (x[2j], x[2j+1]) as it lies in memory
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            if (tid + k * NT >= F4) continue;
+            const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
+            P[y * PZ + j] = make_float2(v[k].x, v[k].y);
+            P[y * PZ + j + 1] = make_float2(v[k].z, v[k].w);
+        }
+    }
+    LAGO_HD static void inv_load(int tid, const float2 *mainp, const float2 *nyqp, float4 (&v)[KV], float2 (&fb)[KV]) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            if (tid + k * NT >= F4) continue;
+            v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
+            const int e = (tid + k * NT) * 2;
+            if (e % NZH == 0) fb[k] = nyqp[e / NZH];
+        }
+    }
+    LAGO_HD static void inv_fill(int tid, const float4 (&v)[KV], const float2 (&fb)[KV], float2 *P) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            if (tid + k * NT >= F4) continue;
+            const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
+            float2 *row = P + pos_of<SY>(ky) * PZ;
+            float2 a = make_float2(v[k].x, v[k].y);
+            if (kz == 0)  // pack FA + i FB: the inverse y transform then returns (X[0](y), X[NZH](y))
+                a = make_float2(a.x - fb[k].y, a.y + fb[k].x);
+            row[pos_of<SZH>(kz)] = a;
+            row[pos_of<SZH>(kz + 1)] = make_float2(v[k].z, v[k].w);
+        }
+    }
+
     // -- forward: real plane -> main[ky][kz], nyq[ky]
     LAGO_HD static void fwd_phase(int ph, int tid, const float *in, float2 *mainp, float2 *nyqp, float2 *P,
                                   float2 *tw) {
         if (ph == 0) {
-            for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
-            // a row of NZ reals is NZH complex z[j] = (x[2j], x[2j+1]) as it lies in memory
+            fill_twiddles(tid, tw);
             float4 v[KV];
-#pragma unroll
-            for (int k = 0; k < KV; ++k)
-                if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(in)[tid + k * NT];
-#pragma unroll
-            for (int k = 0; k < KV; ++k) {
-                if (tid + k * NT >= F4) continue;
-                const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
-                P[y * PZ + j] = make_float2(v[k].x, v[k].y);
-                P[y * PZ + j + 1] = make_float2(v[k].z, v[k].w);
-            }
+            fwd_load(tid, in, v);
+            fwd_fill(tid, v, P);
         } else if (ph <= GZ) {
             run_stage<TZ, true>(ph - 1, P, tw, tid);
         } else if (ph == GZ + 1) {
@@ -476,24 +510,11 @@ struct ZY {
     LAGO_HD static void inv_phase(int ph, int tid, float *out, const float2 *mainp, const float2 *nyqp, float2 *P,
                                   float2 *tw) {
         if (ph == 0) {
-            for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
+            fill_twiddles(tid, tw);
             float4 v[KV];
-#pragma unroll
-            for (int k = 0; k < KV; ++k)
-                if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
-#pragma unroll
-            for (int k = 0; k < KV; ++k) {
-                if (tid + k * NT >= F4) continue;
-                const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
-                float2 *row = P + pos_of<SY>(ky) * PZ;
-                float2 a = make_float2(v[k].x, v[k].y);
-                if (kz == 0) {  // pack FA + i FB: the inverse y transform then returns (X[0](y), X[NZH](y))
-                    const float2 fb = nyqp[ky];
-                    a = make_float2(a.x - fb.y, a.y + fb.x);
-                }
-                row[pos_of<SZH>(kz)] = a;
-                row[pos_of<SZH>(kz + 1)] = make_float2(v[k].z, v[k].w);
-            }
+            float2 fb[KV];
+            inv_load(tid, mainp, nyqp, v, fb);
+            inv_fill(tid, v, fb, P);
         } else if (ph <= GY) {
             run_stage<TY, false>(ph - 1, P, tw, tid);
         } else if (ph == GY + 1) {

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""A/B of the fluid-metric pass settings in one process: persistent zy kernels on / off (planes above 80 KB of LDS),
+batch items per x-pass workgroup.  env: S (160), B (8)."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import lagomorph_amd as lm
+from bench import time_op
+
+lib = lm.lagomorph_ext._lib
+S, B = int(os.environ.get("S", 160)), int(os.environ.get("B", 8))
+shape = tuple(int(x) for x in os.environ["SHAPE"].split("x")) if "SHAPE" in os.environ else (S, S, S)
+dev = torch.device("cuda")
+m = torch.randn((B, 3) + shape, device=dev)
+met = lm.FluidMetric([0.1, 0.0, 0.01])
+ref = None
+for r in range(2):
+    for persist in (0, 1):
+        for ipw in (0, 1, 2):
+            lib.lago_debug_zy_persist(persist)
+            lib.lago_debug_xpass_ipw(ipw)
+            out = met.sharp(m)
+            if ref is None:
+                ref = out
+            same = torch.equal(out, ref)
+            t, _ = time_op(lambda: met.sharp(m), reps=30, warm=20)
+            print(f"{shape} B={B} persist={persist} ipw={ipw}: {t*1e3:7.1f} us  bits {'same' if same else 'DIFFER'}")
+lib.lago_debug_zy_persist(1)
+lib.lago_debug_xpass_ipw(0)
