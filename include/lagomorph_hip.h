@@ -143,6 +143,15 @@ int lago_compose_f32(float *out, const float *u, const float *v, double ds, doub
 int lago_compose_f64(double *out, const double *u, const double *v, double ds, double dt, int dim, int64_t nn,
                      int64_t nx, int64_t ny, int64_t nz, void *stream);
 
+/* lincomb: out[i] = c0 x0[i] + c1 x1[i] + ... (k = 1..4 terms, n elements), evaluated left to right with one fma per
+ * term in the tensors' precision -- the elementwise sums of lddmm_step (lddmm.py:300-325: the regulariser's gradient
+ * joining the velocity gradient, and `m.add_(-lr, p)` with p the sum of three gradient contributions) as one pass
+ * each instead of torch's chain of mul / add kernels.  out may alias any input; unused inputs may be NULL. */
+int lago_lincomb_f32(float *out, int k, const float *x0, const float *x1, const float *x2, const float *x3, double c0,
+                     double c1, double c2, double c3, int64_t n, void *stream);
+int lago_lincomb_f64(double *out, int k, const double *x0, const double *x1, const double *x2, const double *x3,
+                     double c0, double c1, double c2, double c3, int64_t n, void *stream);
+
 /* Ad_star (the coadjoint action of a diffeomorphism): out = (D phiinv + I) (m o (id + phiinv)) -- adjrep.Ad_star
  * (/root/reference/lagomorph/adjrep.py:86-97), which the reference evaluates as interp_forward
  * followed by jacobian_times_vectorfield_forward(displacement = true).  phiinv, m, out:

@@ -6,6 +6,7 @@
 // 3-vector field).  The three roundings of the unfused expression are kept
 // (fl(fl(ds*u) + fl(dt*I))), so the result is bit-identical to evaluating the
 // reference formula with this library's interp.
+#include <algorithm>
 #include "common.hpp"
 
 namespace lago {
@@ -337,9 +338,67 @@ static int ad_star_impl(R *out, R *mphi, const R *phi, const R *m, int dim, int6
     return finish_launch(s, "ad_star");
 }
 
+// out[i] = c0 x0[i] (+ c1 x1[i] (+ c2 x2[i] (+ c3 x3[i]))): the elementwise sums of the atlas step (gradient of the
+// regulariser onto the velocity gradient; momentum update) in one pass each.  Evaluated left to right with one fma
+// per term, coefficients rounded to R first -- the arithmetic of torch's add(alpha=...) chain on the same operands.
+template <typename R, int K, int VEC>
+__global__ __launch_bounds__(256) void lincomb_kernel(R *out, const R *x0, const R *x1, const R *x2, const R *x3, R c0,
+                                                      R c1, R c2, R c3, size_t nvec) {
+    struct alignas(sizeof(R) * VEC) V { R e[VEC]; };
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const V a = reinterpret_cast<const V *>(x0)[i];
+        V b = a, c = a, d = a, r;
+        if (K > 1) b = reinterpret_cast<const V *>(x1)[i];
+        if (K > 2) c = reinterpret_cast<const V *>(x2)[i];
+        if (K > 3) d = reinterpret_cast<const V *>(x3)[i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            R acc = c0 * a.e[e];
+            if (K > 1) acc = lg_fma(c1, b.e[e], acc);
+            if (K > 2) acc = lg_fma(c2, c.e[e], acc);
+            if (K > 3) acc = lg_fma(c3, d.e[e], acc);
+            r.e[e] = acc;
+        }
+        reinterpret_cast<V *>(out)[i] = r;
+    }
+}
+
+template <typename R>
+int lincomb_impl(R *out, int k, const R *x0, const R *x1, const R *x2, const R *x3, double c0, double c1, double c2,
+                 double c3, int64_t n, void *stream) {
+    if (k < 1 || k > 4 || n < 0) return fail_invalid("lincomb: 1 to 4 terms");
+    if (n == 0) return LAGO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int VEC = 16 / sizeof(R);
+    auto aligned = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = n % VEC == 0 && aligned(out) && aligned(x0) && aligned(k > 1 ? x1 : nullptr) &&
+                     aligned(k > 2 ? x2 : nullptr) && aligned(k > 3 ? x3 : nullptr);
+    const size_t nvec = vec ? (size_t)n / VEC : (size_t)n;
+    const uint32_t grid = (uint32_t)std::min<size_t>((nvec + 255) / 256, (size_t)256 * 32);
+#define LAGO_LC(K, V)                                                                                              \
+    hipLaunchKernelGGL((lincomb_kernel<R, K, V>), dim3(grid), dim3(256), 0, s, out, x0, x1, x2, x3, (R)c0, (R)c1, (R)c2, \
+                       (R)c3, nvec)
+    if (vec) {
+        if (k == 1) LAGO_LC(1, VEC); else if (k == 2) LAGO_LC(2, VEC); else if (k == 3) LAGO_LC(3, VEC); else LAGO_LC(4, VEC);
+    } else {
+        if (k == 1) LAGO_LC(1, 1); else if (k == 2) LAGO_LC(2, 1); else if (k == 3) LAGO_LC(3, 1); else LAGO_LC(4, 1);
+    }
+#undef LAGO_LC
+    return finish_launch(s, "lincomb");
+}
+
 }  // namespace lago
 
 extern "C" {
+int lago_lincomb_f32(float *out, int k, const float *x0, const float *x1, const float *x2, const float *x3, double c0,
+                     double c1, double c2, double c3, int64_t n, void *stream) {
+    return lago::lincomb_impl<float>(out, k, x0, x1, x2, x3, c0, c1, c2, c3, n, stream);
+}
+int lago_lincomb_f64(double *out, int k, const double *x0, const double *x1, const double *x2, const double *x3,
+                     double c0, double c1, double c2, double c3, int64_t n, void *stream) {
+    return lago::lincomb_impl<double>(out, k, x0, x1, x2, x3, c0, c1, c2, c3, n, stream);
+}
 int lago_compose_f32(float *out, const float *u, const float *v, double ds, double dt, int dim, int64_t nn,
                      int64_t nx, int64_t ny, int64_t nz, void *stream) {
     return lago::compose_impl<float>(out, u, v, ds, dt, dim, nn, nx, ny, nz, stream);

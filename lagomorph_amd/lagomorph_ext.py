@@ -51,6 +51,7 @@ _SIGS = {
     "lago_regrid_forward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
+    "lago_lincomb": [_vp, _int, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i64, _vp],
     "lago_Ad_star": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_interp_backward_fused": [_vp, _vp, _vp, _vp, _vp, _dbl, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int,
                                    _dbl, _vp],
@@ -433,6 +434,31 @@ def compose(u, v, ds=1.0, dt=1.0):
         raise RuntimeError("compose: u and v must be vector fields of the same shape")
     out = torch.empty_like(u)
     _call("lago_compose", u, _ptr(out), _ptr(u), _ptr(v), float(ds), float(dt), dim, u.size(0), nx, ny, nz)
+    return out
+
+
+def lincomb(terms, out=None):
+    """out = c0*x0 + c1*x1 + ... for 1 to 4 (coefficient, tensor) pairs of one shape and dtype, in one pass
+    (left to right, one fma per term).  `out` may be one of the inputs (in place); a new tensor otherwise.
+    Not part of the reference's extension surface: the elementwise sums of lddmm_step (lddmm.py:300-325)."""
+    if not 1 <= len(terms) <= 4:
+        raise RuntimeError("lincomb: 1 to 4 terms")
+    xs = [x for _, x in terms]
+    for x in xs:
+        _check_input(x, "x")
+        _same(xs[0], x)
+        if x.shape != xs[0].shape:
+            raise RuntimeError("lincomb: shapes differ")
+    if out is None:
+        out = torch.empty_like(xs[0])
+    else:
+        _check_input(out, "out")
+        _same(xs[0], out)
+        if out.shape != xs[0].shape:
+            raise RuntimeError("lincomb: shapes differ")
+    ptrs = [_ptr(x) for x in xs] + [None] * (4 - len(xs))
+    cs = [float(c) for c, _ in terms] + [0.0] * (4 - len(terms))
+    _call("lago_lincomb", xs[0], _ptr(out), len(terms), *ptrs, *cs, xs[0].numel())
     return out
 
 

@@ -59,23 +59,7 @@ class ExpmapFunction(torch.autograd.Function):
     def forward(ctx, metric, m0, phiinv, dt, num_steps, v0):
         m0 = m0.contiguous()
         keep = ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[5]
-        steps = []
-        first = phiinv is None   # shooting from the identity: the first Euler step in closed form (see `expmap`)
-        if first:
-            phi = _first_step(metric, m0, dt, v0)
-        else:
-            phi = phiinv.contiguous()
-        for _ in range(num_steps - 1 if first else num_steps):
-            if keep:
-                m, mphi = lagomorph_ext.Ad_star(phi, m0, save_resampled=True)
-            else:
-                m, mphi = lagomorph_ext.Ad_star(phi, m0), None
-            v = metric.sharp(m)
-            del m
-            nxt = lagomorph_ext.compose(v, phi, -dt, 1.0)
-            if keep:
-                steps.append((phi, v, mphi))
-            phi = nxt
+        phi, steps, first = _shoot(metric, m0, phiinv, dt, num_steps, v0, keep)
         ctx.metric, ctx.dt, ctx.steps, ctx.m0, ctx.first, ctx.has_v0 = metric, dt, steps, m0, first, v0 is not None
         return phi
 
@@ -83,16 +67,7 @@ class ExpmapFunction(torch.autograd.Function):
     def backward(ctx, G):
         metric, dt, m0 = ctx.metric, ctx.dt, ctx.m0
         need_m, need_phi, need_v0 = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[5]
-        G = G.contiguous()
-        d_m0 = torch.zeros_like(m0) if (ctx.steps or not ctx.first) else None
-        for phi, v, mphi in reversed(ctx.steps):
-            d_phi, d_v = lagomorph_ext.interp_backward_fused(G, phi, v, -dt, True, addgo=-dt)
-            d_m = metric.sharp(d_v)
-            del d_v
-            d_phi, d_w = lagomorph_ext.jacobian_times_vectorfield_backward(d_m, phi, mphi, True, False, True, True,
-                                                                            d_v=d_phi)
-            del d_m
-            _, G = lagomorph_ext.interp_backward_fused(d_w, m0, phi, 1.0, True, d_u=d_phi, d_I=d_m0)
+        d_m0, G = _shoot_reverse(metric, m0, dt, ctx.steps, G.contiguous())
         ctx.steps = None
         d_v0 = None
         if ctx.first:
@@ -108,6 +83,42 @@ class ExpmapFunction(torch.autograd.Function):
             G = None
         return (None, d_m0 if need_m else None, G if need_phi else None, None, None,
                 d_v0 if (need_v0 and ctx.has_v0) else None)
+
+
+def _shoot(metric, m0, phiinv, dt, num_steps, v0, keep):
+    """The Euler loop of `expmap` through the fused kernels.  Returns (phi, steps, first): steps = per general step
+    (phi_k, v_k, m0 o (id + phi_k)) when `keep`, first = the first step was taken in closed form (`_first_step`)."""
+    steps = []
+    first = phiinv is None   # shooting from the identity
+    phi = _first_step(metric, m0, dt, v0) if first else phiinv.contiguous()
+    for _ in range(num_steps - 1 if first else num_steps):
+        if keep:
+            m, mphi = lagomorph_ext.Ad_star(phi, m0, save_resampled=True)
+        else:
+            m, mphi = lagomorph_ext.Ad_star(phi, m0), None
+        v = metric.sharp(m)
+        del m
+        nxt = lagomorph_ext.compose(v, phi, -dt, 1.0)
+        if keep:
+            steps.append((phi, v, mphi))
+        phi = nxt
+    return phi, steps, first
+
+
+def _shoot_reverse(metric, m0, dt, steps, G):
+    """Reverse sweep over the general steps of `_shoot` (see ExpmapFunction).  G = dL/dphi_N.  Returns (d_m0, G) with
+    G = dL/d(phi at the start of the first general step) and d_m0 the momentum gradient collected over these steps
+    (None when there were none)."""
+    d_m0 = torch.zeros_like(m0) if steps else None
+    for phi, v, mphi in reversed(steps):
+        d_phi, d_v = lagomorph_ext.interp_backward_fused(G, phi, v, -dt, True, addgo=-dt)
+        d_m = metric.sharp(d_v)
+        del d_v
+        d_phi, d_w = lagomorph_ext.jacobian_times_vectorfield_backward(d_m, phi, mphi, True, False, True, True,
+                                                                        d_v=d_phi)
+        del d_m
+        _, G = lagomorph_ext.interp_backward_fused(d_w, m0, phi, 1.0, True, d_u=d_phi, d_I=d_m0)
+    return d_m0, G
 
 
 def _first_step(metric, m0, dt, v0=None, mommask=None):
@@ -162,6 +173,58 @@ def expmap(metric, m0, T=1.0, num_steps=10, phiinv=None, mommask=None, checkpoin
 # --------------------------------------------------------------------------- atlas step
 
 
+USE_FUSED_STEP = True
+
+
+def _fused_step_ok(I, m, img, metric, integration_steps):
+    return (USE_FUSED_STEP and USE_FUSED_EXPMAP and integration_steps >= 1 and isinstance(metric, FluidMetric)
+            and m.is_cuda and I.is_cuda and img.is_cuda and m.dtype in (torch.float32, torch.float64)
+            and m.dtype == I.dtype == img.dtype and m.size(1) == m.dim() - 2 and m.numel() < 2 ** 31
+            and m.is_contiguous() and torch.is_grad_enabled()
+            and all(hasattr(lagomorph_ext, n) for n in ("Ad_star", "compose", "interp_backward_fused", "lincomb")))
+
+
+def _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_weight, learning_rate_pose,
+                      momentum_preconditioning):
+    """`lddmm_step` with the momentum side written out by hand: the shoot and its reverse sweep (`_shoot`,
+    `_shoot_reverse`), the regulariser <sharp(m), m> and its gradient, and the descent step, with every elementwise
+    sum in one pass (`lagomorph_ext.lincomb`).  Autograd is kept for the image side -- interp of the atlas, the
+    regrid of multiscale momenta, the loss -- so that I.grad and its hooks (the atlas builder's all-reduce) behave
+    as in the plain form.  Same formulas; sums in a different order (rounding only)."""
+    regrid_momenta = tuple(m.shape[2:]) != tuple(I.shape[2:])
+    dt = 1.0 / integration_steps
+    with torch.no_grad():
+        m = m.detach()
+        v = metric.sharp(m)
+        h, steps, _ = _shoot(metric, m, None, dt, integration_steps, v, True)
+    h.requires_grad_(True)
+    hh = regrid(h, shape=I.shape[2:]) if regrid_momenta else h
+    img_term = torch.nn.functional.mse_loss(deform.interp(I, hh), img, reduction="sum") / img.numel()
+    img_term.backward()
+    with torch.no_grad():
+        c = reg_weight / img.numel()
+        if regrid_momenta:  # account for downscaling in averaging (lddmm.py:311-312)
+            c = c * (I.numel() / v[0, 0, ...].numel())
+        reg_term = c * torch.dot(v.reshape(-1), m.reshape(-1))
+        loss = img_term.detach() + reg_term
+        d_m0, G = _shoot_reverse(metric, m, dt, steps, h.grad.contiguous())
+        own = len(steps) > 0   # G came out of the reverse sweep (ours to overwrite), not out of autograd
+        del steps
+        # gradient with respect to v = sharp(m): -dt G from the first Euler step, c m from the regulariser
+        d_v = lagomorph_ext.lincomb([(-dt, G), (c, m)], out=G if own else None)
+        d_mK = metric.sharp(d_v)
+        del d_v, G
+        norm_factor = img.shape[0] / dataset_size
+        terms = [(1.0, d_mK), (c, v)] + ([(1.0, d_m0)] if d_m0 is not None else [])
+        if momentum_preconditioning:
+            p = metric.flat(lagomorph_ext.lincomb(terms, out=d_mK))
+            lagomorph_ext.lincomb([(1.0, m), (-learning_rate_pose, p)], out=m)
+        else:   # m <- m - lr (d_mK + c v + d_m0)
+            lr = learning_rate_pose
+            lagomorph_ext.lincomb([(1.0, m)] + [(-lr * a, x) for a, x in terms], out=m)
+        return m, (loss * norm_factor), (reg_term * norm_factor)
+
+
 def lddmm_step(I, m, img, metric, dataset_size, integration_steps=5, reg_weight=1e2, learning_rate_pose=2e2,
                momentum_preconditioning=False):
     """One matching step of the atlas builder for a minibatch (lddmm.py:300-325).
@@ -170,6 +233,9 @@ def lddmm_step(I, m, img, metric, dataset_size, integration_steps=5, reg_weight=
     m: momenta (B, d, *msp) -- updated in place by gradient descent, img: (B, 1, *sp).
     Returns (m, loss, reg_term) with loss/reg already scaled by B / dataset_size, all on device
     (no host synchronisation)."""
+    if _fused_step_ok(I, m, img, metric, integration_steps):
+        return _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_weight, learning_rate_pose,
+                                 momentum_preconditioning)
     m.requires_grad_(True)
     if m.grad is not None:
         m.grad.detach_()

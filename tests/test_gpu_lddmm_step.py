@@ -199,3 +199,56 @@ def test_expmap_reverse_sweep_equals_autograd_through_the_loop(sp, dtype, tol):
     # no gradient wanted: the plain loop, nothing kept
     with torch.no_grad():
         assert torch.equal(lm.expmap(met, m0, num_steps=4, phiinv=p0), res[True][0])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("sp,msp,steps,precond", [((20, 24, 28), (20, 24, 28), 3, False), ((20, 24, 28), (10, 12, 16), 2, False),
+                                                   ((40, 36), (40, 36), 1, False), ((14, 12, 40), (14, 12, 40), 4, True)])
+def test_fused_lddmm_step_equals_plain_form(sp, msp, steps, precond, dtype, tol):
+    """`_lddmm_step_fused` (hand-written momentum side, one-pass elementwise sums) against the plain autograd form of
+    lddmm_step (lddmm.py:300-325) on the same kernels: loss, regulariser, updated momenta, atlas gradient."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import lddmm
+
+    base, imgs, m = make_problem(sp, msp, dtype, 3)
+    m = scale_momenta(lm, m.cuda(), 1.5).contiguous()
+    res = {}
+    for fused in (True, False):
+        lddmm.USE_FUSED_STEP = fused
+        try:
+            I = base.cuda().requires_grad_(True)
+            mm = m.clone()
+            out, loss, reg = lm.lddmm_step(I, mm, imgs.cuda(), lm.FluidMetric([0.1, 0.0, 0.01]), 5, integration_steps=steps,
+                                           reg_weight=1e-2, learning_rate_pose=1e-3, momentum_preconditioning=precond)
+            assert out.data_ptr() == mm.data_ptr()   # updated in place
+            res[fused] = (loss, reg, out, I.grad)
+        finally:
+            lddmm.USE_FUSED_STEP = True
+    for i, name in enumerate(("loss", "reg", "m", "I.grad")):
+        a, b = res[True][i].double(), res[False][i].double()
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err <= tol, (name, err)
+    assert float((res[True][2] - m).abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003])
+def test_lincomb(n, dtype):
+    """lago_lincomb: left-to-right fma chain; in place; vector and scalar paths (n not a multiple of the vector)."""
+    import lagomorph_amd as lm
+
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xs = [torch.randn(n, device="cuda", dtype=dtype, generator=g) for _ in range(4)]
+    cs = [1.0, -0.37, 2.5e-3, 11.0]
+    for k in range(1, 5):
+        got = ext.lincomb(list(zip(cs[:k], xs[:k])))
+        want = sum(c * x.double() for c, x in zip(cs[:k], xs[:k]))
+        scale = float(want.abs().max())
+        assert float((got.double() - want).abs().max()) <= (1e-6 if dtype == torch.float32 else 1e-15) * max(scale, 1.0)
+        if k == 1:
+            assert torch.equal(got, xs[0] * cs[0])
+        y = xs[0].clone()
+        assert ext.lincomb(list(zip(cs[:k], [y] + xs[1:k])), out=y) is y and torch.equal(y, got)
+    with pytest.raises(RuntimeError):
+        ext.lincomb([(1.0, xs[0]), (1.0, xs[1][:-1].contiguous())] if n > 1 else [])
