@@ -477,6 +477,11 @@ def parse_args():
     return ap.parse_args()
 
 
+# LAGO_BENCH_SHARE_GPU=1: run the N-rank code path on ONE GPU (ranks share device 0, gloo instead of RCCL) -- for
+# checking the multi-rank plumbing on a single-GPU box; the JSON line is marked and is not a measurement.
+SHARE_GPU = os.environ.get("LAGO_BENCH_SHARE_GPU", "") == "1"
+
+
 def spawn_workers(args):
     """Parent of an N-GPU run started without a launcher: start N fresh workers, one per GPU, before any GPU call
     (counting devices does not initialise HIP) and hand their output through.  Returns the exit code."""
@@ -484,7 +489,7 @@ def spawn_workers(args):
     import subprocess
 
     n = torch.cuda.device_count()
-    if n < args.gpus:
+    if n < args.gpus and not SHARE_GPU:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -513,10 +518,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     ensure_built(local_rank)
+    if SHARE_GPU:  # plumbing check only: all ranks on GPU 0, collectives over gloo (RCCL refuses two ranks per device)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if SHARE_GPU:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import lagomorph_amd as lm
 
@@ -656,6 +666,8 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S, E, args.cpu_sample_batch)
+        if SHARE_GPU:
+            result["debug_shared_gpu"] = "LAGO_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo -- a plumbing check, NOT a measurement"
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
