@@ -163,8 +163,8 @@ def micro_fluid(lm, dev, size, batch=8):
     met = lm.FluidMetric([0.1, 0.0, 0.01])
     V = batch * size ** 3
     with torch.no_grad():
-        sharp_ms, _ = time_op(lambda: met.sharp(m), reps=10, warm=3)
-        flat_ms, _ = time_op(lambda: met.flat(m), reps=10, warm=3)
+        sharp_ms, _ = time_op(lambda: met.sharp(m), reps=20, warm=20)
+        flat_ms, _ = time_op(lambda: met.flat(m), reps=20, warm=20)
         Fm = torch.view_as_real(torch.fft.rfftn(m, dim=(-3, -2, -1), norm="ortho").contiguous())
         k_inv, _ = time_op(lambda: lm.lagomorph_ext.fluid_operator(Fm, True, met.luts["cos"], met.luts["sin"], *met.params))
         k_fwd, _ = time_op(lambda: lm.lagomorph_ext.fluid_operator(Fm, False, met.luts["cos"], met.luts["sin"], *met.params))
@@ -213,9 +213,9 @@ def micro_ops(lm, dev, size, batch=8):
         "regrid_backward(128^3->64^3,C=3)": (lambda: ext.regrid_backward(v, half, [size] * 3, [(size // 2 - 1) * 0.5] * 3,
                                                                           [(size // 2 - 1) / (size - 1)] * 3), 12 + 1.5),
     }
-    out = {"workload": f"batch {batch} x 3x{size}^3 fp32, median of 10", "ops": {}}
+    out = {"workload": f"batch {batch} x 3x{size}^3 fp32, median of 20 after 20 warm-up calls", "ops": {}}
     for name, (fn, bpv) in ops.items():
-        med, _ = time_op(fn, reps=10, warm=3)
+        med, _ = time_op(fn, reps=20, warm=20)
         out["ops"][name] = {"ms": med, "alg_bytes_per_voxel": bpv, "GBps": bpv * V / med / 1e6,
                             "frac_of_hbm_peak": bpv * V / med / 1e6 / HBM_PEAK_GBPS}
     return out
