@@ -12,7 +12,7 @@ if not _BUILDING:
     from .adjrep import *  # noqa: F401,F403
     from .adjrep import Ad, Ad_dagger, Ad_star, ad, ad_dagger, ad_star, sym, sym_dagger  # noqa: F401
     from .affine import (AffineInterp, AffineInterpFunction, RegridFunction, RegridModule, StandardizedDataset,  # noqa: F401
-                         affine_atlas, affine_interp, batch_average,
+                         affine_atlas, affine_interp, batch_average, load_affine_atlas, save_affine_atlas,
                          affine_inverse, det_2x2, invert_2x2, invert_3x3, regrid, rigid_inverse, rotation_exp_map)
     from .deform import (InterpFunction, compose, compose_disp_vel, compose_vel_disp, identity, interp,  # noqa: F401
                          interp_hessian_diagonal_image)

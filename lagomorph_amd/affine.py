@@ -277,6 +277,45 @@ def affine_atlas(images, As, Ts, I=None, num_epochs=1000, batch_size=50, image_u
     return I.detach(), As.detach(), Ts.detach(), epoch_losses, iter_losses
 
 
+def save_affine_atlas(path, I, As, Ts, epoch_losses, iter_losses):
+    """The result file of the reference's affine atlas tool (affine.py:581-587): HDF5 datasets `atlas`, `A`, `T`,
+    `epoch_losses`, `iter_losses` when h5py is importable, the same dictionary through torch.save otherwise."""
+    import numpy as np
+
+    st = {"atlas": I.detach().cpu().numpy(), "A": As.detach().cpu().numpy(), "T": Ts.detach().cpu().numpy(),
+          "epoch_losses": np.asarray(epoch_losses), "iter_losses": np.asarray(iter_losses)}
+    try:
+        import h5py
+    except ImportError:
+        torch.save(st, path)
+        return path
+    with h5py.File(path, "w") as f:
+        for k, v in st.items():
+            f.create_dataset(k, data=v)
+    return path
+
+
+def load_affine_atlas(path):
+    """Reads what `save_affine_atlas` (or the reference's tool) wrote: (I, As, Ts, epoch_losses, iter_losses), tensors
+    on the CPU -- the inputs `StandardizedDataset` needs (affine.py:589-600)."""
+    import numpy as np
+
+    with open(path, "rb") as fh:
+        is_h5 = fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    if is_h5:
+        try:
+            import h5py
+        except ImportError:
+            raise RuntimeError(f"{path} is an HDF5 file but h5py is not importable")
+        with h5py.File(path, "r") as f:
+            st = {k: np.asarray(f[k]) for k in ("atlas", "A", "T", "epoch_losses", "iter_losses")}
+    else:
+        st = torch.load(path, map_location="cpu", weights_only=False)
+    return (torch.from_numpy(np.asarray(st["atlas"])), torch.from_numpy(np.asarray(st["A"])),
+            torch.from_numpy(np.asarray(st["T"])), [float(x) for x in st["epoch_losses"]],
+            [float(x) for x in st["iter_losses"]])
+
+
 class StandardizedDataset:
     """Subjects resampled into atlas space by the inverse of their fitted affine map
     (affine.py:418-438); ``dataset[idx]`` is one (C, *spatial) image."""

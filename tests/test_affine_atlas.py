@@ -134,3 +134,52 @@ def test_lddmm_atlas_builder_checkpoint_resume(oracle_ext, tmp_path):
     assert torch.equal(Ia, Ib)
     assert all(torch.equal(x, y) for x, y in zip(a.ms, b.ms))
     assert [float(x) for x in a.epoch_losses] == [float(x) for x in b.epoch_losses]
+
+
+def test_affine_atlas_result_file(tmp_path, monkeypatch):
+    """save_affine_atlas writes the datasets of the reference's tool (affine.py:581-587: atlas, A, T, epoch_losses,
+    iter_losses) through the h5py API when h5py is importable -- checked with an in-memory stand-in, h5py being absent
+    from this image -- and load_affine_atlas reads both that and the torch.save form back."""
+    import sys
+    import types
+
+    import numpy as np
+
+    import lagomorph_amd as lm
+
+    I = torch.randn(1, 1, 5, 6, 7)
+    As, Ts = torch.randn(4, 3, 3, dtype=torch.float64), torch.randn(4, 3, dtype=torch.float64)
+    el, il = [3.0, 2.0], [3.5, 3.0, 2.5, 2.0]
+    p1 = lm.save_affine_atlas(str(tmp_path / "a.pt"), I, As, Ts, el, il)   # no h5py: torch.save
+    back = lm.load_affine_atlas(p1)
+    assert torch.equal(back[0], I) and torch.equal(back[1], As) and torch.equal(back[2], Ts) and back[3] == el and back[4] == il
+
+    store = {}
+
+    class File:
+        def __init__(self, path, mode):
+            self.path = path
+            if mode == "w":
+                store[path] = {}
+                open(path, "wb").write(b"\x89HDF\r\n\x1a\n")
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def create_dataset(self, name, data=None):
+            store[self.path][name] = np.array(data)
+
+        def __getitem__(self, name):
+            return store[self.path][name]
+
+    fake = types.ModuleType("h5py")
+    fake.File = File
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    p2 = lm.save_affine_atlas(str(tmp_path / "a.h5"), I, As, Ts, el, il)
+    assert sorted(store[p2]) == ["A", "T", "atlas", "epoch_losses", "iter_losses"]
+    assert store[p2]["atlas"].shape == (1, 1, 5, 6, 7) and store[p2]["A"].shape == (4, 3, 3) and store[p2]["T"].shape == (4, 3)
+    back = lm.load_affine_atlas(p2)
+    assert torch.equal(back[0], I) and torch.equal(back[1], As) and torch.equal(back[2], Ts) and back[3] == el and back[4] == il
