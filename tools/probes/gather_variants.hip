@@ -69,7 +69,32 @@ __global__ __launch_bounds__(256) void k(float* __restrict__ out, const float* _
         }
     }
     float res[3][U];
-    if (V == 6 || V == 7) {
+    if (V == 10) {   // V10: no gathers (coalesced read at the voxel's own index) but the full select + trilinear arithmetic
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const float x = In[(size_t)c * nv + s[e]];
+                float lo[4], hi[4], c8[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { lo[q] = x + (float)q; hi[q] = x * (float)(q + 2); }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { c8[q] = fhi[e] ? hi[q] : lo[q]; c8[q + 4] = clo[e] ? lo[q] : hi[q]; }
+                res[c][e] = lerp8(c8, t[e], uu[e], v[e]) + (float)rb[e][2];
+            }
+    } else if (V == 9) {   // V9: the gathers of V0, trivial arithmetic
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const Rsrc r = mk(In + (size_t)c * nv, planeB);
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                float lo[4], hi[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ld2(r, rb[e][q], lo[q], hi[q]);
+                res[c][e] = ((lo[0] + hi[0]) + (lo[1] + hi[1])) + ((lo[2] + hi[2]) + (lo[3] + hi[3])) * t[e];
+            }
+        }
+    } else if (V == 6 || V == 7) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -327,6 +352,8 @@ int main(int argc, char** argv) {
     check("V4 12 pair loads in flight, U=1", run<4, 1>(out, img, u, B));
     { const float a6 = run<6, 2>(out, img, u, B), a7 = run<7, 2>(out, img, u, B);
       printf("V6 no image access %.1f us (%.0f GB/s of 24 B/voxel)   V7 coalesced image read %.1f us (%.0f GB/s of 36 B/voxel)\n", a6, 24.0 * B * nv / a6 / 1e3, a7, bytes / a7 / 1e3); }
+    { const float a9 = run<9, 2>(out, img, u, B), a10 = run<10, 2>(out, img, u, B);
+      printf("V9 gathers, trivial arithmetic %.1f us   V10 coalesced read, full select + trilinear arithmetic %.1f us\n", a9, a10); }
     check("V8 LDS 4x8 rows M=1, 1024 thr", runl<4, 8, 1, 1024>(out, img, u, B));
     check("V8 LDS 4x8 rows M=2, 1024 thr", runl<4, 8, 2, 1024>(out, img, u, B));
     check("V8 LDS 4x4 rows M=1, 512 thr", runl<4, 4, 1, 512>(out, img, u, B));
