@@ -108,9 +108,14 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
     }
 }
 
-template <int NX, bool INV>
-__global__ __launch_bounds__(256) void fluid_xpass2_kernel(fl::XArgs a) {
-    using K = fl::XPass<typename SzOf<NX>::T, INV, 256>;
+// threads per x-pass workgroup: 256, except for the 256-point tile (104 KB: one workgroup per CU, which 512 threads
+// serve 12 % faster).  Measured (tools/ab_fluid.py): wider workgroups LOSE 3-14 % at 128, 160 and 192 points, where
+// two or three 256-thread workgroups share a CU and their 120+ VGPRs per thread would cost the second one.
+template <int NX> constexpr int xpass_wide() { return NX >= 256 ? 512 : 256; }
+
+template <int NX, bool INV, int NT>
+__global__ __launch_bounds__(NT) void fluid_xpass2_kernel(fl::XArgs a) {
+    using K = fl::XPass<typename SzOf<NX>::T, INV, NT>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *buf = reinterpret_cast<float2 *>(lago_smem), *tw = buf + 3 * K::NX * K::KCP;
     const uint32_t blk = xcd_swizzle(blockIdx.x, a.total);
@@ -206,22 +211,31 @@ static hipError_t zy_dispatch(int64_t ny, int64_t nz, const fl::ZYArgs &a, bool 
     return hipErrorInvalidValue;
 }
 
-template <int NX>
-static hipError_t xpass2_launch(const fl::XArgs &a, bool inverse, hipStream_t s) {
+template <int NX, int NT>
+static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t s) {
     if (inverse) {
-        using K = fl::XPass<typename SzOf<NX>::T, true, 256>;
-        auto k = fluid_xpass2_kernel<NX, true>;
+        using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
+        auto k = fluid_xpass2_kernel<NX, true, NT>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(256), K::SMEM, s, a);
+        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
     } else {
-        using K = fl::XPass<typename SzOf<NX>::T, false, 256>;
-        auto k = fluid_xpass2_kernel<NX, false>;
+        using K = fl::XPass<typename SzOf<NX>::T, false, NT>;
+        auto k = fluid_xpass2_kernel<NX, false, NT>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(256), K::SMEM, s, a);
+        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
     }
     return hipSuccess;
+}
+
+std::atomic<int> g_xpass_wide{1};
+
+template <int NX>
+static hipError_t xpass2_launch(const fl::XArgs &a, bool inverse, hipStream_t s) {
+    if constexpr (xpass_wide<NX>() != 256)
+        if (g_xpass_wide) return xpass2_launch_nt<NX, xpass_wide<NX>()>(a, inverse, s);
+    return xpass2_launch_nt<NX, 256>(a, inverse, s);
 }
 
 static hipError_t xpass2_dispatch(int64_t nx, const fl::XArgs &a, bool inverse, hipStream_t s) {
@@ -285,3 +299,4 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
 extern "C" void lago_debug_fluid_stage_mask(int m) { lago::g_native_stage_mask = m; }
 extern "C" void lago_debug_xpass_ipw(int n) { lago::g_xpass_ipw = n; }
 extern "C" void lago_debug_zy_persist(int on) { lago::g_zy_persist = on; }
+extern "C" void lago_debug_xpass_wide(int on) { lago::g_xpass_wide = on; }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the fluid-metric pass settings in one process: persistent zy kernels on / off (planes above 80 KB of LDS),
-batch items per x-pass workgroup.  env: S (160), B (8)."""
+"""A/B of the fluid-metric pass settings in one process: x-pass workgroups of 256 threads or wide (the 256-point tile),
+batch items per x-pass workgroup; `lago_debug_zy_persist` switches the persistent zy kernels the same way.  env: S (160), B (8)."""
 import ctypes
 import os
 import sys
@@ -19,10 +19,11 @@ m = torch.randn((B, 3) + shape, device=dev)
 met = lm.FluidMetric([0.1, 0.0, 0.01])
 ref = None
 for r in range(2):
-    for persist in (0, 1):
-        for ipw in (0, 1, 2):
+    for persist in (1,):
+        for ipw in (0, 10, 11):   # 10 / 11: automatic items per workgroup with 256-thread / wide x-pass workgroups
             lib.lago_debug_zy_persist(persist)
-            lib.lago_debug_xpass_ipw(ipw)
+            lib.lago_debug_xpass_wide(0 if ipw == 10 else 1)
+            lib.lago_debug_xpass_ipw(0 if ipw >= 10 else ipw)
             out = met.sharp(m)
             if ref is None:
                 ref = out
@@ -31,3 +32,4 @@ for r in range(2):
             print(f"{shape} B={B} persist={persist} ipw={ipw}: {t*1e3:7.1f} us  bits {'same' if same else 'DIFFER'}")
 lib.lago_debug_zy_persist(1)
 lib.lago_debug_xpass_ipw(0)
+lib.lago_debug_xpass_wide(1)
