@@ -403,7 +403,10 @@ def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
 
 @pytest.mark.parametrize("sp", [(64, 6, 10), (128, 5, 12), (64, 64, 64), (256, 4, 6), (128, 7, 130),
                                 (64, 32, 64), (128, 64, 128), (64, 128, 256), (256, 32, 64), (64, 256, 64),
-                                (160, 160, 160), (96, 64, 160), (160, 96, 192), (192, 160, 96), (64, 192, 192)])
+                                (160, 160, 160), (96, 64, 160), (160, 96, 192), (192, 160, 96), (64, 192, 192),
+                                # every plane shape served by the persistent zy kernels (above 80 KB of LDS)
+                                (64, 128, 192), (64, 160, 128), (64, 192, 128), (64, 128, 160), (64, 160, 192),
+                                (96, 192, 160)])
 @pytest.mark.parametrize("inverse", [True, False])
 def test_fused_fluid_metric_paths(ext, sp, inverse):
     """float32 3D: the three implementations of FluidMetric sharp/flat -- (2) three LDS-tiled FFT
