@@ -433,6 +433,26 @@ def test_fused_fluid_metric_paths(ext, sp, inverse):
     assert_close(got[2], host(got[0]), torch.float32, "native passes vs plain hipFFT")
 
 
+@pytest.mark.parametrize("batch", [1, 2, 5])
+def test_persistent_zy_passes_any_plane_count(ext, batch):
+    """Planes above 80 KB of LDS run on a grid of at most 256 persistent workgroups that prefetch their next plane:
+    fewer planes than workgroups (batch 1: 192), a ragged last round (batch 2: 384 = 256 + 128) and several rounds
+    (batch 5: 960), against the oracle and bit for bit against the one-plane-per-workgroup kernels."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(batch)
+    m = rnd(rng, (batch, 3, 64, 160, 160), torch.float32)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    got = met.sharp(dev(m))
+    assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "persistent zy passes vs oracle")
+    ext._lib.lago_debug_zy_persist(0)
+    try:
+        plain = met.sharp(dev(m))
+    finally:
+        ext._lib.lago_debug_zy_persist(1)
+    assert torch.equal(got, plain)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["near_identity", "rotation", "zoom", "flip"])
 @pytest.mark.parametrize("bc", [False, True])
