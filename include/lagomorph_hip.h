@@ -37,7 +37,7 @@ extern "C" {
 #define LAGO_ERR_INVALID (-1)
 #define LAGO_ERR_HIP (-2)
 
-#define LAGO_ABI_VERSION 2
+#define LAGO_ABI_VERSION 3
 
 /* ---- housekeeping --------------------------------------------------------- */
 
@@ -71,6 +71,22 @@ void lago_set_vector_kernels(int on);
  * plan + fused x-axis pass (nx in {64,128,256}); 0: rocFFT 3D plan + operator kernel.  A mode falls back
  * to the next lower one for shapes it does not support.  Results agree to rounding. */
 void lago_set_fluid_xpass(int mode);
+/* Sheared-window float32 3D displacement splat (csrc/splat.hip: splat_shear_kernel, the form interp_backward takes
+ * for float32 3D fields): on (default 1; 0 leaves every call to the general tiled kernel of lago_set_splat_tile),
+ * source tile TX x TY x TZ (TX an upper bound shrunk until the window fits 80 KB; TZ = 0: whole z rows, split evenly
+ * above 128 voxels), window margins MX MY MZ around the probed origin, threads per workgroup (256 / 512 / 1024).
+ * Default 1, 8 6 0, 1 1 4, 1024.  d_u is bit-identical under every setting; d_I differs by the order of its sums. */
+void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
+/* 1 (default): several channels with d_u wanted keep each voxel's d_u sums in registers over the channel loop
+ * (sheared-window kernel / general tiled kernel); 0: d_u is read-modify-written per channel.  Same bits. */
+void lago_set_splat_shear_mc(int on);
+void lago_set_splat_mc(int on);
+/* FFT-pass fluid metric: batch items per x-pass workgroup (0, the default: chosen by the size of the launch),
+ * persistent prefetching zy kernels for planes above 80 KB of LDS (default 1), 512-thread x-pass workgroups for
+ * the 256-point tile (default 1).  Same bits under every setting. */
+void lago_set_fluid_xpass_ipw(int items);
+void lago_set_fluid_zy_persist(int on);
+void lago_set_fluid_xpass_wide(int on);
 
 #define LAGO_DECLARE(REAL, SUF)                                                                                      \
     /* interp_forward (extension.cpp:135-143 -> cuda/interp.cu:80-130):                                           \

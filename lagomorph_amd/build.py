@@ -4,7 +4,11 @@ In-tree build: objects under lagomorph_amd/_build/, the shared library at
 lagomorph_amd/_lib/liblagomorph_hip.so (git-ignored; travels to the GPU box with
 the gpurun snapshot).  hipcc cross-compiles without a GPU.
 
-    python -m lagomorph_amd.build [-f] [-v]
+    python -m lagomorph_amd.build [-f] [-v] [--profiling]
+
+--profiling builds lagomorph_amd/_lib/liblagomorph_hip_prof.so with -DLAGO_PROFILING: the same library plus the
+`lago_debug_*` knobs that skip stages of kernels (results are WRONG with them set) for the ablation scripts under
+tools/ (select it with LAGO_HIP_LIBRARY=<path>).  The product library has no result-changing knob.
 """
 import os
 import subprocess
@@ -16,6 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblagomorph_hip.so")
+LIB_PROF = os.path.join(LIBDIR, "liblagomorph_hip_prof.so")
 SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
@@ -42,12 +47,12 @@ def _stale(target, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
-def _compile(src, force, verbose):
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src, force, verbose, profiling=False):
+    obj = os.path.join(OBJ, "prof" if profiling else "", os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if not force and not _stale(obj, [path] + _deps()):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DLAGO_PROFILING"] if profiling else []) + ["-c", path, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,21 +63,22 @@ def _compile(src, force, verbose):
     return obj
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=False, profiling=False):
+    os.makedirs(os.path.join(OBJ, "prof") if profiling else OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    lib = LIB_PROF if profiling else LIB
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhipfft"]
+        objs = list(ex.map(lambda s: _compile(s, force, verbose, profiling), srcs))
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lhipfft"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="-f" in sys.argv, verbose="-v" in sys.argv))
+    print(build(force="-f" in sys.argv, verbose="-v" in sys.argv, profiling="--profiling" in sys.argv))

@@ -247,7 +247,12 @@ static hipError_t xpass2_dispatch(int64_t nx, const fl::XArgs &a, bool inverse, 
 }
 
 std::atomic<int> g_xpass_ipw{0};  // batch items per x-pass workgroup; 0 = by the size of the launch (below)
-std::atomic<int> g_native_stage_mask{7};  // profiling only: bit 0 zy forward, bit 1 x pass, bit 2 zy inverse
+#ifdef LAGO_PROFILING  // profiling builds only (results are wrong when != 7): bit 0 zy forward, bit 1 x pass, bit 2 zy inverse
+std::atomic<int> g_native_stage_mask{7};
+#define LAGO_STAGE_MASK ((int)g_native_stage_mask)
+#else
+#define LAGO_STAGE_MASK 7
+#endif
 
 // out = irfftn(operator(rfftn(m))) * scale.  tab: split-layout coefficient table (fluid_coef_launch
 // with split = 1).  work: nn*3*nx*ny*(nz/2+1) complex.
@@ -274,7 +279,7 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     xa.scale = (float)scale;
     xa.nn = (int)nn;
     int ipw = g_xpass_ipw;
-    const int stages = g_native_stage_mask;
+    const int stages = LAGO_STAGE_MASK;
     if (ipw <= 0) {
         // two batch items per workgroup halve the reads of the coefficient table (24 B per bin), but only a launch
         // with several rounds of workgroups to spare can afford workgroups of twice the length: small per-GPU
@@ -296,7 +301,10 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
 
 }  // namespace lago
 
+#ifdef LAGO_PROFILING
 extern "C" void lago_debug_fluid_stage_mask(int m) { lago::g_native_stage_mask = m; }
-extern "C" void lago_debug_xpass_ipw(int n) { lago::g_xpass_ipw = n; }
-extern "C" void lago_debug_zy_persist(int on) { lago::g_zy_persist = on; }
-extern "C" void lago_debug_xpass_wide(int on) { lago::g_xpass_wide = on; }
+#endif
+// tuning settings (speed only; include/lagomorph_hip.h)
+extern "C" void lago_set_fluid_xpass_ipw(int n) { lago::g_xpass_ipw = n; }
+extern "C" void lago_set_fluid_zy_persist(int on) { lago::g_zy_persist = on; }
+extern "C" void lago_set_fluid_xpass_wide(int on) { lago::g_xpass_wide = on; }

@@ -235,7 +235,14 @@ int fluid_coef_launch(float *tab, int inverse, const float *cosX, const float *s
     return finish_launch(s, "fluid_coef");
 }
 
-std::atomic<int> g_xpass_dbg{0};  // profiling only (results are wrong when != 0)
+// Profiling builds only (python -m lagomorph_amd.build --profiling -> liblagomorph_hip_prof.so, used by tools/):
+// a non-zero variant skips stages of the x pass, i.e. the results are wrong.  The product library has no such knob.
+#ifdef LAGO_PROFILING
+std::atomic<int> g_xpass_dbg{0};
+#define LAGO_XPASS_DBG ((int)g_xpass_dbg)
+#else
+#define LAGO_XPASS_DBG 0
+#endif
 bool fluid_xpass_supported(int64_t nx) { return nx == 64 || nx == 128 || nx == 256; }
 
 template <int LOGN>
@@ -256,10 +263,10 @@ static hipError_t xpass_launch(float2 *F, const float *tab, int inverse, int64_t
     }
     if (inverse)
         hipLaunchKernelGGL(kinv, dim3((uint32_t)total), dim3(256), smem, s, F, tab, (int)ny, (int)nzc, KC, nchunks, scale,
-                           (uint32_t)total, (int)g_xpass_dbg);
+                           (uint32_t)total, LAGO_XPASS_DBG);
     else
         hipLaunchKernelGGL(kfwd, dim3((uint32_t)total), dim3(256), smem, s, F, tab, (int)ny, (int)nzc, KC, nchunks, scale,
-                           (uint32_t)total, (int)g_xpass_dbg);
+                           (uint32_t)total, LAGO_XPASS_DBG);
     return hipSuccess;
 }
 
@@ -277,5 +284,7 @@ int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int6
 
 }  // namespace lago
 
+#ifdef LAGO_PROFILING
 extern "C" void lago_debug_xpass_variant(int v) { lago::g_xpass_dbg = v; }
+#endif
 

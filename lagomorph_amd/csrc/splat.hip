@@ -943,9 +943,9 @@ template int regrid_splat_lds<double>(double *, const double *, int64_t, const G
 extern "C" {
 // Tuning hook (bench / tests): tile TX, TY, TZ (0 = auto), window margins, threads per workgroup.
 // Affects speed only, never results.
-void lago_debug_splat_mc(int on) { lago::g_splat_mc = on; }
+void lago_set_splat_mc(int on) { lago::g_splat_mc = on; }
 // sheared-window float32 splat: on/off, tile TX TY TZ (0 = auto), margins, threads per workgroup.  Speed only.
-void lago_debug_splat_shear_mc(int on) { lago::g_shear_mc = on; }
+void lago_set_splat_shear_mc(int on) { lago::g_shear_mc = on; }
 void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
     lago::g_shear_on = on;
     lago::g_shear_cfg.set({tx, ty, tz, mx, my, mz});

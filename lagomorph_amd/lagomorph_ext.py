@@ -19,7 +19,9 @@ import os
 import torch  # must be imported first: it loads the process's libamdhip64.so.7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "liblagomorph_hip.so")
+# LAGO_HIP_LIBRARY selects another build of the same C ABI (tools/ use the -DLAGO_PROFILING build this way)
+LIB_PATH = os.environ.get("LAGO_HIP_LIBRARY") or os.path.join(_HERE, "_lib", "liblagomorph_hip.so")
+ABI_VERSION = 3  # LAGO_ABI_VERSION of include/lagomorph_hip.h this binding was written against
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -27,6 +29,13 @@ if not os.path.exists(LIB_PATH):
         "(run `python -m lagomorph_amd.build`); lagomorph_amd has no CPU fallback"
     )
 _lib = ctypes.CDLL(LIB_PATH)
+_lib.lago_abi_version.restype = ctypes.c_int
+if _lib.lago_abi_version() != ABI_VERSION:
+    # a stale library would be called with shifted arguments (memory corruption, not an error): refuse it
+    raise ImportError(
+        f"{LIB_PATH} has C-ABI version {_lib.lago_abi_version()}, this binding needs {ABI_VERSION}: "
+        "rebuild it with `python -m lagomorph_amd.build -f`"
+    )
 _lib.lago_last_error.restype = ctypes.c_char_p
 _lib.lago_version.restype = ctypes.c_char_p
 
@@ -75,6 +84,9 @@ _lib.lago_set_splat_tile.argtypes = [_int] * 7
 _lib.lago_set_vector_kernels.argtypes = [_int]
 _lib.lago_set_splat_shear.argtypes = [_int] * 8
 _lib.lago_set_fluid_xpass.argtypes = [_int]
+for _name in ("lago_set_splat_mc", "lago_set_splat_shear_mc", "lago_set_fluid_xpass_ipw", "lago_set_fluid_zy_persist",
+              "lago_set_fluid_xpass_wide"):
+    getattr(_lib, _name).argtypes = [_int]
 
 
 def _suffix(t):
@@ -149,6 +161,24 @@ def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
 def set_splat_shear(on=1, tx=8, ty=6, tz=0, mx=1, my=1, mz=4, nthreads=1024):
     """Sheared-window float32 splat (csrc/splat.hip: splat_shear_kernel): on/off and its tile.  Speed only."""
     _lib.lago_set_splat_shear(int(on), int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
+
+
+def set_splat_mc(on):
+    """General tiled splat: 1 (default) the multi-channel single-pass form where it applies.  Speed only."""
+    _lib.lago_set_splat_mc(1 if on else 0)
+
+
+def set_splat_shear_mc(on):
+    """Sheared-window splat: 1 (default) keeps d_u in registers over the channels.  Speed only."""
+    _lib.lago_set_splat_shear_mc(1 if on else 0)
+
+
+def set_fluid_tuning(xpass_ipw=0, zy_persist=1, xpass_wide=1):
+    """FFT-pass fluid metric: batch items per x-pass workgroup (0 = by launch size), persistent zy kernels for
+    planes above 80 KB, 512-thread x pass for the 256-point tile.  Speed only."""
+    _lib.lago_set_fluid_xpass_ipw(int(xpass_ipw))
+    _lib.lago_set_fluid_zy_persist(1 if zy_persist else 0)
+    _lib.lago_set_fluid_xpass_wide(1 if xpass_wide else 0)
 
 
 def set_vector_kernels(on):

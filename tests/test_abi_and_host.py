@@ -30,9 +30,40 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35, names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/lagomorph_hip.h but not exported: {missing}"
-    assert lib.lago_abi_version() == 2
+    assert lib.lago_abi_version() == lagomorph_amd.lagomorph_ext.ABI_VERSION == 3
     lib.lago_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.lago_version()
+
+
+def test_library_exports_nothing_undeclared():
+    """The other direction: every `lago_*` symbol the product library exports is declared in the header -- in
+    particular no `lago_debug_*` profiling knob (those exist only in the -DLAGO_PROFILING build for tools/)."""
+    import subprocess
+
+    import lagomorph_amd
+
+    out = subprocess.run(["nm", "-D", "--defined-only", lagomorph_amd.lagomorph_ext.LIB_PATH], capture_output=True,
+                         text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW"
+                       and ln.split()[-1].startswith("lago_")})
+    assert len(exported) >= 35
+    extra = [n for n in exported if n not in set(declared_symbols())]
+    assert not extra, f"exported by the library but not declared in include/lagomorph_hip.h: {extra}"
+    assert not [n for n in exported if n.startswith("lago_debug")]
+
+
+def test_loader_refuses_a_stale_abi(tmp_path):
+    """a library of another ABI version must be refused at import, not called with shifted arguments."""
+    import subprocess
+    import sys
+
+    src = tmp_path / "stale.c"
+    src.write_text("int lago_abi_version(void) { return 2; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    r = subprocess.run([sys.executable, "-c", "import lagomorph_amd"], capture_output=True, text=True, cwd=ROOT,
+                       env={**os.environ, "LAGO_HIP_LIBRARY": str(so)})
+    assert r.returncode != 0 and "C-ABI version 2" in r.stderr and "lagomorph_amd.build" in r.stderr
 
 
 def test_shim_covers_the_reference_surface():

@@ -445,11 +445,11 @@ def test_persistent_zy_passes_any_plane_count(ext, batch):
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     got = met.sharp(dev(m))
     assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "persistent zy passes vs oracle")
-    ext._lib.lago_debug_zy_persist(0)
+    ext._lib.lago_set_fluid_zy_persist(0)
     try:
         plain = met.sharp(dev(m))
     finally:
-        ext._lib.lago_debug_zy_persist(1)
+        ext._lib.lago_set_fluid_zy_persist(1)
     assert torch.equal(got, plain)
 
 

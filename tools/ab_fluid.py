@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the fluid-metric pass settings in one process: x-pass workgroups of 256 threads or wide (the 256-point tile),
-batch items per x-pass workgroup; `lago_debug_zy_persist` switches the persistent zy kernels the same way.  env: S (160), B (8)."""
+batch items per x-pass workgroup; `lago_set_fluid_zy_persist` switches the persistent zy kernels the same way.  env: S (160), B (8)."""
 import ctypes
 import os
 import sys
@@ -21,15 +21,15 @@ ref = None
 for r in range(2):
     for persist in (1,):
         for ipw in (0, 10, 11):   # 10 / 11: automatic items per workgroup with 256-thread / wide x-pass workgroups
-            lib.lago_debug_zy_persist(persist)
-            lib.lago_debug_xpass_wide(0 if ipw == 10 else 1)
-            lib.lago_debug_xpass_ipw(0 if ipw >= 10 else ipw)
+            lib.lago_set_fluid_zy_persist(persist)
+            lib.lago_set_fluid_xpass_wide(0 if ipw == 10 else 1)
+            lib.lago_set_fluid_xpass_ipw(0 if ipw >= 10 else ipw)
             out = met.sharp(m)
             if ref is None:
                 ref = out
             same = torch.equal(out, ref)
             t, _ = time_op(lambda: met.sharp(m), reps=30, warm=20)
             print(f"{shape} B={B} persist={persist} ipw={ipw}: {t*1e3:7.1f} us  bits {'same' if same else 'DIFFER'}")
-lib.lago_debug_zy_persist(1)
-lib.lago_debug_xpass_ipw(0)
-lib.lago_debug_xpass_wide(1)
+lib.lago_set_fluid_zy_persist(1)
+lib.lago_set_fluid_xpass_ipw(0)
+lib.lago_set_fluid_xpass_wide(1)

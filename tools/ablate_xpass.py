@@ -8,6 +8,9 @@ import lagomorph_amd as lm
 from lagomorph_amd import lagomorph_ext as ext
 
 lib = ext._lib
+assert hasattr(lib, "lago_debug_xpass_variant"), (
+    "needs the profiling build: python -m lagomorph_amd.build --profiling; "
+    "LAGO_HIP_LIBRARY=lagomorph_amd/_lib/liblagomorph_hip_prof.so python " + sys.argv[0])
 m = torch.randn((32, 3, 128, 128, 128), device="cuda")
 met = lm.FluidMetric([0.1, 0.0, 0.01])
 for var in (0, 1, 2, 3, 0):

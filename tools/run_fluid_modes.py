@@ -8,6 +8,9 @@ import lagomorph_amd as lm
 from lagomorph_amd import lagomorph_ext as ext
 
 lib = ext._lib
+assert hasattr(lib, "lago_debug_xpass_variant"), (
+    "needs the profiling build: python -m lagomorph_amd.build --profiling; "
+    "LAGO_HIP_LIBRARY=lagomorph_amd/_lib/liblagomorph_hip_prof.so python " + sys.argv[0])
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 m = torch.randn((batch, 3, size, size, size), device="cuda")
@@ -36,9 +39,9 @@ with torch.no_grad():
         print(f"native stage mask {mask}: sharp {timeit(lambda: met.sharp(m)):.3f} ms", flush=True)
     lib.lago_debug_fluid_stage_mask(7)
     for ipw in (1, 2, 4, 8):
-        lib.lago_debug_xpass_ipw(ipw)
+        lib.lago_set_fluid_xpass_ipw(ipw)
         lib.lago_debug_fluid_stage_mask(2)
         a = timeit(lambda: met.sharp(m))
         lib.lago_debug_fluid_stage_mask(7)
         print(f"x pass, {ipw} batch items per workgroup: x pass alone {a:.3f} ms, sharp {timeit(lambda: met.sharp(m)):.3f} ms", flush=True)
-    lib.lago_debug_xpass_ipw(2)
+    lib.lago_set_fluid_xpass_ipw(2)
