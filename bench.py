@@ -337,7 +337,8 @@ def atlas_leg(lm, dev, world, rank, args):
                     f"gradient, image update), {S}^3 fp32, global minibatch {GB} = {B} per GPU x {world}, 5 integration "
                     f"steps (BASELINE configs[4])",
         "value": vox / T, "unit": "voxels/s", "ms_per_step": 1e3 * T / args.atlas_steps, "steps": args.atlas_steps,
-        "warmup": args.atlas_warmup, "n_ranks": world, "global_batch": GB, "per_gpu_batch": B, "scaling": "strong",
+        "warmup": args.atlas_warmup, "n_ranks": world, "backend": dist.get_backend() if world > 1 else None,
+        "global_batch": GB, "per_gpu_batch": B, "scaling": "strong",
         "collective": "RCCL all_reduce(SUM) of I.grad, %.1f MB fp32, issued from the backward pass" % (4 * S ** 3 / 1e6)
                       if world > 1 else None,
         "allreduce_ms": ar_ms, "alg_bytes_per_voxel": bpv, "achieved_GBps": gbps,
@@ -347,7 +348,7 @@ def atlas_leg(lm, dev, world, rank, args):
 
 def cpu_baseline(size, euler_steps, sample_batch=1):
     """Times the CPU oracle (test infrastructure) on bounded samples of the benchmark's workloads on the host's
-    cores (OpenMP, at most 64 threads) and on one thread: the headline sample (`sample_batch` volumes of size^3,
+    cores (OpenMP, one thread per host CPU) and on one thread: the headline sample (`sample_batch` volumes of size^3,
     one expmap of `euler_steps` steps) and the four operators of BASELINE.md section 4 (interp, splat, jtv, sharp)
     at batch 8.  The oracle stands in for lagomorph_ext only inside this function."""
     import numpy as np
@@ -373,9 +374,9 @@ def cpu_baseline(size, euler_steps, sample_batch=1):
         rng = np.random.default_rng(7)
         met = lm.FluidMetric([0.1, 0.0, 0.01])
         runs = {}
-        nthreads = max(1, min(os.cpu_count() or 1, 64))
+        nthreads = max(1, os.cpu_count() or 1)
         prev_threads = torch.get_num_threads()
-        # all host cores (capped at 64 OpenMP threads) on the full sample, one thread on a quarter of it
+        # all host cores on the full sample, one thread on a quarter of it
         for tag, threads, batch in (("all", nthreads, sample_batch), ("one", 1, max(1, sample_batch // 4))):
             m = torch.from_numpy((0.01 * rng.standard_normal((batch, 3, size, size, size))).astype(np.float32))
             orc.set_threads(threads)
@@ -483,14 +484,13 @@ SHARE_GPU = os.environ.get("LAGO_BENCH_SHARE_GPU", "") == "1"
 
 
 def spawn_workers(args):
-    """Parent of an N-GPU run started without a launcher: start N fresh workers, one per GPU, before any GPU call
-    (counting devices does not initialise HIP) and hand their output through.  Returns the exit code."""
+    """Parent of an N-GPU run started without a launcher: start N fresh workers, one per GPU, and hand their output
+    through.  The parent makes NO GPU call at all -- not even a device count, which on ROCm may fall back to
+    hipGetDeviceCount and initialise the runtime; each worker validates its own device instead
+    (torch.cuda.set_device(local_rank) fails on a box with fewer GPUs).  Returns the exit code."""
     import socket
     import subprocess
 
-    n = torch.cuda.device_count()
-    if n < args.gpus and not SHARE_GPU:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -279,7 +279,7 @@ def affine_atlas(images, As, Ts, I=None, num_epochs=1000, batch_size=50, image_u
 
 def save_affine_atlas(path, I, As, Ts, epoch_losses, iter_losses):
     """The result file of the reference's affine atlas tool (affine.py:581-587): HDF5 datasets `atlas`, `A`, `T`,
-    `epoch_losses`, `iter_losses` when h5py is importable, the same dictionary through torch.save otherwise."""
+    `epoch_losses`, `iter_losses` when h5py is importable, the same arrays as an .npz archive otherwise."""
     import numpy as np
 
     st = {"atlas": I.detach().cpu().numpy(), "A": As.detach().cpu().numpy(), "T": Ts.detach().cpu().numpy(),
@@ -287,7 +287,8 @@ def save_affine_atlas(path, I, As, Ts, epoch_losses, iter_losses):
     try:
         import h5py
     except ImportError:
-        torch.save(st, path)
+        with open(path, "wb") as fh:
+            np.savez(fh, **st)
         return path
     with h5py.File(path, "w") as f:
         for k, v in st.items():
@@ -310,7 +311,8 @@ def load_affine_atlas(path):
         with h5py.File(path, "r") as f:
             st = {k: np.asarray(f[k]) for k in ("atlas", "A", "T", "epoch_losses", "iter_losses")}
     else:
-        st = torch.load(path, map_location="cpu", weights_only=False)
+        with np.load(path, allow_pickle=False) as z:
+            st = {k: z[k] for k in z.files}
     return (torch.from_numpy(np.asarray(st["atlas"])), torch.from_numpy(np.asarray(st["A"])),
             torch.from_numpy(np.asarray(st["T"])), [float(x) for x in st["epoch_losses"]],
             [float(x) for x in st["iter_losses"]])

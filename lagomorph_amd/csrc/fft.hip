@@ -61,7 +61,11 @@ struct CoefTab {
     }
 };
 typedef std::shared_ptr<CoefTab> CoefRef;
-static std::vector<CoefRef> g_tabs;
+// The cache object is heap-allocated and never destroyed: a namespace-scope vector would run ~CoefTab -> hipFree from
+// a static destructor at process exit, possibly after the HIP runtime has been torn down.  Evicted and
+// cleared entries are released OUTSIDE g_plan_mu: hipFree synchronises the device, and doing that under the mutex
+// would stall every other thread's table lookup and hipFFT exec.
+static std::vector<CoefRef> &g_tabs = *new std::vector<CoefRef>();
 static const size_t kCoefCacheBytes = (size_t)1 << 30;  // at most 1 GiB of tables (24 B per frequency bin each)
 
 struct FftPlan {
@@ -105,6 +109,7 @@ static int get_coef(CoefRef &ref, int64_t gen, int inverse, const float *cosX, c
     int device = 0;
     LAGO_HIP_TRY(hipGetDevice(&device));
     const int64_t nzc = nz / 2 + 1;
+    std::vector<CoefRef> evicted;  // declared before the lock: released after it
     std::lock_guard<std::mutex> lk(g_plan_mu);
     for (const CoefRef &t : g_tabs)
         if (t->gen == gen && t->nx == nx && t->ny == ny && t->nz == nz && t->inverse == inverse && t->device == device &&
@@ -124,6 +129,7 @@ static int get_coef(CoefRef &ref, int64_t gen, int inverse, const float *cosX, c
     for (const CoefRef &o : g_tabs) total += o->bytes;
     while (!g_tabs.empty() && (total > kCoefCacheBytes || g_tabs.size() >= 64)) {  // bounded by bytes, oldest first
         total -= g_tabs.front()->bytes;
+        evicted.push_back(std::move(g_tabs.front()));
         g_tabs.erase(g_tabs.begin());
     }
     g_tabs.push_back(t);
@@ -218,8 +224,9 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
 extern "C" {
 void lago_set_fluid_xpass(int mode) { lago::g_fluid_xpass = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 void lago_fluid_cache_clear(void) {
+    std::vector<lago::CoefRef> dropped;  // released after the lock
     std::lock_guard<std::mutex> lk(lago::g_plan_mu);
-    lago::g_tabs.clear();
+    dropped.swap(lago::g_tabs);
 }
 int lago_fluid_cache_entries(void) {
     std::lock_guard<std::mutex> lk(lago::g_plan_mu);

@@ -59,13 +59,21 @@ class ExpmapFunction(torch.autograd.Function):
     def forward(ctx, metric, m0, phiinv, dt, num_steps, v0):
         m0 = m0.contiguous()
         keep = ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[5]
-        phi, steps, first = _shoot(metric, m0, phiinv, dt, num_steps, v0, keep)
-        ctx.metric, ctx.dt, ctx.steps, ctx.m0, ctx.first, ctx.has_v0 = metric, dt, steps, m0, first, v0 is not None
+        phi0 = None if phiinv is None else phiinv.contiguous()
+        phi, steps, first = _shoot(metric, m0, phi0, dt, num_steps, v0, keep)
+        # the two input tensors the reverse sweep reads go through save_for_backward, so that an in-place edit
+        # between forward and backward raises instead of giving silently wrong gradients (phi0 may be the caller's
+        # own tensor); the per-step tensors are intermediates nobody else holds
+        ctx.save_for_backward(*([m0] if phi0 is None else [m0, phi0]))
+        ctx.metric, ctx.dt, ctx.steps, ctx.first, ctx.has_v0 = metric, dt, steps, first, v0 is not None
         return phi
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # the reverse sweep is not itself differentiable
     def backward(ctx, G):
-        metric, dt, m0 = ctx.metric, ctx.dt, ctx.m0
+        metric, dt = ctx.metric, ctx.dt
+        saved = ctx.saved_tensors   # (version-checked)
+        m0 = saved[0]
         need_m, need_phi, need_v0 = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[5]
         d_m0, G = _shoot_reverse(metric, m0, dt, ctx.steps, G.contiguous())
         ctx.steps = None
@@ -498,13 +506,15 @@ class LDDMMAtlasBuilder:
 
     def save(self, filename):
         """HDF5 with the reference's dataset names when h5py is importable (lddmm.py:251-262); otherwise
-        the same dictionary through torch.save.  Rank r > 0 writes `<filename>.rank<r>`."""
+        the same arrays as an uncompressed .npz archive (numpy arrays only: read back without pickle).
+        Rank r > 0 writes `<filename>.rank<r>`."""
         st = self.state_dict()
         path = self._rank_path(filename)
         try:
             import h5py
         except ImportError:
-            torch.save(st, path)
+            with open(path, "wb") as fh:
+                np.savez(fh, **{k: np.asarray(v) for k, v in st.items()})
             return path
         with h5py.File(path, "w") as f:
             f.create_dataset("atlas", data=st["atlas"])
@@ -532,5 +542,6 @@ class LDDMMAtlasBuilder:
                                                     "iter_losses", "iter_reg_terms")}
                 st["batch_sizes"] = [int(s) for s in f["momenta"].attrs["batch_sizes"]]
         else:
-            st = torch.load(path, map_location="cpu", weights_only=False)
+            with np.load(path, allow_pickle=False) as z:
+                st = {k: z[k] for k in z.files}
         self.load_state_dict(st, load_image=load_image, load_momenta=load_momenta, load_losses=load_losses)

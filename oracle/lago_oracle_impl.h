@@ -233,6 +233,45 @@ int FN(oracle_interp_forward)(REAL *out, const REAL *I, const REAL *u, double dt
     return 0;
 }
 
+/* One x-slab [i0, i1) of one channel of one batch item of interp_kernel_backward_{2,3}d (cuda/interp.cu:132-244):
+ * the splat goes into `dIc` (a full channel plane), d_u is owned voxel by voxel. */
+static void FN(lg_interp_backward_slab)(REAL *dIc, REAL *dun, const REAL *gc, const REAL *Ic, const REAL *un,
+                                        double dt, int dim, long nx, long ny, long nz, long i0, long i1, int need_I,
+                                        int need_u) {
+    const size_t nvox = (size_t)nx * ny * nz;
+    for (long i = i0; i < i1; ++i)
+        for (long j = 0; j < ny; ++j)
+            for (long k = 0; k < nz; ++k) {
+                size_t ix = ((size_t)i * ny + j) * nz + k;
+                REAL hx = (REAL)LG_FMAD(dt, (double)un[ix], (double)i);
+                REAL hy = (REAL)LG_FMAD(dt, (double)un[ix + nvox], (double)j);
+                REAL hz = 0;
+                if (dim == 3) hz = (REAL)LG_FMAD(dt, (double)un[ix + 2 * nvox], (double)k);
+                REAL diff = gc[ix];
+                if (need_I) {
+                    if (dim == 2)
+                        FN(lg_splat2)(dIc, diff, hx, hy, nx, ny);
+                    else
+                        FN(lg_splat3)(dIc, diff, hx, hy, hz, nx, ny, nz);
+                }
+                if (need_u) {
+                    REAL gx, gy, gz;
+                    if (dim == 2) {
+                        FN(lg_bilerp_grad)(&gx, &gy, Ic, hx, hy, nx, ny);
+                        diff = (REAL)((double)diff * dt);
+                        dun[ix] = LG_FMA(gx, diff, dun[ix]);
+                        dun[ix + nvox] = LG_FMA(gy, diff, dun[ix + nvox]);
+                    } else {
+                        FN(lg_trilerp_grad)(&gx, &gy, &gz, Ic, hx, hy, hz, nx, ny, nz);
+                        diff = (REAL)((double)diff * dt);
+                        dun[ix] = LG_FMA(gx, diff, dun[ix]);
+                        dun[ix + nvox] = LG_FMA(gy, diff, dun[ix + nvox]);
+                        dun[ix + 2 * nvox] = LG_FMA(gz, diff, dun[ix + 2 * nvox]);
+                    }
+                }
+            }
+}
+
 /* cuda/interp.cu:132-244 (kernels), :246-313 (host: both outputs always
  * allocated as zeros and returned). */
 int FN(oracle_interp_backward)(REAL *d_I, REAL *d_u, const REAL *go, const REAL *I, const REAL *u, double dt,
@@ -244,6 +283,36 @@ int FN(oracle_interp_backward)(REAL *d_I, REAL *d_u, const REAL *go, const REAL 
     const size_t nI = (broadcast_I ? 1 : (size_t)nn) * nc * nvox;
     memset(d_I, 0, nI * sizeof(REAL));
     memset(d_u, 0, (size_t)nn * dim * nvox * sizeof(REAL));
+    /* cpu_baseline leg only (bench.py raises the thread count; the tests run with one thread): with more threads than
+     * batch items every (item, channel) is cut into x-slabs that splat into private planes, which are then added
+     * onto d_I in slab order -- a deterministic summation order, but not the sequential one (the reference's atomic
+     * order is unspecified as well).  d_u is owned voxel by voxel and does not depend on the split. */
+    const long slabs = (lg_oracle_threads > nn && nn > 0 && need_I) ? (lg_oracle_threads + nn - 1) / nn : 1;
+    if (slabs > 1 && nx >= 2 * slabs) {
+        const long ntask = nn * slabs;
+        REAL *priv = (REAL *)calloc((size_t)ntask * nvox, sizeof(REAL));
+        if (!priv) return -2;
+        for (long c = 0; c < nc; ++c) {
+            if (c) memset(priv, 0, (size_t)ntask * nvox * sizeof(REAL));
+            LG_PARALLEL_FOR_IF(1)
+            for (long t = 0; t < ntask; ++t) {
+                const long n = t / slabs, sl = t % slabs;
+                const long i0 = nx * sl / slabs, i1 = nx * (sl + 1) / slabs;
+                const REAL *In = broadcast_I ? I : I + (size_t)n * nc * nvox;
+                FN(lg_interp_backward_slab)(priv + (size_t)t * nvox, d_u + (size_t)n * dim * nvox,
+                                            go + ((size_t)n * nc + c) * nvox, In + (size_t)c * nvox,
+                                            u + (size_t)n * dim * nvox, dt, dim, nx, ny, nz, i0, i1, need_I, need_u);
+            }
+            LG_PARALLEL_FOR
+            for (long x = 0; x < (long)nvox; ++x)
+                for (long t = 0; t < ntask; ++t) {
+                    REAL *dIc = (broadcast_I ? d_I : d_I + (size_t)(t / slabs) * nc * nvox) + (size_t)c * nvox;
+                    dIc[x] += priv[(size_t)t * nvox + x];
+                }
+        }
+        free(priv);
+        return 0;
+    }
     /* a batch item owns its d_u, and its d_I unless I is broadcast: OpenMP over n (cpu_baseline leg only)
      * leaves every sum in the sequential order */
     LG_PARALLEL_FOR_IF(!broadcast_I || !need_I)
@@ -253,42 +322,9 @@ int FN(oracle_interp_backward)(REAL *d_I, REAL *d_u, const REAL *go, const REAL 
         const REAL *In = broadcast_I ? I : I + (size_t)n * nc * nvox;
         REAL *dIn = broadcast_I ? d_I : d_I + (size_t)n * nc * nvox;
         const REAL *gon = go + (size_t)n * nc * nvox;
-        for (long c = 0; c < nc; ++c) {
-            const REAL *Ic = In + (size_t)c * nvox;
-            REAL *dIc = dIn + (size_t)c * nvox;
-            const REAL *gc = gon + (size_t)c * nvox;
-            for (long i = 0; i < nx; ++i)
-                for (long j = 0; j < ny; ++j)
-                    for (long k = 0; k < nz; ++k) {
-                        size_t ix = ((size_t)i * ny + j) * nz + k;
-                        REAL hx = (REAL)LG_FMAD(dt, (double)un[ix], (double)i);
-                        REAL hy = (REAL)LG_FMAD(dt, (double)un[ix + nvox], (double)j);
-                        REAL hz = 0;
-                        if (dim == 3) hz = (REAL)LG_FMAD(dt, (double)un[ix + 2 * nvox], (double)k);
-                        REAL diff = gc[ix];
-                        if (need_I) {
-                            if (dim == 2)
-                                FN(lg_splat2)(dIc, diff, hx, hy, nx, ny);
-                            else
-                                FN(lg_splat3)(dIc, diff, hx, hy, hz, nx, ny, nz);
-                        }
-                        if (need_u) {
-                            REAL gx, gy, gz;
-                            if (dim == 2) {
-                                FN(lg_bilerp_grad)(&gx, &gy, Ic, hx, hy, nx, ny);
-                                diff = (REAL)((double)diff * dt);
-                                dun[ix] = LG_FMA(gx, diff, dun[ix]);
-                                dun[ix + nvox] = LG_FMA(gy, diff, dun[ix + nvox]);
-                            } else {
-                                FN(lg_trilerp_grad)(&gx, &gy, &gz, Ic, hx, hy, hz, nx, ny, nz);
-                                diff = (REAL)((double)diff * dt);
-                                dun[ix] = LG_FMA(gx, diff, dun[ix]);
-                                dun[ix + nvox] = LG_FMA(gy, diff, dun[ix + nvox]);
-                                dun[ix + 2 * nvox] = LG_FMA(gz, diff, dun[ix + 2 * nvox]);
-                            }
-                        }
-                    }
-        }
+        for (long c = 0; c < nc; ++c)
+            FN(lg_interp_backward_slab)(dIn + (size_t)c * nvox, dun, gon + (size_t)c * nvox, In + (size_t)c * nvox, un,
+                                        dt, dim, nx, ny, nz, 0, nx, need_I, need_u);
     }
     return 0;
 }

@@ -71,6 +71,39 @@ def test_config1_interp_splat_batch8_128cubed(lm):
     assert np.array_equal(out[n:n + 1].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("nc", [1, 3])
+@pytest.mark.parametrize("dt", [1.0, -0.2])
+def test_config1_splat_production_geometry_vs_oracle(lm, nc, dt):
+    """The shipped splat kernel in its PRODUCTION geometry (128^3 rows, default 8 x 6 tile shrunk to the 80 KB window,
+    margins 1/1/4, 1024 threads) against the CPU oracle on two items of the configs[1] field: d_u bit for bit, d_I
+    within north_star's 1e-5 x max, one and three channels (the multi-channel form), unit step and the non-unit step
+    of the expmap reverse sweep."""
+    import os
+
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device="cuda").manual_seed(11)
+    N, S = 8, 128
+    I = smooth((N, nc, S, S, S), 2.0, g)
+    I = I / I.std()
+    u = smooth((N, 3, S, S, S), 8.0, g)
+    u = u * (4.0 / u.abs().max())
+    go = torch.randn((N, nc, S, S, S), device="cuda", generator=g)
+    dI, du = ext.interp_backward(go, I, u, dt, True, True)
+    pick = [2, 7]
+    orc.set_threads(min(os.cpu_count() or 1, 64))
+    try:
+        oI, ou = orc.interp_backward(go[pick].cpu().numpy(), I[pick].cpu().numpy(), u[pick].cpu().numpy(), dt, True, True)
+    finally:
+        orc.set_threads(1)
+    assert np.array_equal(du[pick].cpu().numpy(), ou), "d_u of the production splat kernel != oracle"
+    err = np.abs(dI[pick].cpu().numpy().astype(np.float64) - oI).max()
+    assert err <= 1e-5 * np.abs(oI).max(), (err, np.abs(oI).max())
+    # the same call without d_u (another kernel instantiation)
+    dI2, _ = ext.interp_backward(go, I, u, dt, True, False)
+    err = np.abs(dI2[pick].cpu().numpy().astype(np.float64) - oI).max()
+    assert err <= 1e-5 * np.abs(oI).max(), (err, np.abs(oI).max())
+
+
 def test_config2_fluid_metric_batch8(lm):
     """configs[2]: FluidMetric sharp/flat on 3 x 128^3 momentum fields, batch 8."""
     g = torch.Generator(device="cuda").manual_seed(12)
@@ -111,6 +144,41 @@ def test_config3_expmap_batch32(lm):
         # first Euler step from the identity: h1 = -dt * sharp(m)
         h1 = lm.EPDiff_step(met, m, 0.1, torch.zeros_like(m))
         assert torch.allclose(h1, -0.1 * met.sharp(m), rtol=1e-5, atol=1e-6)
+
+
+def test_config3_expmap_batch32_vs_oracle_subbatch(lm):
+    """configs[3] at its real batch: a non-trivial 10-step shoot of 32 different momenta of 3 x 128^3 (about 4 voxels
+    of displacement); three of the items are shot again on the CPU through the oracle backend (the reference's
+    unfused call sequence: interp, jacobian_times_vectorfield, rfft / fluid_operator / irfft, interp + axpy) and
+    compared.  Bound: 1e-4 x max |h| -- ten chained float32 steps, each through an operator with gain 1/gamma^2 = 1e4
+    at the lowest frequencies and FFTs of different factorisations (observed: see profiles/r03_tolerances.md)."""
+    import os
+
+    from test_gpu_lddmm_step import oracle_backend
+
+    g = torch.Generator(device="cuda").manual_seed(31)
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    with torch.no_grad():
+        m = smooth((32, 3, 128, 128, 128), 4.0, g)
+        m = (m * (4.0 / (0.0 + met.sharp(m).abs().max()))).contiguous()
+        h = lm.expmap(met, m, num_steps=10)
+        assert 1.0 < h.abs().max().item() < 20
+        pick = [0, 17, 31]
+        mc = m[pick].cpu()
+        hg = h[pick].cpu()
+        del h
+    orc.set_threads(min(os.cpu_count() or 1, 64))
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    try:
+        with oracle_backend() as lmo, torch.no_grad():
+            hc = lmo.expmap(lmo.FluidMetric([0.1, 0.0, 0.01]), mc, num_steps=10)
+    finally:
+        orc.set_threads(1)
+        torch.set_num_threads(nthr)
+    err = float((hg.double() - hc.double()).abs().max() / hc.double().abs().max())
+    print(f"expmap batch 32 vs oracle sub-batch: {err:.3e} of max |h| = {float(hc.abs().max()):.3f}")
+    assert err <= 1e-4, err
 
 
 def test_jtv_adjoint_identities_128cubed(lm):

@@ -112,6 +112,34 @@ def test_atlas_builder_two_epochs_hip_equals_oracle_backend(sp, msp):
         assert torch.allclose(a.cpu(), b, rtol=0, atol=1e-10 * max(1.0, float(b.abs().max())))
 
 
+@pytest.mark.parametrize("sp,msp", [((16, 18, 20), (16, 18, 20)), ((16, 18, 20), (8, 10, 12))])
+def test_atlas_builder_two_epochs_float32(sp, msp):
+    """The same two epochs in float32, HIP kernels against the oracle backend (both float32: what differs is the
+    summation order of every scatter-add and the FFT).  Stated bounds, relative to the largest value of each
+    quantity: atlas 2e-5, momenta 2e-4 (eight chained lddmm_steps each through sharp, gain 1e4), losses 2e-5
+    (observed on MI355X: profiles/r03_tolerances.md)."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(11)
+    data = torch.from_numpy(smooth_np(rng, (1, 1) + sp, 1.5) + 0.3 * smooth_np(rng, (4, 1) + sp, 1.0)).float()
+    kw = dict(batch_size=2, lddmm_steps=2, lddmm_integration_steps=2, reg_weight=1e-1, learning_rate_pose=2e-6,
+              learning_rate_image=5e-2, momentum_shape=msp)
+    with oracle_backend() as lmo:
+        bc = lmo.LDDMMAtlasBuilder(data, **kw)
+        bc.run(num_epochs=2)
+    bg = lm.LDDMMAtlasBuilder(data.cuda(), **kw)
+    bg.run(num_epochs=2)
+
+    def rel(a, b):
+        return float((a.cpu().double() - b.double()).abs().max() / b.double().abs().max())
+
+    errs = {"atlas": rel(bg.I.detach(), bc.I.detach()),
+            "momenta": max(rel(a, b) for a, b in zip(bg.ms, bc.ms)),
+            "iter_losses": max(abs(a - b) / abs(b) for a, b in zip(bg.iter_losses, bc.iter_losses))}
+    print("two epochs float32, HIP vs oracle backend:", errs)
+    assert errs["atlas"] <= 2e-5 and errs["momenta"] <= 2e-4 and errs["iter_losses"] <= 2e-5, errs
+
+
 def _smooth_cuda(shape, sigma, g):
     import bench
 

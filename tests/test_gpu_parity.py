@@ -129,16 +129,17 @@ def test_tiled_splat_any_tile_config(ext, dtype, tile):
     u = _disp(rng, 2, sp, dtype)
     go = rnd(rng, (2, 2) + sp, dtype)
     oI, ou = orc.interp_backward(go, I, u, 1.0, True, True)
-    for mode in (1,):
+    # shear 0: the sheared-window kernel would take every float32 3D call before the tiled kernel sees it
+    for shear in (0, 1):
         ext.set_splat_tile(*tile)
-        ext.set_splat_mode(mode)
+        ext.set_splat_shear(shear, 8, 6, 0, 1, 1, 4, 1024)
         try:
             dI, du = ext.interp_backward(dev(go), dev(I), dev(u), 1.0, True, True)
         finally:
-            ext.set_splat_tile(0, 8, 0, 1, 1, 4, 512)  # the library default
-            ext.set_splat_mode(1)
-        assert_bits(du, ou, f"d_u mode {mode}")
-        assert_close(dI, oI, dtype, f"d_I mode {mode}")
+            ext.set_splat_tile(0, 8, 0, 1, 1, 4, 512)  # the library defaults
+            ext.set_splat_shear(1, 8, 6, 0, 1, 1, 4, 1024)
+        assert_bits(du, ou, f"d_u shear {shear}")
+        assert_close(dI, oI, dtype, f"d_I shear {shear}")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
