@@ -167,12 +167,21 @@ class RegridModule(torch.nn.Module):
 
 
 def batch_average(images, batch_size=50):
-    """Mean over the first axis, accumulated minibatch by minibatch (utils.batch_average of the
-    reference as used at affine.py:328-333), on the device the images live on."""
-    acc = torch.zeros_like(images[:1])
+    """Mean over the first axis as the reference computes the initial atlas (`data.batch_average`, data.py:308-336,
+    called at affine.py:328-333): minibatch sums in float64 folded into a running average, returned in the images'
+    dtype, shape (1, *images.shape[1:]); on the device the images live on."""
+    avg, seen = None, 0
     for b in range(0, images.size(0), batch_size):
-        acc += images[b:b + batch_size].sum(dim=0, keepdim=True)
-    return acc / max(images.size(0), 1)
+        img = images[b:b + batch_size]
+        sz = img.size(0)
+        avi = img.to(torch.float64).sum(dim=0)
+        avg = avi / sz if avg is None else avg * (seen / (seen + sz)) + avi / (seen + sz)
+        seen += sz
+    if avg is None:
+        return torch.zeros_like(images[:1])
+    if images.dtype in (torch.float32, torch.float64):
+        avg = avg.to(images.dtype)
+    return avg.unsqueeze(0)
 
 
 def affine_atlas(images, As, Ts, I=None, num_epochs=1000, batch_size=50, image_update_freq=0, affine_steps=1,
@@ -208,7 +217,7 @@ def affine_atlas(images, As, Ts, I=None, num_epochs=1000, batch_size=50, image_u
         nvox *= s
     if I is None:
         with torch.no_grad():
-            I = batch_average(images.to(dt), batch_size)
+            I = batch_average(images, batch_size).to(dt)
             if world_size > 1:
                 dist.all_reduce(I)
                 I /= world_size
