@@ -115,9 +115,8 @@ def test_atlas_builder_two_epochs_hip_equals_oracle_backend(sp, msp):
 @pytest.mark.parametrize("sp,msp", [((16, 18, 20), (16, 18, 20)), ((16, 18, 20), (8, 10, 12))])
 def test_atlas_builder_two_epochs_float32(sp, msp):
     """The same two epochs in float32, HIP kernels against the oracle backend (both float32: what differs is the
-    summation order of every scatter-add and the FFT).  Stated bounds, relative to the largest value of each
-    quantity: atlas 2e-5, momenta 2e-4 (eight chained lddmm_steps each through sharp, gain 1e4), losses 2e-5
-    (observed on MI355X: profiles/r03_tolerances.md)."""
+    summation order of every scatter-add and the FFT).  Bound: north_star's 1e-5 relative to the largest value of
+    each quantity (observed on MI355X: atlas identical, momenta 3.5e-7, losses 1.4e-7)."""
     import lagomorph_amd as lm
 
     rng = np.random.default_rng(11)
@@ -137,7 +136,7 @@ def test_atlas_builder_two_epochs_float32(sp, msp):
             "momenta": max(rel(a, b) for a, b in zip(bg.ms, bc.ms)),
             "iter_losses": max(abs(a - b) / abs(b) for a, b in zip(bg.iter_losses, bc.iter_losses))}
     print("two epochs float32, HIP vs oracle backend:", errs)
-    assert errs["atlas"] <= 2e-5 and errs["momenta"] <= 2e-4 and errs["iter_losses"] <= 2e-5, errs
+    assert max(errs.values()) <= 1e-5, errs
 
 
 def _smooth_cuda(shape, sigma, g):
