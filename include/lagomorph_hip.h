@@ -65,6 +65,10 @@ int lago_get_splat_mode(void);
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
 /* 1 (default): use the slab-unrolled 3D gather kernels (two voxels per lane) when the shape allows; 0: one-voxel-per-lane kernels only. */
 void lago_set_vector_kernels(int on);
+/* 1 (default): the 3D Jacobian / stencil terms of Ad_star and jacobian_times_vectorfield_backward are taken from an
+ * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows; 0: every
+ * neighbour is loaded from global memory.  Same bits. */
+void lago_set_stencil_tile(int on);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
  * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
  * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z)

@@ -313,6 +313,9 @@ struct Lerp3 {
     __device__ __forceinline__ R value(const R *__restrict__ img) const {
         R c[8];
         fetch(img, c);
+        return value_of(c);
+    }
+    __device__ __forceinline__ R value_of(const R (&c)[8]) const {
         const R omt = (R)1.f - t, omu = (R)1.f - u, omv = (R)1.f - v;
         return lg_fma(omv, lg_fma(omu, lg_fma(omt, c[0], t * c[1]), u * lg_fma(omt, c[3], t * c[2])),
                       v * lg_fma(omu, lg_fma(omt, c[4], t * c[5]), u * lg_fma(omt, c[7], t * c[6])));

@@ -8,6 +8,7 @@
 // reference formula with this library's interp.
 #include <algorithm>
 #include "common.hpp"
+#include "stencil_tile.hpp"
 
 namespace lago {
 
@@ -308,6 +309,120 @@ __global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__
     }
 }
 
+
+// Row-tile variant (stencil_tile.hpp): the three phiinv planes of a TX x TY-row tile are staged in LDS with a
+// one-voxel halo and the 18 stencil neighbours of a voxel come from there -- 24 gathered + 3 centre + 3 (2 TX + 2 TY)
+// / (TX TY) halo dwords per voxel through the vector-memory path instead of 24 + 3 + 18 (31.5 instead of 45 for the
+// 2 x 4-row tile of a 128-voxel row).  The momentum gathers are issued before the barrier, so their latency and the
+// staging overlap.  Arithmetic and its order are those of ad_star3_unroll_kernel: same bits.
+template <typename R, int NT, int U, int RI, int ZC>
+__global__ __launch_bounds__(NT) void ad_star3_tile_kernel(R *__restrict__ out, R *__restrict__ mphi,
+                                                           const R *__restrict__ phi, const R *__restrict__ m, Geom g,
+                                                           RowTile t) {
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    R *lds = reinterpret_cast<R *>(lago_smem);
+    const uint32_t Lb = xcd_swizzle(blockIdx.x, t.total);
+    const uint32_t n = t.d_tiles.div(Lb);
+    const uint32_t r = Lb - n * t.tiles_per_item;
+    const uint32_t tx = t.d_nty.div(r), ty = r - tx * t.nty;
+    const int x0 = (int)tx * t.TX, y0 = (int)ty * t.TY;
+    const size_t nv = g.nvox;
+    const R *pn = phi + (size_t)n * 3 * nv;
+    const R *mn = m + (size_t)n * 3 * nv;
+    R *on = out + (size_t)n * 3 * nv;
+    TileVox q[U];
+    R pv[3][U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+        q[e] = tile_voxel(t, g, x0, y0, threadIdx.x + (uint32_t)e * NT);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pv[d][e] = pn[(size_t)d * nv + q[e].s];
+    }
+    TileHalo<R, NT, 3, RI, ZC> halo;
+    halo.issue(pn, nv, t, g, x0, y0);
+    halo.commit(lds, g);
+#pragma unroll
+    for (int e = 0; e < U; ++e)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) tile_put(lds + (size_t)d * t.plane, q[e], g.nz, pv[d][e]);
+    Lerp3<R, false> L[U];  // nz >= 2 guaranteed by the host
+#pragma unroll
+    for (int e = 0; e < U; ++e)
+        L[e].setup(sample_pos_t<R, true>(q[e].i, 1.0, pv[0][e]), sample_pos_t<R, true>(q[e].j, 1.0, pv[1][e]),
+                   sample_pos_t<R, true>(q[e].k, 1.0, pv[2][e]), g.nx, g.ny, g.nz);
+    R wv[3][U];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d) __builtin_amdgcn_sched_barrier(0);  // 4 U pair loads in flight at a time, as in interp / compose
+#pragma unroll
+        for (int e = 0; e < U; ++e) wv[d][e] = L[e].value(mn + (size_t)d * nv);
+    }
+    if (mphi) {  // the resampled momentum, kept for the backward pass (what interp_forward would have stored)
+        R *mo = mphi + (size_t)n * 3 * nv;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e = 0; e < U; ++e)
+                if (q[e].ok) mo[(size_t)d * nv + q[e].s] = wv[d][e];
+    }
+    __syncthreads();
+    const uint32_t sy = (uint32_t)t.P, sx = (uint32_t)t.RY * (uint32_t)t.P;
+    // all 18 U neighbour reads first (every lane has a valid slot index, so they need no predicate), then the products
+    R fp[3][U][3], fm[3][U][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const R *pl = lds + (size_t)c * t.plane;
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const uint32_t li = q[e].li;
+            fp[c][e][0] = pl[li + sx]; fm[c][e][0] = pl[li - sx];
+            fp[c][e][1] = pl[li + sy]; fm[c][e][1] = pl[li - sy];
+            fp[c][e][2] = pl[li + 1];  fm[c][e][2] = pl[li - 1];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        R sacc[U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            R gq[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                gq[d] = (R)0.5f * (fp[c][e][d] - fm[c][e][d]);
+                if (c == d) gq[d] = gq[d] + (R)1.0;
+            }
+            sacc[e] = lg_fma(gq[2], wv[2][e], lg_fma(gq[0], wv[0][e], gq[1] * wv[1][e]));
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e)
+            if (q[e].ok) on[(size_t)c * nv + q[e].s] = sacc[e];
+    }
+}
+
+std::atomic<int> g_stencil_tile{1};  // 1: LDS row-tile stencil kernels where the shape allows (default); 0: direct kernels
+
+// 512 threads x 2 voxels: 8 rows of 128 voxels (2 x 4) or 6 rows of 160 (2 x 3) per workgroup, 63 VGPRs (four
+// workgroups per CU).  Measured against 256 x 2 (2 x 2 rows), 1024 x 2 (4 x 4), 768 x 2, 256 x 4 and 512 x 4 voxels
+// per thread, halo rows by LDS-direct loads, streaming stores and an earlier issue of the first gathers: all within
+// +-3 % or slower (profiles/r03_stencil_tile.md).
+template <typename R>
+static bool ad_star_tile_launch(R *out, R *mphi, const R *phi, const R *m, const Geom &g, int64_t nn, hipStream_t s) {
+    constexpr int NT = 512, U = 2, RI = 5;
+    RowTile t;
+    size_t smem;
+    if (!make_row_tile(t, g, nn, NT * U, NT, 3, (int)sizeof(R), RI, smem)) return false;
+    const int zc = (g.nz + 63) / 64;
+#define LAGO_ADT(ZC)                                                                                               \
+    hipLaunchKernelGGL((ad_star3_tile_kernel<R, NT, U, RI, ZC>), dim3(t.total), dim3(NT), smem, s, out, mphi, phi, m, g, t)
+    if (zc == 1) LAGO_ADT(1);
+    else if (zc == 2) LAGO_ADT(2);
+    else if (zc == 3) LAGO_ADT(3);
+    else if (zc == 4) LAGO_ADT(4);
+    else return false;
+#undef LAGO_ADT
+    return true;
+}
+
 template <typename R>
 static int ad_star_impl(R *out, R *mphi, const R *phi, const R *m, int dim, int64_t nn, int64_t nx, int64_t ny,
                         int64_t nz, void *stream) {
@@ -322,6 +437,8 @@ static int ad_star_impl(R *out, R *mphi, const R *phi, const R *m, int dim, int6
         return fail_invalid("Jacobian times vectorfield not implemented for 'thin' dimensions");
     hipStream_t s = (hipStream_t)stream;
     constexpr int U = 2;
+    if (dim == 3 && g_interp_vec && g_stencil_tile && g.nvox >= 4096u && ad_star_tile_launch<R>(out, mphi, phi, m, g, nn, s))
+        return finish_launch(s, "ad_star");
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
@@ -391,6 +508,7 @@ int lincomb_impl(R *out, int k, const R *x0, const R *x1, const R *x2, const R *
 }  // namespace lago
 
 extern "C" {
+void lago_set_stencil_tile(int on) { lago::g_stencil_tile = on ? 1 : 0; }
 int lago_lincomb_f32(float *out, int k, const float *x0, const float *x1, const float *x2, const float *x3, double c0,
                      double c1, double c2, double c3, int64_t n, void *stream) {
     return lago::lincomb_impl<float>(out, k, x0, x1, x2, x3, c0, c1, c2, c3, n, stream);

@@ -703,6 +703,31 @@ def test_ad_star_saves_the_resampled_momentum(ext, dtype, sp):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", [(16, 16, 16), (20, 12, 40), (9, 11, 33), (5, 37, 128), (33, 6, 160), (7, 5, 250), (18, 17, 2)])
+def test_ad_star_row_tile_kernel(ext, dtype, sp):
+    """The LDS row-tile form of Ad_star (csrc/stencil_tile.hpp: stencil neighbours from a staged tile with a
+    one-voxel halo) against the oracle's interp + jacobian_times_vectorfield, bit for bit, and against the direct
+    kernel: ragged last tiles in x and y, rows of 2 ... 250 voxels (1 to 4 z chunks), clamped faces on every side,
+    far-out-of-range displacements, with and without the saved resampled momentum."""
+    rng = np.random.default_rng(hash(sp) % 2**31)
+    phi = _disp(rng, 3, sp, dtype)
+    m = rnd(rng, (3, 3) + sp, dtype)
+    want_m = orc.interp_forward(m, phi, 1.0)
+    want = orc.jacobian_times_vectorfield_forward(phi, want_m, True, False)
+    got = {}
+    for tile in (1, 0):
+        ext.set_stencil_tile(tile)
+        try:
+            got[tile] = ext.Ad_star(dev(phi), dev(m))
+            out, mphi = ext.Ad_star(dev(phi), dev(m), save_resampled=True)
+        finally:
+            ext.set_stencil_tile(1)
+        assert_bits(got[tile], want, f"Ad_star tile={tile} {sp}")
+        assert_bits(out, want, f"Ad_star(save) tile={tile} {sp}")
+        assert_bits(mphi, want_m, f"resampled momentum tile={tile} {sp}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp", [(6, 5, 8), (7, 9), (10, 12, 40)])
 def test_fused_compose_backward_matches_unfused(ext, dtype, sp):
     """ComposeFunction.backward (one splat kernel whose d_u sum starts from ds * grad) == autograd through
