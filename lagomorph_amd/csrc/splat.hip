@@ -619,13 +619,295 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Geometry-once form of the sheared-window splat for SEVERAL channels with d_u wanted (the reverse sweep of expmap
+// splats three-channel fields: 33 % of the 160^3 atlas step, profiles/r02_atlas160_kernel_stats.md).
+// splat_shear_kernel<..., VPL> recomputes a voxel's whole geometry per channel -- u re-read (1.54 x the algorithmic
+// HBM traffic), the float64 position of the non-unit step, floors, window addressing with two origin look-ups, the
+// gather offset: about 150 of its 245 vector instructions per voxel-channel.  Here the tile is covered by at most
+// VPL = 2 passes of the 1024-thread workgroup and each lane keeps, per voxel, across the channel loop:
+//   the two LDS byte addresses of its footprint's z cells (or NOWIN), the gather byte offset with the two z-border
+//   flags in its low bits (or NOROW), the three fractions, the voxel index and the three d_u sums
+// -- 10 registers per voxel.  Per channel what is left is: one grad_out load, the eight sequentially flipped weights,
+// eight float64 LDS adds, four pair gathers, the gradient expressions.  Voxels whose footprint leaves the window or
+// whose rows are clamped (well under 1 % of a smooth field) recompute their position from u per channel and take the
+// reference's clamped paths, as in splat_shear_kernel.  The flush re-zeroes the cells it reads, so a channel costs
+// two barriers instead of three.  Arithmetic per voxel and channel is that of splat_shear_kernel: d_u bit-identical.
+template <int NT, bool UNIT, bool BC, int VPL>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void splat_shear_mc_kernel(
+    float *__restrict__ d_I, float *__restrict__ d_u, const float *__restrict__ go, const float *__restrict__ I,
+    const float *__restrict__ u, double dt, int nc, ShearGeom sg, int umode, float addgo) {
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    double *win = reinterpret_cast<double *>(lago_smem);
+    int2 *org = reinterpret_cast<int2 *>(lago_smem + (size_t)sg.win_cells * 8);  // (x, y) origin per z segment
+    const int nx = sg.nx, ny = sg.ny, nz = sg.nz;
+    const uint32_t nv = (uint32_t)nx * ny * nz;
+    const uint32_t planeB = nv * 4u;
+    constexpr uint32_t NOWIN = 0xffffffffu, NOROW = 0xffffffffu, DEAD = 0xffffffffu;
+
+    // workgroup -> (batch item, tile)
+    const uint32_t L = xcd_swizzle(blockIdx.x, sg.total);
+    const uint32_t n = sg.d_tiles.div(L);
+    uint32_t r = L - n * sg.tiles_per_item;
+    const uint32_t bx = sg.d_tyz.div(r);
+    r -= bx * (sg.nty * sg.ntz);
+    const uint32_t by = sg.d_tz.div(r);
+    const uint32_t bz = r - by * sg.ntz;
+    const int x0 = bx * sg.TX, y0 = by * sg.TY, z0 = bz * sg.TZ;
+    const int ex = min(sg.TX, nx - x0), ey = min(sg.TY, ny - y0), ez = min(sg.TZ, nz - z0);
+
+    const float *un = u + (size_t)n * 3 * nv;
+    const float *In = BC ? I : I + (size_t)n * nc * nv;
+    float *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
+    const float *gon = go + (size_t)n * nc * nv;
+    float *dun = d_u + (size_t)n * 3 * nv;
+
+    const int WX = sg.WX, WY = sg.WY, WZ = sg.WZ;
+    const int wez = min(WZ, nz);
+    const int cxs = x0 + ex / 2, cys = y0 + ey / 2;
+    int wz0;
+    {
+        const float fdt = (float)dt;
+        const size_t sc = ((size_t)cxs * ny + cys) * nz + (z0 + ez / 2);
+        const int bzo = z0 + (int)floorf(fdt * un[sc + 2 * (size_t)nv]);
+        wz0 = max(0, min((bzo - sg.MZ) & ~15, nz - wez));
+    }
+    if ((int)threadIdx.x < sg.nseg) {
+        const float fdt = (float)dt;
+        const int zc = min(wz0 + (int)threadIdx.x * 16 + 8, nz - 1);
+        const size_t sc = ((size_t)cxs * ny + cys) * nz + zc;
+        int2 o;
+        o.x = max(-1, min(x0 + (int)floorf(fdt * un[sc]) - sg.MX, nx + 1 - WX));
+        o.y = max(-1, min(y0 + (int)floorf(fdt * un[sc + nv]) - sg.MY, ny + 1 - WY));
+        org[threadIdx.x] = o;
+    }
+    for (uint32_t f = threadIdx.x; f < sg.win_cells; f += NT) win[f] = 0.0;
+    __syncthreads();
+    const uint32_t sxB = (uint32_t)(WY * WZ) * 8u, syB = (uint32_t)WZ * 8u;            // window strides in bytes
+    const uint32_t gxB = (uint32_t)ny * nz * 4u, gyB = (uint32_t)nz * 4u;              // grid strides in bytes
+    const uint32_t wxu1 = (uint32_t)(WX - 1), wyu1 = (uint32_t)(WY - 1), wezu = (uint32_t)wez;
+
+    // ---- per-voxel geometry, once
+    uint32_t SV[VPL], A0[VPL], A1[VPL], OG[VPL];
+    float FT[VPL], FU[VPL], FV[VPL], rux[VPL], ruy[VPL], ruz[VPL];
+#pragma unroll
+    for (int it = 0; it < VPL; ++it) {
+        const uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+        const uint32_t a = sg.d_TyTz.div(tt);
+        const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
+        const uint32_t b = sg.d_Tz.div(rr);
+        const uint32_t kk = rr - b * (uint32_t)sg.TZ;
+        SV[it] = DEAD;
+        A0[it] = A1[it] = NOWIN;
+        OG[it] = NOROW;
+        FT[it] = FU[it] = FV[it] = rux[it] = ruy[it] = ruz[it] = 0.f;
+        if (tt >= sg.tile_vox || (int)a >= ex || (int)b >= ey || (int)kk >= ez) continue;
+        const int vi = x0 + a, vj = y0 + b, vk = z0 + kk;
+        const uint32_t sv = ((uint32_t)vi * ny + vj) * nz + vk;
+        SV[it] = sv;
+        const float hx = shear_pos<UNIT>(vi, dt, un[sv]);
+        const float hy = shear_pos<UNIT>(vj, dt, un[sv + nv]);
+        const float hz = shear_pos<UNIT>(vk, dt, un[sv + 2 * (size_t)nv]);
+        const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+        FT[it] = hx - (float)fx;
+        FU[it] = hy - (float)fy;
+        FV[it] = hz - (float)fz;
+        // the two z cells, clamped as the reference clamps them, and the window segment each falls in
+        const int cz0 = clamp1(fz, nz), cz1 = clamp1(fz + 1, nz);
+        const uint32_t lz0 = (uint32_t)(cz0 - wz0), lz1 = (uint32_t)(cz1 - wz0);
+        bool inwin = lz0 < wezu && lz1 < wezu;
+        int2 o0 = {0, 0}, o1 = {0, 0};
+        if (inwin) {
+            o0 = org[lz0 >> 4];
+            o1 = org[lz1 >> 4];
+        }
+        const uint32_t lx0 = (uint32_t)(fx - o0.x), ly0 = (uint32_t)(fy - o0.y);
+        const uint32_t lx1 = (uint32_t)(fx - o1.x), ly1 = (uint32_t)(fy - o1.y);
+        inwin = inwin && lx0 < wxu1 && ly0 < wyu1 && lx1 < wxu1 && ly1 < wyu1;
+        if (inwin) {
+            A0[it] = __umul24(lx0, sxB) + __umul24(ly0, syB) + lz0 * 8u;
+            A1[it] = __umul24(lx1, sxB) + __umul24(ly1, syB) + lz1 * 8u;
+        }
+        if ((uint32_t)fx < (uint32_t)(nx - 1) && (uint32_t)fy < (uint32_t)(ny - 1)) {
+            // rows unclamped; the z pair is fetched at zb = clamp(fz, 0, nz-2) and picked as Lerp3 does (common.hpp)
+            const int zb = lg_med3(fz, 0, nz - 2);
+            const uint32_t f_hi = fz > nz - 2 ? 1u : 0u, c_lo = fz < 0 ? 2u : 0u;
+            OG[it] = (__umul24((uint32_t)fx, gxB) + __umul24((uint32_t)fy, gyB) + (uint32_t)zb * 4u) | f_hi | c_lo;
+        }
+        if (umode == 1) {
+            rux[it] = dun[sv]; ruy[it] = dun[sv + nv]; ruz[it] = dun[sv + 2 * (size_t)nv];
+        } else if (umode == 2) {
+            rux[it] = addgo * gon[sv]; ruy[it] = addgo * gon[sv + nv]; ruz[it] = addgo * gon[sv + 2 * (size_t)nv];
+        }
+    }
+
+    // ---- channels.  What bounds these kernels is the number of DEPENDENT memory round trips inside a barrier-phased
+    // workgroup (two workgroups per CU), not instructions, LDS atomics or HBM bytes (profiles/r03_splat_latency.md):
+    //  * the next channel's grad_out values are requested before the barrier / flush / barrier of the current one;
+    //  * a channel's corner-pair gathers are all issued first (unconditional buffer loads: an out-of-range offset --
+    //    DEAD / NOROW are 0xffffffff -- returns 0; a load inside a branch would be waited for at the branch's join),
+    //    so that the weights and the LDS adds of every pass run under their latency;
+    //  * a footprint that leaves the window takes its clamped cells from the kept gather offset (no reload of u); only
+    //    samples whose rows are clamped -- positions outside the grid -- recompute their position.
+    float pgv[VPL];
+    auto request_gv = [&](int c) {
+        const BufRsrc rg = make_rsrc(gon + (size_t)c * nv, planeB);
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) pgv[it] = buf_load1<float>(rg, SV[it] == DEAD ? DEAD : SV[it] * 4u);
+    };
+    request_gv(0);
+    for (int c = 0; c < nc; ++c) {
+        const float *Ic = In + (size_t)c * nv;
+        const BufRsrc rdI = make_rsrc(dIn + (size_t)c * nv, planeB);
+        const BufRsrc rI = make_rsrc(Ic, planeB);
+        float gvs[VPL];
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) gvs[it] = pgv[it];
+        if (c + 1 < nc) request_gv(c + 1);
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            if (VPL > 1 && it) __builtin_amdgcn_sched_barrier(0);  // one pass after the other (register pressure)
+            // the kept geometry is made opaque once per channel: otherwise everything derived from it (eight window
+            // addresses, four gather offsets, 1 - t ..., per voxel) is hoisted out of the channel loop into registers
+            // (111 VGPRs instead of 64: one workgroup per CU)
+            asm volatile("" : "+v"(A0[it]), "+v"(A1[it]), "+v"(OG[it]), "+v"(FT[it]), "+v"(FU[it]), "+v"(FV[it]), "+v"(SV[it]));
+            unsigned long long pq[4];   // the four corner pairs: rows (fx,fy) (fx+1,fy) (fx+1,fy+1) (fx,fy+1)
+            {
+                const uint32_t o = OG[it] & ~3u;
+                pq[0] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, 0u, 0));
+                pq[1] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, gxB, 0));
+                pq[2] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, gxB + gyB, 0));
+                pq[3] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, gyB, 0));
+            }
+            const uint32_t sv = SV[it];
+            const float gv = gvs[it];
+            if (sv == DEAD) continue;
+            const float omt = 1.f - FT[it], omu = 1.f - FU[it], omv = 1.f - FV[it];
+            // sequentially flipped weights (include/interp.h:431-453): x outer, y, z inner
+            float wq[8];
+            {
+                float ddx = omt, ddy = omu, ddz = omv;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    wq[q] = (ddx * ddy * ddz) * gv;
+                    ddz = 1.f - ddz;
+                    if (q & 1) ddy = 1.f - ddy;
+                    if ((q & 3) == 3) ddx = 1.f - ddx;
+                }
+            }
+            const uint32_t a0 = A0[it], a1 = A1[it];
+            if (a0 != NOWIN) {
+                lds_add(reinterpret_cast<double *>(lago_smem + a0), (double)wq[0]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1), (double)wq[1]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + syB), (double)wq[2]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + syB), (double)wq[3]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + sxB), (double)wq[4]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + sxB), (double)wq[5]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + sxB + syB), (double)wq[6]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + sxB + syB), (double)wq[7]);
+            } else {
+                // beyond the window: the reference's clamped global atomics (include/interp.h:330-401, :431-453)
+                uint32_t X0, X1, Y0, Y1, Z0, Z1;
+                if (OG[it] != NOROW) {
+                    // rows unclamped: the cells follow from the gather offset (fx, fy, zb) and its z-border flags
+                    const uint32_t o = OG[it] & ~3u;
+                    X0 = o; X1 = o + gxB; Y0 = 0u; Y1 = gyB;
+                    Z0 = (OG[it] & 1u) ? 4u : 0u;              // floor beyond the upper face: both cells are nz - 1 = zb + 1
+                    Z1 = (OG[it] & 2u) ? 0u : 4u;              // floor below the lower face: both cells are 0 = zb
+                } else {
+                    const uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+                    const uint32_t a = sg.d_TyTz.div(tt);
+                    const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
+                    const uint32_t b = sg.d_Tz.div(rr);
+                    const uint32_t kk = rr - b * (uint32_t)sg.TZ;
+                    const int fx = lg_floor(shear_pos<UNIT>(x0 + (int)a, dt, un[sv]));
+                    const int fy = lg_floor(shear_pos<UNIT>(y0 + (int)b, dt, un[sv + nv]));
+                    const int fz = lg_floor(shear_pos<UNIT>(z0 + (int)kk, dt, un[sv + 2 * (size_t)nv]));
+                    X0 = __umul24((uint32_t)clamp1(fx, nx), gxB); X1 = __umul24((uint32_t)clamp1(fx + 1, nx), gxB);
+                    Y0 = __umul24((uint32_t)clamp1(fy, ny), gyB); Y1 = __umul24((uint32_t)clamp1(fy + 1, ny), gyB);
+                    Z0 = (uint32_t)clamp1(fz, nz) * 4u; Z1 = (uint32_t)clamp1(fz + 1, nz) * 4u;
+                }
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[0], rdI, X0 + Y0 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[1], rdI, X0 + Y0 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[2], rdI, X0 + Y1 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[3], rdI, X0 + Y1 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[4], rdI, X1 + Y0 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[5], rdI, X1 + Y0 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[6], rdI, X1 + Y1 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[7], rdI, X1 + Y1 + Z1, 0, 0);
+            }
+            const float t = FT[it], uu = FU[it], v = FV[it];
+            float gx, gy, gz;
+            if (OG[it] != NOROW) {
+                const bool f_hi = OG[it] & 1u, c_lo = OG[it] & 2u;
+                auto lo = [](unsigned long long x) { return __builtin_bit_cast(float, (unsigned int)x); };
+                auto hi = [](unsigned long long x) { return __builtin_bit_cast(float, (unsigned int)(x >> 32)); };
+                const float l0 = lo(pq[0]), l1 = lo(pq[1]), l2 = lo(pq[2]), l3 = lo(pq[3]);
+                const float h0 = hi(pq[0]), h1 = hi(pq[1]), h2 = hi(pq[2]), h3 = hi(pq[3]);
+                const float c0 = f_hi ? h0 : l0, c1 = f_hi ? h1 : l1, c2 = f_hi ? h2 : l2, c3 = f_hi ? h3 : l3;
+                const float c4 = c_lo ? l0 : h0, c5 = c_lo ? l1 : h1, c6 = c_lo ? l2 : h2, c7 = c_lo ? l3 : h3;
+                // include/interp.h:315-326
+                gx = lg_fma(omv, lg_fma(omu, c1 - c0, uu * (c2 - c3)), v * lg_fma(omu, c5 - c4, uu * (c6 - c7)));
+                gy = lg_fma(omv, lg_fma(omt, c3 - c0, t * (c2 - c1)), v * lg_fma(omt, c7 - c4, t * (c6 - c5)));
+                gz = lg_fma(omu, lg_fma(omt, c4 - c0, t * (c5 - c1)), uu * lg_fma(omt, c7 - c3, t * (c6 - c2)));
+            } else {  // rows clamped (a sample outside the grid): position again, same expressions, same bits
+                const uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+                const uint32_t a = sg.d_TyTz.div(tt);
+                const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
+                const uint32_t b = sg.d_Tz.div(rr);
+                const uint32_t kk = rr - b * (uint32_t)sg.TZ;
+                Lerp3<float, false> Lq;
+                Lq.setup(shear_pos<UNIT>(x0 + (int)a, dt, un[sv]), shear_pos<UNIT>(y0 + (int)b, dt, un[sv + nv]),
+                         shear_pos<UNIT>(z0 + (int)kk, dt, un[sv + 2 * (size_t)nv]), nx, ny, nz);
+                Lq.grad(Ic, gx, gy, gz);
+            }
+            // cuda/interp.cu:230: (Real)((double)diff * dt); for dt = +-1 that is +-diff exactly
+            const float diff = UNIT ? (float)dt * gv : (float)((double)gv * dt);
+            rux[it] = lg_fma(gx, diff, rux[it]);   // ascending channel order, as the reference's thread-owned sum
+            ruy[it] = lg_fma(gy, diff, ruy[it]);
+            ruz[it] = lg_fma(gz, diff, ruz[it]);
+        }
+        __syncthreads();
+        // flush touched cells (one wave per window row, lanes along z) and re-zero them for the next channel
+        {
+            const int lane = threadIdx.x & 63;
+            const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const uint32_t nrows = (uint32_t)(WX * WY);
+            for (uint32_t row = wave; row < nrows; row += NT / 64) {
+                const uint32_t lx = sg.d_wy.div(row), ly = row - lx * (uint32_t)WY;
+                double *wrow = win + row * (uint32_t)WZ;
+                for (int lz = lane; lz < wez; lz += 64) {
+                    const double acc = wrow[lz];
+                    if (acc != 0.0) {
+                        wrow[lz] = 0.0;
+                        const int2 o = org[lz >> 4];
+                        const uint32_t off = __umul24((uint32_t)clamp1(o.x + (int)lx, nx), gxB) +
+                                             __umul24((uint32_t)clamp1(o.y + (int)ly, ny), gyB) + (uint32_t)(wz0 + lz) * 4u;
+                        (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((float)acc, rdI, off, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < VPL; ++it)
+        if (SV[it] != DEAD) {
+            dun[SV[it]] = rux[it]; dun[SV[it] + nv] = ruy[it]; dun[SV[it] + 2 * (size_t)nv] = ruz[it];
+        }
+}
+
 // TX TY TZ(0 = auto) margins MX MY MZ.  TX is an upper bound: make_shear shrinks it until the float64 window fits
 // 80 KB (8 x 6 -> 5 x 6 x 128 at nz = 128, 8 x 6 x 80 at nz = 160: 3840-voxel tiles).  Measured against 4 x 8
 // (tools/ab_tiles.py, steady state): 1-3 % faster at 128^3 and 160^3, one and three channels.
 static KnobArray<6> g_shear_cfg({8, 6, 0, 1, 1, 4});
-static std::atomic<int> g_shear_nt{1024}, g_shear_on{1}, g_shear_mc{1};
+// g_shear_mc, several channels with d_u wanted: 0 d_u read-modify-written per channel, 1 d_u in registers over the
+// channels (splat_shear_kernel<..., VPL>), 2 (default) the geometry-once kernel (splat_shear_mc_kernel)
+static std::atomic<int> g_shear_nt{1024}, g_shear_on{1}, g_shear_mc{2};
 
-static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem) {
+// max_vox > 0 (the geometry-once multi-channel kernel): the tile is shrunk further, larger of TX / TY first, until it
+// has at most that many voxels.
+static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem, int max_vox = 0) {
     const std::array<int, 6> cfg = g_shear_cfg.get();
     int TX = cfg[0], TY = cfg[1], TZ = cfg[2];
     const int EX = cfg[3], EY = cfg[4], EZ = cfg[5];
@@ -645,8 +927,15 @@ static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem) {
         sg.WZ = TZ >= g.nz ? g.nz : ((TZ + 1 + 2 * EZ + 15 + 15) / 16) * 16;
         if (sg.WZ > g.nz) sg.WZ = g.nz;
         sg.nseg = (sg.WZ + 15) / 16;
-        if ((uint64_t)sg.WX * sg.WY * sg.WZ * 8 + (uint64_t)sg.nseg * 8 <= 80 * 1024) break;  // two workgroups per CU
-        if (TX > 2) --TX;
+        const bool fits = (uint64_t)sg.WX * sg.WY * sg.WZ * 8 + (uint64_t)sg.nseg * 8 <= 80 * 1024;  // two workgroups per CU
+        if (fits && (max_vox <= 0 || (int64_t)TX * TY * TZ <= max_vox)) break;
+        if (max_vox > 0) {
+            if (TX >= TY && TX > 1) --TX;
+            else if (TY > 1) --TY;
+            else if (TX > 1) --TX;
+            else if (TZ > 16) TZ = ((TZ / 2 + 15) / 16) * 16;
+            else return false;
+        } else if (TX > 2) --TX;
         else if (TY > 2) --TY;
         else if (TZ > 16) TZ = ((TZ / 2 + 15) / 16) * 16;
         else return false;
@@ -712,9 +1001,32 @@ static int interp_backward_shear(float *d_I, float *d_u, const float *go, const 
     if (!g_shear_on) return 1;
     ShearGeom sg;
     size_t smem;
-    if (!make_shear(sg, g, nn, smem)) return 1;
     hipError_t e;
     const int shear_nt = g_shear_nt;
+    // the geometry-once kernel pays for non-unit steps (the float64 position and the re-read of u per channel are what
+    // it removes: -7 ... -12 %); with a unit step it measures within +-3 % of splat_shear_kernel<..., VPL>, whose
+    // larger tiles flush fewer cells -- mode 3 forces it for every step (tests, tools/ab_shear_mc.py)
+    const bool unit_step = unit_dt<float>(dt);
+    if (need_u && nc > 1 && (g_shear_mc >= 3 || (g_shear_mc == 2 && !unit_step)) && shear_nt >= 1024 &&
+        make_shear(sg, g, nn, smem, 2048)) {
+        const bool unit = unit_step;
+        const bool one = sg.tile_vox <= 1024u;
+#define LAGO_SHEAR_MC(UN, B)                                                                                      \
+    do {                                                                                                          \
+        auto k = one ? splat_shear_mc_kernel<1024, UN, B, 1> : splat_shear_mc_kernel<1024, UN, B, 2>;             \
+        if (smem > 64 * 1024) {                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)smem);                                                                   \
+            if (e != hipSuccess) return fail_hip(e, "interp_backward (sheared-window splat)");                    \
+        }                                                                                                         \
+        hipLaunchKernelGGL(k, dim3(sg.total), dim3(1024), smem, s, d_I, d_u, go, I, u, dt, nc, sg, umode, addgo);  \
+    } while (0)
+        if (unit) { if (bc) LAGO_SHEAR_MC(true, true); else LAGO_SHEAR_MC(true, false); }
+        else { if (bc) LAGO_SHEAR_MC(false, true); else LAGO_SHEAR_MC(false, false); }
+#undef LAGO_SHEAR_MC
+        return finish_launch(s, "interp_backward (sheared-window splat)");
+    }
+    if (!make_shear(sg, g, nn, smem)) return 1;
     if (shear_nt >= 1024) e = launch_shear<1024>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
     else if (shear_nt >= 512) e = launch_shear<512>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
     else e = launch_shear<256>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
@@ -945,7 +1257,7 @@ extern "C" {
 // Affects speed only, never results.
 void lago_set_splat_mc(int on) { lago::g_splat_mc = on; }
 // sheared-window float32 splat: on/off, tile TX TY TZ (0 = auto), margins, threads per workgroup.  Speed only.
-void lago_set_splat_shear_mc(int on) { lago::g_shear_mc = on; }
+void lago_set_splat_shear_mc(int mode) { lago::g_shear_mc = mode; }
 void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
     lago::g_shear_on = on;
     lago::g_shear_cfg.set({tx, ty, tz, mx, my, mz});

@@ -42,23 +42,23 @@ inline bool make_row_tile(RowTile &t, const Geom &g, int64_t nn, int cap, int nt
     if (g.nz < 2 || g.nx < 2 || g.ny < 2) return false;
     const int rows = cap / g.nz;
     if (rows < 4) return false;
+    const int waves = nthreads / 64;
     int bx = 0, by = 0;
     double best = 1e30;
     for (int tx = 2; tx <= rows && tx <= g.nx; ++tx) {
-        int ty = rows / tx;
-        if (ty > g.ny) ty = g.ny;
-        if (ty < 2) break;
-        // halo rows per tile row, plus the lanes a partly filled workgroup leaves idle
-        const double cost = (2.0 * tx + 2.0 * ty) / (tx * ty) + 4.0 * (1.0 - (double)tx * ty * g.nz / cap);
-        if (cost < best) { best = cost; bx = tx; by = ty; }
+        for (int ty = 2; ty <= rows / tx && ty <= g.ny; ++ty) {
+            // the loader's compile-time bound on halo rows per wave
+            if ((int)(((2 * tx + 2 * ty) * nplanes + waves - 1) / waves) > max_halo_rows_per_wave) continue;
+            // halo rows per tile row, plus the lanes a partly filled workgroup leaves idle
+            const double cost = (2.0 * tx + 2.0 * ty) / (tx * ty) + 4.0 * (1.0 - (double)tx * ty * g.nz / cap);
+            if (cost < best) { best = cost; bx = tx; by = ty; }
+        }
     }
-    if (!bx) return false;
+    if (!bx || (int64_t)bx * by * g.nz * 2 < cap) return false;  // short rows: a workgroup would be half empty
     t.TX = bx; t.TY = by;
     t.RY = by + 2;
     t.P = g.nz + 2;
     t.nhrows = 2u * by + 2u * bx;
-    const int waves = nthreads / 64;
-    if ((int)((t.nhrows * nplanes + waves - 1) / waves) > max_halo_rows_per_wave) return false;
     t.plane = (uint32_t)(bx + 2) * t.RY * t.P;
     smem = (size_t)t.plane * nplanes * esize;
     if (smem > 64 * 1024) return false;

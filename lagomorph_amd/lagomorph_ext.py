@@ -168,9 +168,10 @@ def set_splat_mc(on):
     _lib.lago_set_splat_mc(1 if on else 0)
 
 
-def set_splat_shear_mc(on):
-    """Sheared-window splat: 1 (default) keeps d_u in registers over the channels.  Speed only."""
-    _lib.lago_set_splat_shear_mc(1 if on else 0)
+def set_splat_shear_mc(mode):
+    """Sheared-window splat, several channels with d_u: 3 geometry and d_u sums in registers over the channels,
+    2 (default) that form for non-unit steps only, 1 the d_u sums only, 0 neither.  Speed only (same d_u bits)."""
+    _lib.lago_set_splat_shear_mc(int(mode))
 
 
 def set_fluid_tuning(xpass_ipw=0, zy_persist=1, xpass_wide=1):

@@ -703,7 +703,7 @@ def test_ad_star_saves_the_resampled_momentum(ext, dtype, sp):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("sp", [(16, 16, 16), (20, 12, 40), (9, 11, 33), (5, 37, 128), (33, 6, 160), (7, 5, 250), (18, 17, 2)])
+@pytest.mark.parametrize("sp", [(16, 16, 16), (20, 12, 40), (9, 11, 70), (5, 37, 128), (33, 6, 160), (7, 5, 250), (18, 17, 2), (3, 2, 256)])
 def test_ad_star_row_tile_kernel(ext, dtype, sp):
     """The LDS row-tile form of Ad_star (csrc/stencil_tile.hpp: stencil neighbours from a staged tile with a
     one-voxel halo) against the oracle's interp + jacobian_times_vectorfield, bit for bit, and against the direct
