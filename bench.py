@@ -143,12 +143,13 @@ def micro_interp_splat(ext, dev, size, batch=8):
         r["pair_Gvoxel_per_s"] = V / pair / 1e6
         res[label] = r
     # HBM bytes per launch of the two kernels from the PMC passes over tools/run_micro.py (same workload, same batch)
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic_micro.json")
-    if os.path.exists(tpath) and size == 128 and batch == 8:
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic_micro.json", "r02_traffic_micro.json"))
+                  if os.path.exists(q)), "")
+    if tpath and size == 128 and batch == 8:
         t = json.load(open(tpath))
         pick = lambda prefix: next((rec["traffic_bytes"] for name, rec in t.items() if name.startswith(prefix)), None)
         res["traffic"] = {
-            "source": "profiles/r02_traffic_micro.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, tools/run_micro.py)",
+            "source": f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, tools/run_micro.py)",
             "interp_forward": {"kernel": "interp_fwd3_unroll_kernel<float,false,2,true>", "bytes": pick("lago::interp_fwd3_unroll_kernel<float, false"),
                                "algorithmic_bytes": 20.0 * V},
             "interp_backward": {"kernel": "splat_shear_kernel<1024,true,true,false,0>", "bytes": pick("lago::splat_shear_kernel<1024, true, true, false, 0>"),
@@ -620,7 +621,7 @@ def main():
         # the dominant single kernel of the timed region (fluid_metric is three kernels and is reported
         # separately): all four candidates move 36 algorithmic bytes per voxel at C = 3
         cands = {
-            "Ad_star": ("ad_star3_unroll_kernel<float,2>", "lago::ad_star3_unroll_kernel<float"),
+            "Ad_star": ("ad_star3_tile_kernel<float,512,2,5,2>", "lago::ad_star3_tile_kernel<float"),
             "compose": ("compose3_unroll_kernel<float,2,false>", "lago::compose3_unroll_kernel<float"),
             "interp_forward": ("interp_fwd3_unroll_kernel<float,false,2,true> (C=3)", "lago::interp_fwd3_unroll_kernel<float"),
             "jacobian_times_vectorfield_forward": ("jtv_fwd_kernel<float,3,true,false>", "lago::jtv_fwd_kernel<float, 3, true"),
@@ -634,7 +635,7 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
             # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
             traffic, tsrc = None, None
-            for tname in ("r02_traffic_expmap.json", "r01_traffic.json"):
+            for tname in ("r03_traffic_expmap.json", "r02_traffic_expmap.json", "r01_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and B == 32 and S == 128:
                     for name, rec in json.load(open(tpath)).items():

@@ -28,6 +28,9 @@ for _ in range(5):
     ext.interp_forward(I, u, 1.0)                                  # interp_fwd3_unroll_kernel<float,false,2,true>, C = 1
     ext.interp_backward(go, I, u, 1.0, True, True)                 # splat_shear_kernel<1024,true,true,false,0>
     ext.interp_backward(g3, v3, u, 1.0, True, True)                # splat_shear_kernel<..., 4>: C = 3, d_u in registers
+    ext.interp_backward(g3, v3, u, -0.2, True, True)               # splat_shear_mc_kernel<1024,false,false,2>: non-unit step
+    ext.Ad_star(u, v3)                                             # ad_star3_tile_kernel
+    ext.compose(u, v3, -0.1, 1.0)
     ext.jacobian_times_vectorfield_backward(g3, v3, u, True, False, True, True)
     ext.jacobian_times_vectorfield_forward(v3, u, True, False)
     ext.affine_interp_forward(I, A, T)
