@@ -19,7 +19,7 @@ if not _BUILDING:
     from .diff import (JacobianTimesVectorFieldAdjointFunction, JacobianTimesVectorFieldFunction,  # noqa: F401
                        jacobian_times_vectorfield, jacobian_times_vectorfield_adjoint)
     from .lagomorph_ext import set_debug_mode  # noqa: F401
-    from .lddmm import EPDiff_step, LDDMMAtlasBuilder, expmap, expmap_advect, lddmm_step  # noqa: F401
+    from .lddmm import EPDiff_step, LDDMMAtlasBuilder, expmap, expmap_advect, lddmm_step, shard_indices  # noqa: F401
     from .metric import FluidMetric, FluidMetricOperator, Metric  # noqa: F401
 
     __version__ = "0.1.0"

@@ -289,13 +289,27 @@ def streaming_batch_average(images, batch_size):
     return avg
 
 
+def shard_indices(n, world_size, rank, shuffle=True, seed=0, epoch=0):
+    """The subjects rank `rank` of `world_size` works on, exactly as the reference assigns them (lddmm.py:164-167:
+    `DistributedSampler(dataset, num_replicas=world_size, rank=rank)` with its defaults and `set_epoch` never called):
+    a seed-0 permutation of range(n), PADDED by wrapping around to a multiple of world_size (so every rank holds the
+    same number of subjects, hence of minibatches -- a few subjects are then seen by two ranks), dealt round-robin.
+    torch's own sampler is used, so the assignment is the reference's by construction.  shuffle=False gives the
+    unshuffled variant of the same padding rule."""
+    from torch.utils.data.distributed import DistributedSampler
+
+    sampler = DistributedSampler(range(n), num_replicas=world_size, rank=rank, shuffle=shuffle, seed=seed)
+    sampler.set_epoch(epoch)
+    return list(iter(sampler))
+
+
 class LDDMMAtlasBuilder:
     """Batch-sharded atlas building over in-memory volumes (lddmm.py:108-375, compute path only).
 
     Each rank owns a contiguous shard of the subjects and of their momenta, both resident in HBM
     (the reference parks momenta in pinned host memory and copies them every iteration,
-    lddmm.py:236,328,337).  Every rank must hold the same number of minibatches (the reference's
-    DistributedSampler pads the shards to equal length for the same reason).
+    lddmm.py:236,328,337).  Every rank must hold the same number of minibatches: `from_dataset` builds the shard
+    with the reference's DistributedSampler rule (padded, equal-length shards; `shard_indices`).
 
     Collectives -- the atlas gradient only, as lddmm.py:292-297 prescribes:
       * ONE SUM all-reduce of `I.grad` (1, 1, *image_shape) per image update.  It is issued
@@ -367,6 +381,22 @@ class LDDMMAtlasBuilder:
         self._reduce_now = False   # set by iteration(): the hook should start the reduction
         self._work = None          # outstanding all-reduce of I.grad
         self._hook = self.I.register_post_accumulate_grad_hook(self._on_image_grad)
+
+    @classmethod
+    def from_dataset(cls, images, world_size=1, rank=0, device=None, shuffle=True, **kw):
+        """The builder of rank `rank` over the WHOLE dataset `images` (n, 1, *sp), sharded as the reference shards it
+        (`shard_indices`: the padded DistributedSampler assignment of lddmm.py:164-167).  `dataset_size` is the
+        unpadded n, as the reference's `len(dataloader.dataset)` (lddmm.py:320-323).  The rank's subjects are moved to
+        `device` (default: where `images` lives); `builder.subject_indices` records which ones they are."""
+        n = images.shape[0]
+        idx = shard_indices(n, world_size, rank, shuffle=shuffle) if world_size > 1 else list(range(n))
+        shard = images[torch.as_tensor(idx, dtype=torch.long, device=images.device)]
+        if device is not None:
+            shard = shard.to(device)
+        kw.setdefault("dataset_size", n)
+        b = cls(shard.contiguous(), world_size=world_size, rank=rank, **kw)
+        b.subject_indices = idx
+        return b
 
     # ---- atlas gradient all-reduce -------------------------------------------------------
 
