@@ -38,6 +38,10 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
                         int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s);
 int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int64_t nx, int64_t ny, int64_t nzc,
                        double scale, hipStream_t s);
+bool fluid2d_supported(int64_t h, int64_t w);
+int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, const float *sinX, const float *cosY,
+                    const float *sinY, double alpha, double beta, double gamma, int64_t nn, int64_t h, int64_t w,
+                    hipStream_t s);
 // 0: rocFFT 3D plan + operator kernel; 1: rocFFT 2D (y, z) plan + fused x pass (fftx.hip);
 // 2: three LDS-tiled passes, no rocFFT (fft3.hip).  Each falls back to the previous one where the
 // shape is not supported.
@@ -180,6 +184,11 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
         return fail_invalid("fluid_metric: bad extent");
     if (nn == 0) return LAGO_OK;
     if (!out || !m || !work) return fail_invalid("fluid_metric: null pointer");
+    // 2D float32 fields whose two component planes fit the LDS together: one kernel for the whole operator (fft3.hip)
+    if (sizeof(R) == 4 && dim == 2 && g_fluid_xpass >= 2 && fluid2d_supported(nx, ny) && nn < (1ll << 31) &&
+        (((uintptr_t)out | (uintptr_t)m) & 15) == 0)
+        return fluid_metric_2d((float *)out, (const float *)m, inverse, (const float *)cosX, (const float *)sinX,
+                               (const float *)cosY, (const float *)sinY, alpha, beta, gamma, nn, nx, ny, (hipStream_t)stream);
     // the table-based fast paths need a LUT generation to key their cached coefficient table on
     if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass >= 2 && fluid_native_supported(nx, ny, nz) &&
         (((uintptr_t)out | (uintptr_t)m | (uintptr_t)work) & 15) == 0) {  // 16-byte vector accesses

@@ -108,6 +108,150 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
     }
 }
 
+template <typename Kern>
+static hipError_t allow_smem(Kern k, size_t smem) {
+    if (smem <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem);
+}
+
+// ---- 2D fields: the whole FluidMetricOperator.forward (metric.py:11-19) of one batch item in ONE kernel ----------
+// Both component planes of an (H, W) field fit the LDS together up to about 128 x 128 (2 x 66.5 KB): real 2D
+// transform of both (the zy phases above, H along "y", W along "z"), the reference's 2 x 2 operator per frequency
+// (fluid_kernel_2d, cuda/metric.cu:162-218: the expressions and roundings of metric.hip, coefficients straight from
+// the cos / sin LUTs), inverse transform, store: 8 bytes of HBM traffic per value instead of the 28 of
+// rocFFT R2C + operator kernel + rocFFT C2R (and three launches less).
+template <typename R>
+__device__ __forceinline__ R fl2d_safe_sqrt(R x) {  // cuda/metric.cu:14-18
+    if ((double)x < 1e-8) return (R)1e-4;
+    return (R)sqrtf((float)x);
+}
+
+template <int NY, int NZ, bool INV>
+__global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void fluid2d_kernel(float *__restrict__ out, const float *__restrict__ m,
+                                                                       const float *__restrict__ cosX, const float *__restrict__ sinX,
+                                                                       const float *__restrict__ cosY, const float *__restrict__ sinY,
+                                                                       double alpha, double beta, double gamma, float scale) {
+    using K = ZYK<NY, NZ>;
+    using SY = typename SzOf<NY>::T;
+    using SZH = typename SzOf<NZ / 2>::T;
+    constexpr int NT = K::THREADS, PZ = K::PZ, NZH = K::NZH;
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    float2 *P0 = reinterpret_cast<float2 *>(lago_smem), *P1 = P0 + NY * PZ, *tw = P1 + NY * PZ;
+    const size_t n = blockIdx.x;
+    const float *in0 = m + n * 2 * (size_t)(NY * NZ), *in1 = in0 + (size_t)(NY * NZ);
+    float *out0 = out + n * 2 * (size_t)(NY * NZ), *out1 = out0 + (size_t)(NY * NZ);
+    // forward transform of both planes, up to and including the unpack phase (the store phase is not needed)
+#pragma unroll
+    for (int ph = 0; ph < K::NPH - 1; ++ph) {
+        K::fwd_phase(ph, threadIdx.x, in0, nullptr, nullptr, P0, tw);
+        K::fwd_phase(ph, threadIdx.x, in1, nullptr, nullptr, P1, tw);
+        __syncthreads();
+    }
+    // operator: bin (kx, ky) of the half spectrum sits at row pos_of(kx), column pos_of(ky) (ky = NZH: the spare column)
+    for (int w = threadIdx.x; w < NY * (NZH + 1); w += NT) {
+        const int kx = w / (NZH + 1), ky = w - kx * (NZH + 1);
+        const int at = fl::pos_of<SY>(kx) * PZ + (ky == NZH ? NZH : fl::pos_of<SZH>(ky));
+        const float wx = cosX[kx], wy = cosY[ky];
+        const float lambda = (float)__builtin_fma(alpha, (double)(wx + wy), gamma);
+        const float l00 = (float)__builtin_fma(-beta, (double)wx, (double)lambda);
+        const float l11 = (float)__builtin_fma(-beta, (double)wy, (double)lambda);
+        const float l10 = (float)(beta * (double)sinX[kx] * (double)sinY[ky]);
+        const float L00 = lg_fma(l00, l00, l10 * l10);
+        const float L10 = lg_fma(l00, l10, l10 * l11);
+        const float L11 = lg_fma(l11, l11, l10 * l10);
+        float ooG00 = 0, G10 = 0, ooG11 = 0;
+        if (INV) {  // cuda/metric.cu:20-45
+            ooG00 = (float)(1. / (double)fl2d_safe_sqrt(L00));
+            G10 = L10 * ooG00;
+            ooG11 = lg_fma(-G10, G10, L11);
+            ooG11 = (float)(1. / (double)fl2d_safe_sqrt(ooG11));
+        }
+        const float2 a = P0[at], b = P1[at];
+        float X[2] = {a.x, a.y}, Y[2] = {b.x, b.y};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float bX = X[q], bY = Y[q];
+            if (INV) {  // cuda/metric.cu:80-101
+                const float y0 = bX * ooG00;
+                const float y1 = lg_fma(-G10, y0, bY) * ooG11;
+                bY = y1 * ooG11;
+                bX = lg_fma(-G10, bY, y0) * ooG00;
+            } else {  // cuda/metric.cu:132-143
+                const float x = lg_fma(L00, bX, L10 * bY);
+                bY = lg_fma(L10, bX, L11 * bY);
+                bX = x;
+            }
+            X[q] = bX * scale; Y[q] = bY * scale;
+        }
+        P0[at] = make_float2(X[0], X[1]);
+        P1[at] = make_float2(Y[0], Y[1]);
+    }
+    __syncthreads();
+    // what inv_fill does to column 0: FA + i FB (FB = the Nyquist column), so that the inverse y transform returns
+    // (X[0](y), X[NZH](y)) in one complex column
+    for (int kx = threadIdx.x; kx < 2 * NY; kx += NT) {
+        float2 *row = (kx < NY ? P0 : P1) + fl::pos_of<SY>(kx < NY ? kx : kx - NY) * PZ;
+        const float2 fa = row[0], fb = row[NZH];
+        row[0] = make_float2(fa.x - fb.y, fa.y + fb.x);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ph = 1; ph < K::NPH_INV; ++ph) {
+        K::inv_phase(ph, threadIdx.x, out0, nullptr, nullptr, P0, tw);
+        K::inv_phase(ph, threadIdx.x, out1, nullptr, nullptr, P1, tw);
+        if (ph + 1 < K::NPH_INV) __syncthreads();
+    }
+}
+
+// (H, W) the fused 2D kernel is instantiated for: both planes + the twiddle table within 160 KB of LDS
+#define LAGO_2D_SHAPES(X)                                                                                   \
+    X(64, 64) X(64, 96) X(64, 128) X(96, 64) X(96, 96) X(96, 128) X(128, 64) X(128, 96) X(128, 128)        \
+    X(32, 64) X(32, 128) X(160, 64) X(160, 96) X(192, 64) X(192, 96) X(256, 64) X(64, 160) X(96, 160)       \
+    X(64, 192) X(96, 192) X(64, 256)
+
+bool fluid2d_supported(int64_t h, int64_t w) {
+    bool ok = false;
+#define X(H, W) ok = ok || (h == H && w == W);
+    LAGO_2D_SHAPES(X)
+#undef X
+    return ok;
+}
+
+template <int NY, int NZ>
+static hipError_t fluid2d_launch(float *out, const float *m, int inverse, const float *cosX, const float *sinX,
+                                 const float *cosY, const float *sinY, double alpha, double beta, double gamma,
+                                 int64_t nn, hipStream_t s) {
+    using K = ZYK<NY, NZ>;
+    constexpr size_t smem = (size_t)(2 * NY * K::PZ + K::LTW) * sizeof(float2);
+    static_assert(smem <= 160 * 1024, "two planes do not fit the LDS");
+    const float scale = (float)(1.0 / ((double)NY * (double)NZ));
+    if (inverse) {
+        auto k = fluid2d_kernel<NY, NZ, true>;
+        hipError_t e = allow_smem(k, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((uint32_t)nn), dim3(K::THREADS), smem, s, out, m, cosX, sinX, cosY, sinY, alpha, beta, gamma, scale);
+    } else {
+        auto k = fluid2d_kernel<NY, NZ, false>;
+        hipError_t e = allow_smem(k, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((uint32_t)nn), dim3(K::THREADS), smem, s, out, m, cosX, sinX, cosY, sinY, alpha, beta, gamma, scale);
+    }
+    return hipSuccess;
+}
+
+int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, const float *sinX, const float *cosY,
+                    const float *sinY, double alpha, double beta, double gamma, int64_t nn, int64_t h, int64_t w,
+                    hipStream_t s) {
+    hipError_t e = hipErrorInvalidValue;
+#define X(H, W) \
+    if (h == H && w == W) e = fluid2d_launch<H, W>(out, m, inverse, cosX, sinX, cosY, sinY, alpha, beta, gamma, nn, s);
+    LAGO_2D_SHAPES(X)
+#undef X
+    if (e != hipSuccess) return fail_hip(e, "fluid_metric (2D)");
+    return finish_launch(s, "fluid_metric");
+}
+
 // threads per x-pass workgroup: 256, except for the 256-point tile (104 KB: one workgroup per CU, which 512 threads
 // serve 12 % faster).  Measured (tools/ab_fluid.py): wider workgroups LOSE 3-14 % at 128, 160 and 192 points, where
 // two or three 256-thread workgroups share a CU and their 120+ VGPRs per thread would cost the second one.
@@ -159,13 +303,6 @@ bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz) {
 }
 
 std::atomic<int> g_zy_persist{1};  // 1: persistent prefetching zy kernels for planes above 80 KB of LDS
-
-template <typename Kern>
-static hipError_t allow_smem(Kern k, size_t smem) {
-    if (smem <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem);
-}
 
 template <int NY, int NZ>
 static hipError_t zy_launch(const fl::ZYArgs &a, bool inverse, hipStream_t s) {
