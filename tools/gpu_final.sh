@@ -7,5 +7,7 @@ if [ "$1" != "nobench" ]; then
 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; echo "bench exit $?"
 python bench.py --batch 8 --atlas-batch 8 --no-micro --no-cpu-baseline > gpurun_out/r03_bench_b8.json 2>/dev/null
 python bench.py --batch 4 --atlas-batch 4 --no-micro --no-cpu-baseline > gpurun_out/r03_bench_b4.json 2>/dev/null
+# the N-rank code path (spawned ranks, barriers, the all-reduce hook, max over ranks) on ONE GPU over gloo: a plumbing check
+LAGO_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 2 --warmup 1 --atlas-steps 2 --no-micro --no-cpu-baseline > gpurun_out/r03_bench_share2.json 2> gpurun_out/r03_bench_share2.err; echo "share-gpu 2-rank bench exit $?"
 fi
 tail -3 gpurun_out/r03_pytest.log; tail -2 gpurun_out/r03_smoke.log
