@@ -14,6 +14,8 @@
 
 #include <string.h>
 
+#include <cmath>
+
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -75,6 +77,7 @@ static const size_t kCoefCacheBytes = (size_t)1 << 30;  // at most 1 GiB of tabl
 struct FftPlan {
     int dim, n[3], batch, dbl, device;
     hipfftHandle fwd, inv;
+    int verified;   // the plan's first transforms were spot-checked against a direct DFT (below)
 };
 static std::vector<FftPlan> g_plans;
 static std::mutex g_plan_mu;
@@ -106,6 +109,193 @@ static int get_plan(FftPlan &out, int dim, const int *n, int batch, int dbl) {
     out = p;
     return LAGO_OK;
 }
+
+// ---- first-use spot check of a rocFFT plan ---------------------------------------------------------------------
+// rocFFT (ROCm 7.2) was caught returning a batched 2D real transform 60 % wrong once plans for other shapes existed
+// (tools/probes/rocfft_2d_repro.py reproduces it with torch alone).  A third-party wrong answer must not reach the
+// caller silently: the FIRST forward and inverse execution of every cached plan is compared, for the first and the last
+// transform of the batch, with a direct DFT at six frequencies / six voxels (double accumulation; a few milliseconds
+// and one stream synchronisation, once per plan).  A mismatch fails the call with a message naming the shape.
+constexpr int kSpot = 6;
+
+struct SpotGeom {
+    int dim, n[3], nzc;          // extents (2D: n[2] = 1); bins of the last axis in the half spectrum
+    long long plane, cplane;     // real / complex elements per transform
+    int member[2];               // the two transforms of the batch that are checked
+};
+
+__device__ __forceinline__ void spot_pick(const SpotGeom &g, int q, int (&k)[3]) {
+    // frequencies / voxels: the origin, one step along each axis, two generic ones (the last axis stays inside the half spectrum)
+    const int pick[kSpot][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {g.n[0] / 2, g.n[1] / 3, 0}, {3, 5, 2}};
+    for (int d = 0; d < 3; ++d) k[d] = pick[q][d] % (g.n[d] > 0 ? g.n[d] : 1);
+    const int last = g.dim - 1;
+    if (q == 4) k[last] = g.nzc - 1;
+    if (q == 3 && g.dim == 2) { k[1] = 1 % g.nzc; k[2] = 0; }
+    if (k[last] >= g.nzc) k[last] = g.nzc - 1;
+}
+
+// forward: X[k] = sum_x x[r] exp(-2 pi i k.r / n) of the real input, for (member, q); out[(mi*kSpot+q)*2 + {0,1}]
+template <typename R>
+__global__ __launch_bounds__(256) void spot_forward_kernel(double *out, const R *x, SpotGeom g) {
+    const int mi = blockIdx.x / kSpot, q = blockIdx.x % kSpot;
+    int k[3];
+    spot_pick(g, q, k);
+    const R *xm = x + (size_t)g.member[mi] * g.plane;
+    double re = 0, im = 0;
+    const long long n12 = (long long)g.n[1] * g.n[2];
+    for (long long e = threadIdx.x; e < g.plane; e += 256) {
+        const long long i0 = e / n12, r = e - i0 * n12, i1 = r / g.n[2], i2 = r - i1 * g.n[2];
+        const double ph = -2.0 * 3.14159265358979323846 * ((double)(k[0] * i0 % g.n[0]) / g.n[0] + (double)(k[1] * i1 % g.n[1]) / g.n[1] +
+                                                            (double)(k[2] * i2 % g.n[2]) / g.n[2]);
+        const double v = (double)xm[e];
+        re += v * cos(ph);
+        im += v * sin(ph);
+    }
+    __shared__ double sr[256], si[256];
+    sr[threadIdx.x] = re; si[threadIdx.x] = im;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { sr[threadIdx.x] += sr[threadIdx.x + st]; si[threadIdx.x] += si[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = sr[0]; out[blockIdx.x * 2 + 1] = si[0]; }
+}
+
+// inverse (unnormalised C2R): x[r] = sum over the half spectrum of w(k_last) Re(X[k] exp(+2 pi i k.r / n)), w = 1 on
+// the two self-conjugate planes of the last axis, 2 elsewhere -- the value a correct C2R returns at voxel r
+template <typename R>
+__global__ __launch_bounds__(256) void spot_inverse_kernel(double *out, const R *X, SpotGeom g) {
+    const int mi = blockIdx.x / kSpot, q = blockIdx.x % kSpot;
+    int r3[3];
+    spot_pick(g, q, r3);
+    const int last = g.dim - 1;
+    if (q == 4) r3[last] = g.n[last] - 1;   // (spot_pick keeps the last index inside the half spectrum: widen for voxels)
+    const R *Xm = X + (size_t)g.member[mi] * g.cplane * 2;
+    const int nl = g.n[last];
+    const long long c12 = g.dim == 3 ? (long long)g.n[1] * g.nzc : (long long)g.nzc;
+    double acc = 0;
+    for (long long e = threadIdx.x; e < g.cplane; e += 256) {
+        int kk[3] = {0, 0, 0};
+        if (g.dim == 3) { kk[0] = (int)(e / c12); const long long r = e - kk[0] * c12; kk[1] = (int)(r / g.nzc); kk[2] = (int)(r - (long long)kk[1] * g.nzc); }
+        else { kk[0] = (int)(e / g.nzc); kk[1] = (int)(e - (long long)kk[0] * g.nzc); }
+        const int kl = kk[last];
+        const double w = (kl == 0 || (nl % 2 == 0 && kl == nl / 2)) ? 1.0 : 2.0;
+        double ph = 0;
+        for (int d = 0; d < g.dim; ++d) ph += (double)((long long)kk[d] * r3[d] % g.n[d]) / g.n[d];
+        ph *= 2.0 * 3.14159265358979323846;
+        const double xr = (double)Xm[2 * e], xi = (double)Xm[2 * e + 1];
+        acc += w * (xr * cos(ph) - xi * sin(ph));
+    }
+    __shared__ double sa[256];
+    sa[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sa[threadIdx.x] += sa[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long idx = 0;
+        for (int d = 0; d < g.dim; ++d) idx = idx * g.n[d] + r3[d];
+        out[blockIdx.x * 2] = sa[0];
+        out[blockIdx.x * 2 + 1] = (double)idx;   // which voxel (read back by the host to pick the value to compare)
+    }
+}
+
+static SpotGeom spot_geom(int dim, const int *n, int batch) {
+    SpotGeom g{};
+    g.dim = dim;
+    for (int d = 0; d < 3; ++d) g.n[d] = d < dim ? n[d] : 1;
+    g.nzc = n[dim - 1] / 2 + 1;
+    g.plane = 1;
+    for (int d = 0; d < dim; ++d) g.plane *= n[d];
+    g.cplane = g.plane / n[dim - 1] * g.nzc;
+    g.member[0] = 0;
+    g.member[1] = batch - 1;
+    return g;
+}
+
+static void mark_verified(const FftPlan &p) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (FftPlan &q : g_plans)
+        if (q.fwd == p.fwd) q.verified = 1;
+}
+
+// after `work = R2C(m)`: compare.  Returns LAGO_OK or a failure.
+template <typename R>
+static int spot_check_forward(const FftPlan &p, const R *m, const R *work, hipStream_t s) {
+    const SpotGeom g = spot_geom(p.dim, p.n, p.batch);
+    double *d = nullptr;
+    LAGO_HIP_TRY(hipMalloc((void **)&d, 2 * kSpot * 2 * sizeof(double)));
+    hipLaunchKernelGGL((spot_forward_kernel<R>), dim3(2 * kSpot), dim3(256), 0, s, d, m, g);
+    double want[2 * kSpot * 2];
+    hipError_t e = hipMemcpyAsync(want, d, sizeof(want), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
+    double scale = 0, worst = 0;
+    R got[2];
+    for (int i = 0; i < 2 * kSpot; ++i) {
+        const int mi = i / kSpot, q = i % kSpot;
+        // the bin's index in the half spectrum (host replica of spot_pick)
+        const int pick[kSpot][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {g.n[0] / 2, g.n[1] / 3, 0}, {3, 5, 2}};
+        int k[3];
+        for (int dd = 0; dd < 3; ++dd) k[dd] = pick[q][dd] % (g.n[dd] > 0 ? g.n[dd] : 1);
+        const int last = g.dim - 1;
+        if (q == 4) k[last] = g.nzc - 1;
+        if (q == 3 && g.dim == 2) { k[1] = 1 % g.nzc; k[2] = 0; }
+        if (k[last] >= g.nzc) k[last] = g.nzc - 1;
+        long long idx = g.dim == 3 ? ((long long)k[0] * g.n[1] + k[1]) * g.nzc + k[2] : (long long)k[0] * g.nzc + k[1];
+        e = hipMemcpy(got, work + ((size_t)g.member[mi] * g.cplane + idx) * 2, 2 * sizeof(R), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
+        const double dr = (double)got[0] - want[2 * i], di = (double)got[1] - want[2 * i + 1];
+        worst = std::max(worst, std::sqrt(dr * dr + di * di));
+        scale = std::max(scale, std::sqrt(want[2 * i] * want[2 * i] + want[2 * i + 1] * want[2 * i + 1]));
+    }
+    const double tol = (sizeof(R) == 4 ? 1e-3 : 1e-9) * std::max(scale, 1e-30);
+    if (worst > tol)
+        return fail_invalid("fluid_metric: rocFFT returned a WRONG forward transform for %dD extents %d x %d x %d, batch %d "
+                            "(spot check against a direct DFT: deviation %.3g of %.3g); see tools/probes/rocfft_2d_repro.py",
+                            p.dim, p.n[0], p.n[1], p.dim == 3 ? p.n[2] : 1, p.batch, worst, scale);
+    return LAGO_OK;
+}
+
+// before `out = C2R(work)`: the expected voxel values; after it: compare
+template <typename R>
+struct SpotInverse {
+    double want[2 * kSpot * 2];
+    SpotGeom g;
+    int prepare(const FftPlan &p, const R *work, hipStream_t s) {
+        g = spot_geom(p.dim, p.n, p.batch);
+        double *d = nullptr;
+        LAGO_HIP_TRY(hipMalloc((void **)&d, sizeof(want)));
+        hipLaunchKernelGGL((spot_inverse_kernel<R>), dim3(2 * kSpot), dim3(256), 0, s, d, work, g);
+        hipError_t e = hipMemcpyAsync(want, d, sizeof(want), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(d);
+        if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
+        return LAGO_OK;
+    }
+    int compare(const FftPlan &p, const R *out, hipStream_t s) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
+        double scale = 0, worst = 0;
+        for (int i = 0; i < 2 * kSpot; ++i) {
+            R got;
+            const long long idx = (long long)want[2 * i + 1];
+            e = hipMemcpy(&got, out + (size_t)g.member[i / kSpot] * g.plane + idx, sizeof(R), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
+            worst = std::max(worst, std::fabs((double)got - want[2 * i]));
+            scale = std::max(scale, std::fabs(want[2 * i]));
+        }
+        const double tol = (sizeof(R) == 4 ? 1e-3 : 1e-9) * std::max(scale, 1e-30);
+        if (worst > tol)
+            return fail_invalid("fluid_metric: rocFFT returned a WRONG inverse transform for %dD extents %d x %d x %d, "
+                                "batch %d (spot check against a direct DFT: deviation %.3g of %.3g); see "
+                                "tools/probes/rocfft_2d_repro.py", p.dim, p.n[0], p.n[1], p.dim == 3 ? p.n[2] : 1, p.batch,
+                                worst, scale);
+        return LAGO_OK;
+    }
+};
 
 static int get_coef(CoefRef &ref, int64_t gen, int inverse, const float *cosX, const float *sinX, const float *cosY,
                     const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta, double gamma,
@@ -167,10 +357,25 @@ static int fluid_metric_xpass(float *out, const float *m, float *work, int64_t g
     if (rc != LAGO_OK) return rc;
     hipfftResult r = exec_on(p.fwd, s, [&] { return hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work); });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecR2C(2D)");
+    const bool check = !p.verified;   // first use of this plan: spot-check rocFFT against a direct DFT
+    if (check) {
+        rc = spot_check_forward<float>(p, m, work, s);
+        if (rc != LAGO_OK) return rc;
+    }
     rc = fluid_xpass_launch(work, tab->d, inverse, nn, nx, ny, nzc, 1.0 / ((double)nx * (double)ny * (double)nz), s);
     if (rc != LAGO_OK) return rc;
+    SpotInverse<float> spot;
+    if (check) {
+        rc = spot.prepare(p, work, s);
+        if (rc != LAGO_OK) return rc;
+    }
     r = exec_on(p.inv, s, [&] { return hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out); });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecC2R(2D)");
+    if (check) {
+        rc = spot.compare(p, out, s);
+        if (rc != LAGO_OK) return rc;
+        mark_verified(p);
+    }
     return finish_launch(s, "fluid_metric");
 }
 
@@ -214,17 +419,32 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
                               : hipfftExecD2Z(p.fwd, (hipfftDoubleReal *)m, (hipfftDoubleComplex *)work);
     });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExec(forward)");
+    const bool check = !p.verified;   // first use of this plan: spot-check rocFFT against a direct DFT
+    if (check) {
+        rc = spot_check_forward<R>(p, m, work, s);
+        if (rc != LAGO_OK) return rc;
+    }
     // half-spectrum extents: the last axis keeps n/2 + 1 bins
     const int64_t cx = nx, cy = dim == 2 ? ny / 2 + 1 : ny, cz = dim == 3 ? nz / 2 + 1 : 1;
     const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
     rc = fluid_operator_impl<R>(work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, cx, cy,
                                 cz, stream, scale);
     if (rc != LAGO_OK) return rc;
+    SpotInverse<R> spot;
+    if (check) {
+        rc = spot.prepare(p, work, s);
+        if (rc != LAGO_OK) return rc;
+    }
     r = exec_on(p.inv, s, [&] {
         return sizeof(R) == 4 ? hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out)
                               : hipfftExecZ2D(p.inv, (hipfftDoubleComplex *)work, (hipfftDoubleReal *)out);
     });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExec(inverse)");
+    if (check) {
+        rc = spot.compare(p, out, s);
+        if (rc != LAGO_OK) return rc;
+        mark_verified(p);
+    }
     return finish_launch(s, "fluid_metric");
 }
 
