@@ -65,6 +65,10 @@ int lago_get_splat_mode(void);
 void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
 /* 1 (default): use the slab-unrolled 3D gather kernels (two voxels per lane) when the shape allows; 0: one-voxel-per-lane kernels only. */
 void lago_set_vector_kernels(int on);
+/* 1 (default): every launch of the large kernels walks its workgroups in the opposite direction of the launch before
+ * it, so that a consumer starts on what its producer wrote last -- still in the 256 MB Infinity Cache; 0: always
+ * ascending.  Same results (scatter-add outputs differ in their last bits, as between any two runs). */
+void lago_set_launch_order(int alternate);
 /* 1 (default): the 3D Jacobian / stencil terms of Ad_star and jacobian_times_vectorfield_backward are taken from an
  * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows; 0: every
  * neighbour is loaded from global memory.  Same bits. */

@@ -9,6 +9,8 @@ namespace lago {
 static std::atomic<int> g_debug{0};
 std::atomic<int> g_splat_mode{1};
 std::atomic<int> g_interp_vec{1};
+std::atomic<int> g_launch_alt{1};
+std::atomic<unsigned> g_launch_seq{0};
 static thread_local char g_err[512] = "";
 
 int fail_invalid(const char *fmt, ...) {
@@ -47,4 +49,5 @@ const char *lago_last_error(void) { return lago::g_err; }
 void lago_set_splat_mode(int mode) { lago::g_splat_mode = mode; }
 int lago_get_splat_mode(void) { return lago::g_splat_mode; }
 void lago_set_vector_kernels(int on) { lago::g_interp_vec = on ? 1 : 0; }
+void lago_set_launch_order(int alternate) { lago::g_launch_alt = alternate ? 1 : 0; }
 }

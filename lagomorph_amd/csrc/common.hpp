@@ -46,6 +46,14 @@ struct KnobArray {  // array-valued setting: read and written as a whole under a
         v = nv;
     }
 };
+// Launch direction.  The 256 MB Infinity Cache (memory side) still holds the END of what the previous kernel wrote:
+// a consumer that walks its blocks in the REVERSE of its producer's order starts on cached data (streaming chain of
+// 805 MB buffers: 5.54 -> 5.90 TB/s, 256 MB: 5.38 -> 6.03; tools/probes/mall_order.hip).  Every launch of the big
+// kernels therefore takes the opposite direction of the launch before it (0 = ascending logical blocks).  Speed
+// only: the block -> data mapping is a bijection either way.
+extern std::atomic<int> g_launch_alt;        // 1 (default): alternate; 0: always ascending
+extern std::atomic<unsigned> g_launch_seq;
+inline int next_direction() { return g_launch_alt ? (int)(g_launch_seq.fetch_add(1) & 1u) : 0; }
 extern std::atomic<int> g_splat_mode;
 extern std::atomic<int> g_interp_vec;  // 1: use the vectorised 3D kernels when shapes allow (default)
 
@@ -79,6 +87,7 @@ struct Geom {
     uint32_t nvox;      // nx*ny*nz
     uint32_t nbx;       // workgroups per batch item
     uint32_t nblocks;   // nbx * nn
+    int rev;            // launch direction (next_direction()): logical blocks descending
     FastDiv dyz, dz, dnbx;
 };
 
@@ -100,6 +109,7 @@ inline bool make_geom(Geom &g, int dim, int64_t nn, int64_t nx, int64_t ny, int6
     int64_t nb = (int64_t)g.nbx * nn;
     if (nb >= (1ll << 31)) return false;
     g.nblocks = (uint32_t)nb;
+    g.rev = next_direction();
     g.dyz = FastDiv((uint32_t)(ny * nz));
     g.dz = FastDiv((uint32_t)nz);
     g.dnbx = FastDiv(g.nbx);
@@ -116,6 +126,11 @@ __device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t total) {
     if (b >= (q << 3)) return b;
     return (b & 7u) * q + (b >> 3);
 }
+// ... and in the launch's direction (Geom::rev / next_direction())
+__device__ __forceinline__ uint32_t block_order(uint32_t b, uint32_t total, int rev) {
+    const uint32_t L = xcd_swizzle(b, total);
+    return rev ? total - 1u - L : L;
+}
 
 struct Vox {
     uint32_t n;  // batch item
@@ -126,7 +141,7 @@ struct Vox {
 
 __device__ __forceinline__ Vox locate(const Geom &g) {
     Vox v;
-    uint32_t L = xcd_swizzle(blockIdx.x, g.nblocks);
+    uint32_t L = block_order(blockIdx.x, g.nblocks, g.rev);
     v.n = g.dnbx.div(L);
     uint32_t bx = L - v.n * g.nbx;
     v.s = bx * kBlock + threadIdx.x;

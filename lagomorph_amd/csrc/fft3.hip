@@ -34,7 +34,7 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_kernel(fl::
     using K = ZYK<NY, NZ>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
-    const size_t p = blockIdx.x;
+    const size_t p = a.rev ? a.total - 1u - blockIdx.x : blockIdx.x;
     const float *in = a.in + p * (size_t)(K::NY * K::NZ);
     float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
 #pragma unroll
@@ -49,7 +49,7 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_kernel(fl::
     using K = ZYK<NY, NZ>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
-    const size_t p = blockIdx.x;
+    const size_t p = a.rev ? a.total - 1u - blockIdx.x : blockIdx.x;
     float *out = a.out + p * (size_t)(K::NY * K::NZ);
     const float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
 #pragma unroll
@@ -69,12 +69,14 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_persist_ker
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
     K::fill_twiddles(threadIdx.x, tw);
     float4 v[K::KV];
-    size_t p = blockIdx.x;
-    K::fwd_load(threadIdx.x, a.in + p * (size_t)(K::NY * K::NZ), v);
-    for (; p < a.total; p += gridDim.x) {
+    auto at = [&](size_t q) { return a.rev ? (size_t)a.total - 1 - q : q; };   // launch direction (common.hpp)
+    size_t pq = blockIdx.x;
+    K::fwd_load(threadIdx.x, a.in + at(pq) * (size_t)(K::NY * K::NZ), v);
+    for (; pq < a.total; pq += gridDim.x) {
+        const size_t p = at(pq);
         K::fwd_fill(threadIdx.x, v, P);
         __syncthreads();
-        if (p + gridDim.x < a.total) K::fwd_load(threadIdx.x, a.in + (p + gridDim.x) * (size_t)(K::NY * K::NZ), v);
+        if (pq + gridDim.x < a.total) K::fwd_load(threadIdx.x, a.in + at(pq + gridDim.x) * (size_t)(K::NY * K::NZ), v);
         float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
 #pragma unroll
         for (int ph = 1; ph < K::NPH; ++ph) {
@@ -92,13 +94,17 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
     K::fill_twiddles(threadIdx.x, tw);
     float4 v[K::KV];
     float2 fb[K::KV];
-    size_t p = blockIdx.x;
-    K::inv_load(threadIdx.x, a.main_ + p * (size_t)(K::NY * K::NZH), a.nyq + p * (size_t)K::NY, v, fb);
-    for (; p < a.total; p += gridDim.x) {
+    auto at = [&](size_t q) { return a.rev ? (size_t)a.total - 1 - q : q; };   // launch direction (common.hpp)
+    size_t pq = blockIdx.x;
+    K::inv_load(threadIdx.x, a.main_ + at(pq) * (size_t)(K::NY * K::NZH), a.nyq + at(pq) * (size_t)K::NY, v, fb);
+    for (; pq < a.total; pq += gridDim.x) {
+        const size_t p = at(pq);
         K::inv_fill(threadIdx.x, v, fb, P);
         __syncthreads();
-        const size_t pn = p + gridDim.x;
-        if (pn < a.total) K::inv_load(threadIdx.x, a.main_ + pn * (size_t)(K::NY * K::NZH), a.nyq + pn * (size_t)K::NY, v, fb);
+        if (pq + gridDim.x < a.total) {
+            const size_t pn = at(pq + gridDim.x);
+            K::inv_load(threadIdx.x, a.main_ + pn * (size_t)(K::NY * K::NZH), a.nyq + pn * (size_t)K::NY, v, fb);
+        }
         float *out = a.out + p * (size_t)(K::NY * K::NZ);
 #pragma unroll
         for (int ph = 1; ph < K::NPH_INV; ++ph) {
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(NT) void fluid_xpass2_kernel(fl::XArgs a) {
     using K = fl::XPass<typename SzOf<NX>::T, INV, NT>;
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *buf = reinterpret_cast<float2 *>(lago_smem), *tw = buf + 3 * K::NX * K::KCP;
-    const uint32_t blk = xcd_swizzle(blockIdx.x, a.total);
+    const uint32_t blk = block_order(blockIdx.x, a.total, a.rev);
     typename K::Block b = K::locate(a, blk);
     typename K::Regs r;
     // consecutive batch items under the same coefficients (held in registers): the 24-byte table
@@ -427,10 +433,13 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     xa.ipw = ipw;
     xa.total = (uint32_t)((nn + xa.ipw - 1) / xa.ipw * items);
     hipError_t e = hipSuccess;
+    za.rev = next_direction();
     if (stages & 1) e = zy_dispatch(ny, nz, za, false, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy forward)");
+    xa.rev = next_direction();
     if (stages & 2) e = xpass2_dispatch(nx, xa, inverse != 0, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (x pass)");
+    za.rev = next_direction();
     if (stages & 4) e = zy_dispatch(ny, nz, za, true, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy inverse)");
     return finish_launch(s, "fluid_metric");

@@ -271,6 +271,7 @@ struct XArgs {
     int nn, ipw;                // batch size; batch items one workgroup runs through with the same coefficients
     float scale;
     uint32_t total;             // ceil(nn / ipw) * items_per_n workgroups
+    int rev;                    // launch direction (common.hpp)
 };
 
 template <class SX, bool INV, int NT = 256>
@@ -379,6 +380,7 @@ struct ZYArgs {
     float *out;        // inverse: real planes
     float2 *main_, *nyq;
     uint32_t total;
+    int rev;           // launch direction (common.hpp): planes descending
 };
 
 // threads per plane: 1024 once a plane has at least 2048 float4 (two per thread), else 512; the load / store phases

@@ -53,7 +53,7 @@ template <typename R, int U, bool UNIT>
 __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__ out, const R *__restrict__ u,
                                                                  const R *__restrict__ v, double ds, double dt, Geom g,
                                                                  uint32_t nbx_u, uint32_t nblocks_u) {
-    const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
+    const uint32_t Lb = block_order(blockIdx.x, nblocks_u, g.rev);
     const uint32_t n = Lb / nbx_u;
     const uint32_t bx = Lb - n * nbx_u;
     const size_t nv = g.nvox;
@@ -214,7 +214,7 @@ template <typename R, int U>
 __global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__ out, R *__restrict__ mphi,
                                                                  const R *__restrict__ phi, const R *__restrict__ m,
                                                                  Geom g, uint32_t nbx_u, uint32_t nblocks_u) {
-    const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
+    const uint32_t Lb = block_order(blockIdx.x, nblocks_u, g.rev);
     const uint32_t n = Lb / nbx_u;  // uniform: scalar division
     const uint32_t bx = Lb - n * nbx_u;
     const size_t nv = g.nvox;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NT) void ad_star3_tile_kernel(R *__restrict__ out, 
                                                            RowTile t) {
     extern __shared__ __align__(16) unsigned char lago_smem[];
     R *lds = reinterpret_cast<R *>(lago_smem);
-    const uint32_t Lb = xcd_swizzle(blockIdx.x, t.total);
+    const uint32_t Lb = block_order(blockIdx.x, t.total, g.rev);
     const uint32_t n = t.d_tiles.div(Lb);
     const uint32_t r = Lb - n * t.tiles_per_item;
     const uint32_t tx = t.d_nty.div(r), ty = r - tx * t.nty;
@@ -460,10 +460,11 @@ static int ad_star_impl(R *out, R *mphi, const R *phi, const R *m, int dim, int6
 // per term, coefficients rounded to R first -- the arithmetic of torch's add(alpha=...) chain on the same operands.
 template <typename R, int K, int VEC>
 __global__ __launch_bounds__(256) void lincomb_kernel(R *out, const R *x0, const R *x1, const R *x2, const R *x3, R c0,
-                                                      R c1, R c2, R c3, size_t nvec) {
+                                                      R c1, R c2, R c3, size_t nvec, int rev) {
     struct alignas(sizeof(R) * VEC) V { R e[VEC]; };
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < nvec; j += stride) {
+        const size_t i = rev ? nvec - 1 - j : j;   // launch direction (common.hpp)
         const V a = reinterpret_cast<const V *>(x0)[i];
         V b = a, c = a, d = a, r;
         if (K > 1) b = reinterpret_cast<const V *>(x1)[i];
@@ -493,9 +494,10 @@ int lincomb_impl(R *out, int k, const R *x0, const R *x1, const R *x2, const R *
                      aligned(k > 2 ? x2 : nullptr) && aligned(k > 3 ? x3 : nullptr);
     const size_t nvec = vec ? (size_t)n / VEC : (size_t)n;
     const uint32_t grid = (uint32_t)std::min<size_t>((nvec + 255) / 256, (size_t)256 * 32);
+    const int rev = next_direction();
 #define LAGO_LC(K, V)                                                                                              \
     hipLaunchKernelGGL((lincomb_kernel<R, K, V>), dim3(grid), dim3(256), 0, s, out, x0, x1, x2, x3, (R)c0, (R)c1, (R)c2, \
-                       (R)c3, nvec)
+                       (R)c3, nvec, rev)
     if (vec) {
         if (k == 1) LAGO_LC(1, VEC); else if (k == 2) LAGO_LC(2, VEC); else if (k == 3) LAGO_LC(3, VEC); else LAGO_LC(4, VEC);
     } else {

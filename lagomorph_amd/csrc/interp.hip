@@ -47,7 +47,7 @@ template <typename R, bool BC, int U, bool UNIT>
 __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restrict__ out, const R *__restrict__ I,
                                                                     const R *__restrict__ u, double dt, int nc,
                                                                     Geom g, uint32_t nbx_u, uint32_t nblocks_u) {
-    const uint32_t Lb = xcd_swizzle(blockIdx.x, nblocks_u);
+    const uint32_t Lb = block_order(blockIdx.x, nblocks_u, g.rev);
     const uint32_t n = Lb / nbx_u;  // uniform: scalar division
     const uint32_t bx = Lb - n * nbx_u;
     const size_t nv = g.nvox;

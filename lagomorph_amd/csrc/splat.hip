@@ -58,6 +58,7 @@ struct TileGeom {
     int WX, WY, WZ;     // LDS window (cells)
     int MX, MY, MZ;     // margin below the probed origin
     uint32_t ntx, nty, ntz, tiles_per_item, total;
+    int rev;                           // launch direction (common.hpp)
     uint32_t tile_groups, win_cells;   // tile size in VPL-groups; window size in cells
                                        // atomics, bit2 no flush atomics; always 0 in production
     FastDiv d_tiles, d_tyz, d_tz;      // block id -> (n, bx, by, bz)
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     constexpr bool DISP = MODE == POS_DISP || MODE == POS_DISP_UNIT;
 
     // workgroup -> (batch item, tile)
-    const uint32_t L = xcd_swizzle(blockIdx.x, tg.total);
+    const uint32_t L = block_order(blockIdx.x, tg.total, tg.rev);
     const uint32_t n = tg.d_tiles.div(L);
     uint32_t r = L - n * tg.tiles_per_item;
     const uint32_t bx = tg.d_tyz.div(r);
@@ -397,6 +398,7 @@ struct ShearGeom {
     int MX, MY, MZ;
     int nseg;              // 16-cell z segments of the window
     uint32_t ntx, nty, ntz, tiles_per_item, total, tile_vox, win_cells;
+    int rev;               // launch direction (common.hpp)
     FastDiv d_tiles, d_tyz, d_tz, d_TyTz, d_Tz, d_wy;
 };
 
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
     const uint32_t planeB = nv * 4u;
 
     // workgroup -> (batch item, tile)
-    const uint32_t L = xcd_swizzle(blockIdx.x, sg.total);
+    const uint32_t L = block_order(blockIdx.x, sg.total, sg.rev);
     const uint32_t n = sg.d_tiles.div(L);
     uint32_t r = L - n * sg.tiles_per_item;
     const uint32_t bx = sg.d_tyz.div(r);
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
     constexpr uint32_t NOWIN = 0xffffffffu, NOROW = 0xffffffffu, DEAD = 0xffffffffu;
 
     // workgroup -> (batch item, tile)
-    const uint32_t L = xcd_swizzle(blockIdx.x, sg.total);
+    const uint32_t L = block_order(blockIdx.x, sg.total, sg.rev);
     const uint32_t n = sg.d_tiles.div(L);
     uint32_t r = L - n * sg.tiles_per_item;
     const uint32_t bx = sg.d_tyz.div(r);
@@ -953,6 +955,7 @@ static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem, i
     const int64_t total = (int64_t)sg.tiles_per_item * nn;
     if (total >= (1ll << 31)) return false;
     sg.total = (uint32_t)total;
+    sg.rev = g.rev;
     sg.tile_vox = (uint32_t)TX * TY * TZ;
     sg.d_tiles = FastDiv(sg.tiles_per_item);
     sg.d_tyz = FastDiv(sg.nty * sg.ntz);
@@ -1104,6 +1107,7 @@ static bool make_tiles(TileGeom &tg, const Geom &g, const Geom &gs, int64_t nn, 
     int64_t total = (int64_t)tg.tiles_per_item * nn;
     if (total >= (1ll << 31)) return false;
     tg.total = (uint32_t)total;
+    tg.rev = g.rev;
     tg.tile_groups = (uint32_t)TX * TY * TZ;  // voxels per tile
     while (nthreads > 256 && (uint32_t)nthreads > tg.tile_groups) nthreads >>= 1;
     tg.d_tiles = FastDiv(tg.tiles_per_item);

@@ -84,7 +84,7 @@ _lib.lago_set_splat_tile.argtypes = [_int] * 7
 _lib.lago_set_vector_kernels.argtypes = [_int]
 _lib.lago_set_splat_shear.argtypes = [_int] * 8
 _lib.lago_set_fluid_xpass.argtypes = [_int]
-for _name in ("lago_set_stencil_tile", "lago_set_splat_mc", "lago_set_splat_shear_mc", "lago_set_fluid_xpass_ipw", "lago_set_fluid_zy_persist",
+for _name in ("lago_set_launch_order", "lago_set_stencil_tile", "lago_set_splat_mc", "lago_set_splat_shear_mc", "lago_set_fluid_xpass_ipw", "lago_set_fluid_zy_persist",
               "lago_set_fluid_xpass_wide"):
     getattr(_lib, _name).argtypes = [_int]
 
@@ -180,6 +180,12 @@ def set_fluid_tuning(xpass_ipw=0, zy_persist=1, xpass_wide=1):
     _lib.lago_set_fluid_xpass_ipw(int(xpass_ipw))
     _lib.lago_set_fluid_zy_persist(1 if zy_persist else 0)
     _lib.lago_set_fluid_xpass_wide(1 if xpass_wide else 0)
+
+
+def set_launch_order(alternate):
+    """1 (default): successive launches walk their workgroups in alternating directions (a consumer starts on what
+    its producer wrote last: Infinity-Cache reuse); 0: always ascending.  Speed only."""
+    _lib.lago_set_launch_order(1 if alternate else 0)
 
 
 def set_stencil_tile(on):
