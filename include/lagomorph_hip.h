@@ -85,10 +85,9 @@ void lago_set_fluid_xpass(int mode);
  * above 128 voxels), window margins MX MY MZ around the probed origin, threads per workgroup (256 / 512 / 1024).
  * Default 1, 8 6 0, 1 1 4, 1024.  d_u is bit-identical under every setting; d_I differs by the order of its sums. */
 void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
-/* Several channels with d_u wanted.  Sheared-window kernel: 3 each voxel's geometry -- window addresses, gather
- * offset, fractions -- and its d_u sums stay in registers over the channel loop (tiles of at most 2048 voxels),
- * 2 (default) that form for non-unit steps and form 1 for dt = +-1, 1 only the d_u sums stay in registers (geometry
- * recomputed per channel), 0 d_u is read-modify-written per channel.  General tiled
+/* Several channels with d_u wanted.  Sheared-window kernel: 2 (default) each voxel's geometry -- window addresses,
+ * gather offset, fractions -- and its d_u sums stay in registers over the channel loop (tiles of at most 2048
+ * voxels), 1 only the d_u sums do (geometry recomputed per channel), 0 d_u is read-modify-written per channel.  General tiled
  * kernel: 1 (default) / 0 likewise.  Same d_u bits under every setting. */
 void lago_set_splat_shear_mc(int mode);
 void lago_set_splat_mc(int on);

@@ -1006,12 +1006,11 @@ static int interp_backward_shear(float *d_I, float *d_u, const float *go, const 
     size_t smem;
     hipError_t e;
     const int shear_nt = g_shear_nt;
-    // the geometry-once kernel pays for non-unit steps (the float64 position and the re-read of u per channel are what
-    // it removes: -7 ... -12 %); with a unit step it measures within +-3 % of splat_shear_kernel<..., VPL>, whose
-    // larger tiles flush fewer cells -- mode 3 forces it for every step (tests, tools/ab_shear_mc.py)
+    // the geometry-once kernel: in isolation it gains 7-12 % for non-unit steps and measures within +-3 % for dt = +-1
+    // (smaller tiles flush more cells); inside lddmm_step -- running d_u / d_I sums, 3-voxel displacements -- it wins
+    // for both: 21.63 -> 20.40 ms per step at 8 x 160^3, 10.27 -> 9.85 at 8 x 128^3 (tools/ab_step_mc.py)
     const bool unit_step = unit_dt<float>(dt);
-    if (need_u && nc > 1 && (g_shear_mc >= 3 || (g_shear_mc == 2 && !unit_step)) && shear_nt >= 1024 &&
-        make_shear(sg, g, nn, smem, 2048)) {
+    if (need_u && nc > 1 && g_shear_mc >= 2 && shear_nt >= 1024 && make_shear(sg, g, nn, smem, 2048)) {
         const bool unit = unit_step;
         const bool one = sg.tile_vox <= 1024u;
 #define LAGO_SHEAR_MC(UN, B)                                                                                      \

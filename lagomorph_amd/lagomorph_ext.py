@@ -169,8 +169,8 @@ def set_splat_mc(on):
 
 
 def set_splat_shear_mc(mode):
-    """Sheared-window splat, several channels with d_u: 3 geometry and d_u sums in registers over the channels,
-    2 (default) that form for non-unit steps only, 1 the d_u sums only, 0 neither.  Speed only (same d_u bits)."""
+    """Sheared-window splat, several channels with d_u: 2 (default) geometry and d_u sums in registers over the
+    channels, 1 the d_u sums only, 0 neither.  Speed only (same d_u bits)."""
     _lib.lago_set_splat_shear_mc(int(mode))
 
 

@@ -27,7 +27,7 @@ cases = {
 }
 ref = {}
 for rep in range(2):
-    for mc in [int(x) for x in os.environ.get("MODES", "1,3").split(",")]:
+    for mc in [int(x) for x in os.environ.get("MODES", "1,2").split(",")]:
         ext.set_splat_shear_mc(mc)
         for name, fn in cases.items():
             dI, du = fn()
