@@ -62,11 +62,12 @@ def scale_momenta(lm, m, vox):
 CASES = [((20, 24, 28), (20, 24, 28)), ((20, 24, 28), (10, 12, 16)), ((40, 36), (40, 36)), ((40, 36), (18, 20))]
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 1e-5)])
 @pytest.mark.parametrize("sp,msp", CASES)
 def test_lddmm_step_hip_equals_oracle_backend(sp, msp, dtype, tol):
-    """One matching step: loss, regularisation term, updated momenta and atlas gradient.  The float32 bound is
-    loose on purpose: the step chains ~40 kernels, half of them scatter-adds whose summation order differs."""
+    """One matching step: loss, regularisation term, updated momenta and atlas gradient, at north_star's bound
+    (1e-5 x max in float32, 1e-12 in float64; observed on MI355X: 1.5e-6 / 4e-15 -- the step chains ~40 kernels, half
+    of them scatter-adds whose summation order differs)."""
     import lagomorph_amd as lm
 
     base, imgs, m = make_problem(sp, msp, dtype, 3)
@@ -87,6 +88,7 @@ def test_lddmm_step_hip_equals_oracle_backend(sp, msp, dtype, tol):
         return float((a.cpu().double() - b.double()).abs().max() / b.double().abs().max())
 
     errs = {"loss": rel(lg, lc), "reg": rel(rg, rc), "m": rel(mg, mc), "I.grad": rel(Ig.grad, Ic.grad)}
+    print(f"lddmm_step HIP vs oracle backend {sp} {msp} {dtype}: {errs}")
     assert all(e <= tol for e in errs.values()), errs
     assert float((mg.cpu() - m).abs().max()) > 0  # the step moved the momenta
 

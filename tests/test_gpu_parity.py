@@ -277,13 +277,14 @@ def test_affine_interp(ext, dtype, sp, nn, nc, bc):
             assert_close(dI, oI, dtype, "affine d_I")
         else:
             assert dI.numel() == 0
-        # dA/dT are sums over nvox terms; fp32 summation order differs from the reference's tree
+        # dA/dT are sums over nvox terms whose fp32 summation order differs from the reference's tree: still within
+        # north_star's 1e-5 x max |reference| (no inflated scale: round-2 review)
         if needs[1]:
-            assert_close(dA, oA, dtype, "affine d_A", scale=np.abs(oA).max() + np.sqrt(nvox) * max(sp))
+            assert_close(dA, oA, dtype, "affine d_A")
         else:
             assert dA.numel() == 0
         if needs[2]:
-            assert_close(dT, oT, dtype, "affine d_T", scale=np.abs(oT).max() + np.sqrt(nvox))
+            assert_close(dT, oT, dtype, "affine d_T")
         else:
             assert dT.numel() == 0
 
