@@ -489,6 +489,38 @@ def test_fused_2d_fluid_metric(ext, sp, inverse):
         assert np.allclose(s_out, s_in / 0.01 ** 2, rtol=1e-3, atol=1e-3 * np.abs(s_in).max() / 0.01 ** 2)
 
 
+def test_launch_order_does_not_change_results(ext):
+    """`lago_set_launch_order`: walking the workgroups in alternating directions (Infinity-Cache reuse) is a pure
+    re-ordering -- every non-atomic output is bit-identical under both settings, scatter-adds stay within the bound."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(8)
+    sp = (24, 20, 64)
+    phi = _disp(rng, 3, sp, torch.float32)
+    m = rnd(rng, (3, 3) + sp, torch.float32)
+    go = rnd(rng, (3, 3) + sp, torch.float32)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    big = rnd(rng, (2, 3, 64, 64, 64), torch.float32)   # a shape on the hand-written FFT passes
+    res = {}
+    for alt in (0, 1, 1, 0):   # (twice with alternation: both parities of the launch counter)
+        ext.set_launch_order(alt)
+        try:
+            cur = [ext.Ad_star(dev(phi), dev(m)), ext.compose(dev(phi), dev(m), -0.3, 1.0), ext.interp_forward(dev(m), dev(phi), 0.7),
+                   ext.jacobian_times_vectorfield_backward(dev(go), dev(phi), dev(m), True, False, True, True)[0],
+                   met.sharp(dev(big)), ext.lincomb([(0.5, dev(m)), (-2.0, dev(go))]),
+                   lm.expmap(met, dev(0.01 * big), num_steps=3)]
+            dI, du = ext.interp_backward(dev(go), dev(m), dev(phi), 0.9, True, True)
+        finally:
+            ext.set_launch_order(1)
+        if not res:
+            res["plain"], res["dI"], res["du"] = cur, dI, du
+            continue
+        for a, b in zip(cur, res["plain"]):
+            assert torch.equal(a, b)
+        assert torch.equal(du, res["du"])
+        assert_close(dI, host(res["dI"]), torch.float32, "splat under the other launch order")
+
+
 def test_rocfft_fallback_is_right_or_loud(ext):
     """The rocFFT-based fallbacks spot-check the first forward / inverse execution of every plan against a direct DFT
     (csrc/fft.hip): a call either returns what the oracle returns or raises, naming the shape -- never a silently
