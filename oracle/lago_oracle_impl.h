@@ -436,11 +436,16 @@ int FN(oracle_jtv_forward)(REAL *out, const REAL *v, const REAL *w, int displace
  * the linear indices of the centre voxel inside a and b. */
 static inline REAL FN(lg_dT_term)(const REAL *a, size_t ia, const REAL *b, size_t ib, size_t s, long pos,
                                   long len) {
+    if (len == 1) return (REAL)0; /* see below */
     if (pos == 0) return (REAL)(-.5) * LG_FMA(a[ia], b[ib], a[ia + s] * b[ib + s]);
     if (pos == len - 1) return (REAL)(.5) * LG_FMA(a[ia], b[ib], a[ia - s] * b[ib - s]);
     return (REAL)(-.5) * LG_FMA(a[ia + s], b[ib + s], -(a[ia - s] * b[ib - s]));
 }
-/* cuda/diff.cu:345-356 and :597-600 write the i==0 / j==0 / k==0 case of the 3D
+/* An axis of extent 1: the clamped difference along it is identically zero and
+ * so is its adjoint.  The reference's `pos == 0` case would read a[ia + s] there,
+ * which is the next channel or past the end of the allocation (undefined); the
+ * oracle and the HIP kernels both define it as 0 (deviations).
+ * cuda/diff.cu:345-356 and :597-600 write the i==0 / j==0 / k==0 case of the 3D
  * kernels with the +stride product first; here the centre product is the fused
  * one in every case (which product nvcc fuses is its choice). */
 
