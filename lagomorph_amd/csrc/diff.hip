@@ -42,18 +42,21 @@ struct Stencil {
 #pragma unroll
         for (int d = 0; d < DIM; ++d) gq[d] = (R)0.5f * (f[plus[d]] - f[minus[d]]);
     }
-    // Adjoint of the clamped central difference along axis d applied to a*b: the reference's three-case
-    // border formula (cuda/diff.cu:224-248, 334-391, 560-573, 603-620) on values that are already in
-    // registers (x0 = centre, xp / xm = the clamped +1 / -1 neighbours along axis d; the clamped side is
-    // never used at its border).  The kernels below load every needed neighbour once up front: all loads
-    // are then independent and in flight together, instead of up to six dependent-on-branch loads per
-    // (component, axis) pair.
-    // An axis of extent 1 contributes nothing: the clamped difference along it is identically zero, so
-    // its adjoint is too.  (The reference's `i == 0` case reads the +stride neighbour there, which is
-    // the next channel or past the allocation; DESIGN.md "deviations".)
+    // Adjoint of the clamped central difference along axis d applied to a*b
+    // (cuda/diff.cu:224-248, 334-391, 560-573, 603-620).  a, b point at the centre voxel.
+    template <typename R>
+    __device__ __forceinline__ R dT(const R *__restrict__ a, const R *__restrict__ b, int d) const {
+        const int st = stride[d];
+        if (pos[d] == 0) return (R)(-.5) * lg_fma(a[0], b[0], a[st] * b[st]);
+        if (pos[d] == len[d] - 1) return (R)(.5) * lg_fma(a[0], b[0], a[-st] * b[-st]);
+        return (R)(-.5) * lg_fma(a[st], b[st], -(a[-st] * b[-st]));
+    }
+    // Same formula on values that are already in registers (x0 = centre, xp / xm = the clamped +1 / -1
+    // neighbours along axis d; the clamped side is never used at its border).  The kernels below load
+    // every needed neighbour once up front: all loads are then independent and in flight together,
+    // instead of up to six dependent-on-branch loads per (component, axis) pair.
     template <typename R>
     __device__ __forceinline__ R dTv(R a0, R ap, R am, R b0, R bp, R bm, int d) const {
-        if (len[d] == 1) return (R)0;
         if (pos[d] == 0) return (R)(-.5) * lg_fma(a0, b0, ap * bp);
         if (pos[d] == len[d] - 1) return (R)(.5) * lg_fma(a0, b0, am * bm);
         return (R)(-.5) * lg_fma(ap, bp, -(am * bm));
