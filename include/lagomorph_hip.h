@@ -73,6 +73,11 @@ void lago_set_launch_order(int alternate);
  * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows; 0: every
  * neighbour is loaded from global memory.  Same bits. */
 void lago_set_stencil_tile(int on);
+/* 1 (default): float32 3D trilinear gathers of smooth fields (compose, Ad_star's momentum) stage the source block of a
+ * tile of voxels in LDS with LDS-direct loads and take the corners from there (csrc/gather_window.hpp) where the
+ * shape allows; a workgroup whose samples leave its window, and every other shape, uses the pair gathers through the
+ * vector L1; 0: pair gathers only.  Same bits. */
+void lago_set_gather_window(int on);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
  * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
  * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z)

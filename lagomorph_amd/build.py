@@ -36,8 +36,8 @@ FLAGS = [
 
 
 def _deps():
-    return [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "fft_lds.hpp"),
-            os.path.join(HERE, "..", "include", "lagomorph_hip.h")]
+    return [os.path.join(CSRC, h) for h in ("common.hpp", "fft_lds.hpp", "stencil_tile.hpp", "gather_window.hpp")] + [
+        os.path.join(HERE, "..", "include", "lagomorph_hip.h")]
 
 
 def _stale(target, srcs):

@@ -7,8 +7,10 @@
 // (fl(fl(ds*u) + fl(dt*I))), so the result is bit-identical to evaluating the
 // reference formula with this library's interp.
 #include <algorithm>
+#include <type_traits>
 #include "common.hpp"
 #include "stencil_tile.hpp"
+#include "gather_window.hpp"
 
 namespace lago {
 
@@ -109,6 +111,131 @@ __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__
     }
 }
 
+// LDS-window variant (gather_window.hpp): the three channels of v go through one 48 KB window in turn.
+// Same expressions as compose3_unroll_kernel; samples whose corners leave the window take them with that kernel's
+// pair gathers.
+template <int NT, int U, bool UNIT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void compose3_window_kernel(
+    float *__restrict__ out, const float *__restrict__ u, const float *__restrict__ v, double ds, double dt, Geom g, GWGrid w) {
+    extern __shared__ float gwin[];
+    constexpr int XS = NT / 512;
+    static_assert(XS * U == GW::TX && (NT == 512 || NT == 1024), "tile shape");  // 1024 x 4 has 64 VGPRs: measured slower
+    const GWTile tl = gw_tile(w, g.rev);
+    const size_t nv = g.nvox;
+    const uint32_t plane = g.nvox * 4u;
+    const float *un = u + (size_t)tl.n * 3 * nv;
+    const float *vn = v + (size_t)tl.n * 3 * nv;
+    float *on = out + (size_t)tl.n * 3 * nv;
+    const float dsr = (float)ds, dtr = (float)dt;
+    const int lz = threadIdx.x & 31, ly = (threadIdx.x >> 5) & 15, lxb = threadIdx.x >> 9;
+    const int j = tl.y0 + ly, k = tl.z0 + lz;
+
+    // window origin from the tile's centre voxel (uniform loads), then start moving channel 0
+    GWOrigin o;
+    {
+        const int cxi = min(tl.x0 + GW::TX / 2, g.nx - 1), cyi = min(tl.y0 + GW::TY / 2, g.ny - 1),
+                  czi = min(tl.z0 + GW::TZ / 2, g.nz - 1);
+        const uint32_t cs = ((uint32_t)cxi * (uint32_t)g.ny + (uint32_t)cyi) * (uint32_t)g.nz + (uint32_t)czi;
+        o = gw_origin(tl, g, lg_floor(sample_pos_t<float, UNIT>(cxi, ds, un[cs])),
+                      lg_floor(sample_pos_t<float, UNIT>(cyi, ds, un[nv + cs])),
+                      lg_floor(sample_pos_t<float, UNIT>(czi, ds, un[2 * nv + cs])));
+    }
+    GWLoader<NT> ld;
+    ld.plan(o, g);
+    ld.issue(vn, plane, gwin);
+
+    // byte offset of voxel e in a plane: off0 + e * estep where the voxel exists (x0 + lxb + XS e < nx, row in the grid)
+    const bool row_ok = j < g.ny && k < g.nz;
+    const uint32_t off0 = (((uint32_t)(tl.x0 + lxb) * (uint32_t)g.ny + (uint32_t)j) * (uint32_t)g.nz + (uint32_t)k) * 4u;
+    const uint32_t estep = (uint32_t)XS * (uint32_t)g.ny * (uint32_t)g.nz * 4u;
+    auto voff = [&](int e) { return row_ok && tl.x0 + lxb + XS * e < g.nx ? off0 + (uint32_t)e * estep : GW::kOutside; };
+    GWLerp L[U];
+    uint32_t outm = 0;  // bit e: sample e has a corner outside the window
+    float uu[3][U];
+    {
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) uu[d][e] = buf_load1<float>(make_rsrc(un + (size_t)d * nv, plane), voff(e));
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const int i = tl.x0 + lxb + XS * e;
+            const bool in = L[e].setup(sample_pos_t<float, UNIT>(i, ds, uu[0][e]), sample_pos_t<float, UNIT>(j, ds, uu[1][e]),
+                                       sample_pos_t<float, UNIT>(k, ds, uu[2][e]), g, o);
+            outm |= (in | (voff(e) == GW::kOutside)) ? 0u : 1u << e;
+            __builtin_amdgcn_sched_barrier(0);  // one sample at a time: interleaved, the eight setups need > 128 VGPRs
+        }
+    }
+    // Three channels through the window.  STRAY: some sample of the workgroup has a corner outside the window; those
+    // lanes take their corners with the pair gathers of Lerp3 instead (same value expression), wave by wave.
+    auto channels = [&](auto stray) {
+        constexpr bool STRAY = decltype(stray)::value;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (c > 0) __syncthreads();  // channel c's window has landed
+            float r[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                float q[8];
+                L[e].fetch(gwin, q);
+                float val = L[e].value_of(q);
+                if constexpr (STRAY) {
+                    const bool mine = outm & (1u << e);
+                    if (__builtin_amdgcn_ballot_w64(mine) != 0) {  // wave-uniform
+                        if (mine) {
+                            const int i = tl.x0 + lxb + XS * e;
+                            Lerp3<float, false> P;
+                            P.setup(sample_pos_t<float, UNIT>(i, ds, uu[0][e]), sample_pos_t<float, UNIT>(j, ds, uu[1][e]),
+                                    sample_pos_t<float, UNIT>(k, ds, uu[2][e]), g.nx, g.ny, g.nz);
+                            val = P.value(vn + (size_t)c * nv);
+                        }
+                    }
+                }
+                const float a = dsr * uu[c][e];
+                const float b = dtr * val;
+                r[e] = a + b;
+            }
+            if (c < 2) {
+                __syncthreads();  // everyone has read channel c: the window is free
+                ld.issue(vn + (size_t)(c + 1) * nv, plane, gwin);
+            }
+            // stores after the next window's loads: the wait in front of the next barrier then covers both at once
+            const BufRsrc ro = make_rsrc(on + (size_t)c * nv, plane);
+#pragma unroll
+            for (int e = 0; e < U; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r[e]), ro, voff(e), 0, 0);
+        }
+    };
+    // channel 0's window has landed behind this barrier (the compiler waits for the LDS-direct loads first)
+    if (__syncthreads_or(outm != 0))
+        channels(std::true_type{});
+    else
+        channels(std::false_type{});
+}
+
+// (explicit instantiations: hipcc 7.2 drops the host stub of a variant that is only named in the `else` of a launch)
+template __global__ void compose3_window_kernel<512, 8, true>(float *, const float *, const float *, double, double, Geom, GWGrid);
+template __global__ void compose3_window_kernel<512, 8, false>(float *, const float *, const float *, double, double, Geom, GWGrid);
+
+std::atomic<int> g_gather_window{1};  // 1: LDS-window gathers where the shape allows (default); 0: pair gathers only
+
+template <typename R>
+static bool compose_window_launch(R *out, const R *u, const R *v, double ds, double dt, const Geom &g, int64_t nn,
+                                  hipStream_t s) {
+    if constexpr (sizeof(R) == 4) {
+        GWGrid w;
+        if (!make_gwgrid(w, g, nn) || ((uintptr_t)v & 15u)) return false;
+        constexpr int NT = 512, U = 8;
+        const size_t smem = GW::lds_bytes<NT>();
+        if (unit_dt<R>(ds))
+            hipLaunchKernelGGL((compose3_window_kernel<NT, U, true>), dim3(w.total), dim3(NT), smem, s, out, u, v, ds, dt, g, w);
+        else
+            hipLaunchKernelGGL((compose3_window_kernel<NT, U, false>), dim3(w.total), dim3(NT), smem, s, out, u, v, ds, dt, g, w);
+        return true;
+    }
+    return false;
+}
+
 template <typename R>
 static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, int dim, int64_t nn, int64_t nx,
                         int64_t ny, int64_t nz, void *stream) {
@@ -119,6 +246,8 @@ static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, in
     if (!out || !u || !v) return fail_invalid("compose: null pointer");
     hipStream_t s = (hipStream_t)stream;
     constexpr int U = 2;
+    if (dim == 3 && g_interp_vec && g_gather_window && g.nvox >= 32768u && compose_window_launch(out, u, v, ds, dt, g, nn, s))
+        return finish_launch(s, "compose");
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;
@@ -511,6 +640,7 @@ int lincomb_impl(R *out, int k, const R *x0, const R *x1, const R *x2, const R *
 
 extern "C" {
 void lago_set_stencil_tile(int on) { lago::g_stencil_tile = on ? 1 : 0; }
+void lago_set_gather_window(int on) { lago::g_gather_window = on ? 1 : 0; }
 int lago_lincomb_f32(float *out, int k, const float *x0, const float *x1, const float *x2, const float *x3, double c0,
                      double c1, double c2, double c3, int64_t n, void *stream) {
     return lago::lincomb_impl<float>(out, k, x0, x1, x2, x3, c0, c1, c2, c3, n, stream);

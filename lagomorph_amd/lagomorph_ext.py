@@ -84,7 +84,7 @@ _lib.lago_set_splat_tile.argtypes = [_int] * 7
 _lib.lago_set_vector_kernels.argtypes = [_int]
 _lib.lago_set_splat_shear.argtypes = [_int] * 8
 _lib.lago_set_fluid_xpass.argtypes = [_int]
-for _name in ("lago_set_launch_order", "lago_set_stencil_tile", "lago_set_splat_mc", "lago_set_splat_shear_mc", "lago_set_fluid_xpass_ipw", "lago_set_fluid_zy_persist",
+for _name in ("lago_set_launch_order", "lago_set_stencil_tile", "lago_set_gather_window", "lago_set_splat_mc", "lago_set_splat_shear_mc", "lago_set_fluid_xpass_ipw", "lago_set_fluid_zy_persist",
               "lago_set_fluid_xpass_wide"):
     getattr(_lib, _name).argtypes = [_int]
 
@@ -192,6 +192,12 @@ def set_stencil_tile(on):
     """1 (default): LDS row-tile stencil kernels (Ad_star, jacobian_times_vectorfield_backward) where shapes allow;
     0: the direct one-lane-per-voxel kernels.  Same bits."""
     _lib.lago_set_stencil_tile(1 if on else 0)
+
+
+def set_gather_window(on):
+    """1 (default): float32 3D gathers through an LDS window (compose, Ad_star) where shapes allow; 0: pair gathers
+    through the vector L1 only.  Same bits."""
+    _lib.lago_set_gather_window(1 if on else 0)
 
 
 def set_vector_kernels(on):

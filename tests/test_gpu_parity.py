@@ -359,6 +359,57 @@ def test_fused_compose_bit_exact(ext, dtype, sp):
         assert torch.equal(ext.compose(ud, vd, ds, dt), ds * ud + dt * ext.interp_forward(vd, ud, ds))
 
 
+def _smooth_disp(rng, nn, sp, amp, shift, rough=0.0):
+    """A smooth displacement (what the LDS-window gathers are for): a few low-frequency waves of amplitude `amp` plus
+    a constant shift per item and component, optionally with `rough` voxels of noise on top."""
+    grids = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in sp], indexing="ij")
+    u = np.empty((nn, 3) + sp, np.float64)
+    for n in range(nn):
+        for c in range(3):
+            k = rng.uniform(0.02, 0.12, 3) * rng.choice([-1, 1], 3)
+            u[n, c] = amp * np.sin(sum(kk * g for kk, g in zip(k, grids)) + rng.uniform(0, 6)) + shift * rng.uniform(-1, 1)
+    if rough:
+        u += rough * rng.standard_normal(u.shape)
+    return u.astype(np.float32)
+
+
+WINDOW_CASES = [
+    # shape, amplitude, shift, rough: (window for every tile) ... (pair-gather path for most)
+    ((16, 32, 64), 0.6, 0.0, 0.0),
+    ((16, 32, 64), 1.5, 7.3, 0.0),     # a translated window
+    ((24, 16, 36), 1.2, 2.5, 0.0),     # partially filled tiles in x and z
+    ((8, 48, 32), 0.8, 40.0, 0.0),     # displaced past the grid: clamped corners, windows half outside
+    ((16, 32, 64), 1.0, 3.0, 0.4),     # a few samples leave their windows: those workgroups take the pair path
+    ((16, 32, 64), 6.0, 0.0, 3.0),     # nothing fits
+    ((40, 16, 32), 0.7, -5.5, 0.0),
+]
+
+
+@pytest.mark.parametrize("case", WINDOW_CASES, ids=[f"{c[0]}-a{c[1]}-s{c[2]}-r{c[3]}" for c in WINDOW_CASES])
+def test_lds_window_gather_compose_same_bits(ext, case):
+    """compose through the LDS window == the pair-gather kernel == the oracle, bit for bit:
+    window placement and the per-workgroup choice of path never show in the result."""
+    import lagomorph_amd.lagomorph_ext as shim
+
+    sp, amp, shift, rough = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    u = _smooth_disp(rng, 3, sp, amp, shift, rough)
+    u.reshape(-1)[::997] = np.round(u.reshape(-1)[::997])  # exact-integer positions
+    v = rnd(rng, (3, 3) + sp, torch.float32)
+    ud, vd = dev(u), dev(v)
+    try:
+        for ds, dt in ((1.0, -0.1), (-1.0, 1.0), (0.7, -1.3)):
+            want = np.float32(ds) * u + np.float32(dt) * orc.interp_forward(v, u, ds)
+            outs = {}
+            for mode in (0, 1):
+                shim.set_gather_window(mode)
+                outs[mode] = ext.compose(ud, vd, ds, dt)
+                assert_bits(outs[mode], want, f"compose window mode {mode} ds={ds}")
+            assert torch.equal(outs[1], outs[0])
+    finally:
+        shim.set_gather_window(1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp", [(8, 6, 10), (7, 5, 9), (16, 16, 16), (12, 10), (9, 7)])
 @pytest.mark.parametrize("inverse", [True, False])
