@@ -73,7 +73,7 @@ void lago_set_launch_order(int alternate);
  * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows; 0: every
  * neighbour is loaded from global memory.  Same bits. */
 void lago_set_stencil_tile(int on);
-/* 1 (default): float32 3D trilinear gathers of smooth fields (compose, Ad_star's momentum) stage the source block of a
+/* 1 (default): float32 3D trilinear gathers of smooth fields (compose) stage the source block of a
  * tile of voxels in LDS with LDS-direct loads and take the corners from there (csrc/gather_window.hpp) where the
  * shape allows; a workgroup whose samples leave its window, and every other shape, uses the pair gathers through the
  * vector L1; 0: pair gathers only.  Same bits. */

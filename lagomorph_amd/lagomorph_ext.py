@@ -195,9 +195,13 @@ def set_stencil_tile(on):
 
 
 def set_gather_window(on):
-    """1 (default): float32 3D gathers through an LDS window (compose, Ad_star) where shapes allow; 0: pair gathers
+    """1 (default): float32 3D gathers through an LDS window (compose) where shapes allow; 0: pair gathers
     through the vector L1 only.  Same bits."""
     _lib.lago_set_gather_window(1 if on else 0)
+
+
+if os.environ.get("LAGO_GATHER_WINDOW") is not None:  # profiling convenience: A/B under rocprofv3 without code changes
+    set_gather_window(int(os.environ["LAGO_GATHER_WINDOW"]))
 
 
 def set_vector_kernels(on):

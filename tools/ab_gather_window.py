@@ -54,6 +54,25 @@ def main():
                 row2.append(timeit(lambda: lm.Ad_star(u, v), reps))
             print(f"{nn}x3x{sp[0]}^3 amp {amp:4.1f} shift {shift:3.1f}: compose pair {row[0]:7.1f} us  window {row[1]:7.1f}  "
                   f"same bits {same} | Ad_star pair {row2[0]:7.1f}  window {row2[1]:7.1f}", flush=True)
+    # the headline workload's own fields: displacement after k Euler steps of bench.py's shoot, velocity of the next step
+    from bench import gaussian_blur
+
+    metric = lm.FluidMetric([0.1, 0.0, 0.01])
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        m = gaussian_blur(torch.randn((32, 3, 128, 128, 128), device="cuda"), 4.0)
+        m *= 5.0 / metric.sharp(m).abs().max()
+        for ksteps in (2, 5, 9):
+            h = lm.expmap(metric, m, num_steps=10)  # dt = 1/10 per step
+            h = lm.expmap(metric, m * (ksteps / 10.0), num_steps=ksteps)  # the same flow stopped after k of 10 steps
+            v = metric.sharp(lm.Ad_star(h, m))
+            row = []
+            for mode in (0, 1):
+                ext.set_gather_window(mode)
+                row.append(timeit(lambda: ext.compose(h, v, 1.0, -0.1), reps))
+            gx = (h[:, :, 1:] - h[:, :, :-1]).abs().max().item()
+            print(f"bench fields after {ksteps}/10 steps: |h|max {h.abs().max().item():.2f}, max |dh/dx| {gx:.2f}: compose pair "
+                  f"{row[0]:7.1f} us  window {row[1]:7.1f}", flush=True)
     ext.set_gather_window(1)
 
 
