@@ -78,6 +78,9 @@ void lago_set_stencil_tile(int on);
  * shape allows; a workgroup whose samples leave its window, and every other shape, uses the pair gathers through the
  * vector L1; 0: pair gathers only.  Same bits. */
 void lago_set_gather_window(int on);
+/* Number of launches so far in this process that took an LDS-window kernel (the tests use it to make sure a shape
+ * meant to exercise that path does). */
+long long lago_gather_window_launches(void);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
  * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
  * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z)

@@ -194,6 +194,15 @@ def set_stencil_tile(on):
     _lib.lago_set_stencil_tile(1 if on else 0)
 
 
+_lib.lago_gather_window_launches.restype = ctypes.c_longlong
+_lib.lago_gather_window_launches.argtypes = []
+
+
+def gather_window_launches():
+    """Launches so far that took an LDS-window kernel."""
+    return int(_lib.lago_gather_window_launches())
+
+
 def set_gather_window(on):
     """1 (default): float32 3D gathers through an LDS window (compose) where shapes allow; 0: pair gathers
     through the vector L1 only.  Same bits."""

@@ -17,7 +17,7 @@ def declared_symbols():
     names = set()
     for m in re.finditer(r"\b(lago_\w+)##SUF\s*\(", text):
         names.update({m.group(1) + "_f32", m.group(1) + "_f64"})
-    for m in re.finditer(r"^\s*(?:int|void|const char \*)\s*\*?(lago_\w+)\s*\(", text, re.M):
+    for m in re.finditer(r"^\s*(?:int|void|long long|const char \*)\s*\*?(lago_\w+)\s*\(", text, re.M):
         names.add(m.group(1))
     return sorted(names)
 

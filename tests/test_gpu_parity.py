@@ -377,11 +377,14 @@ WINDOW_CASES = [
     # shape, amplitude, shift, rough: (window for every tile) ... (pair-gather path for most)
     ((16, 32, 64), 0.6, 0.0, 0.0),
     ((16, 32, 64), 1.5, 7.3, 0.0),     # a translated window
-    ((24, 16, 36), 1.2, 2.5, 0.0),     # partially filled tiles in x and z
-    ((8, 48, 32), 0.8, 40.0, 0.0),     # displaced past the grid: clamped corners, windows half outside
+    ((28, 32, 64), 1.2, 2.5, 0.0),     # last tile in x half empty (28 = 3.5 tiles; fill 0.875 >= 0.85: window path)
+    ((24, 30, 64), 0.9, -1.5, 0.0),    # ragged in y
+    ((24, 32, 60), 0.9, 1.5, 0.0),     # ragged in z (60 = 1.875 tiles, still a multiple of 4)
+    ((24, 16, 36), 1.2, 2.5, 0.0),     # fill 0.56: stays on the pair-gather kernel
+    ((16, 48, 64), 0.8, 40.0, 0.0),    # displaced past the grid: clamped corners, windows half outside
     ((16, 32, 64), 1.0, 3.0, 0.4),     # a few samples leave their windows: those workgroups take the pair path
     ((16, 32, 64), 6.0, 0.0, 3.0),     # nothing fits
-    ((40, 16, 32), 0.7, -5.5, 0.0),
+    ((40, 32, 32), 0.7, -5.5, 0.0),
 ]
 
 
@@ -403,7 +406,11 @@ def test_lds_window_gather_same_bits(ext, case):
             outs = {}
             for mode in (0, 1):
                 shim.set_gather_window(mode)
+                before = shim.gather_window_launches()
                 outs[mode] = ext.compose(ud, vd, ds, dt)
+                took = shim.gather_window_launches() - before
+                # every case but the 0.56-fill one must really run the window kernel when it is on
+                assert took == (1 if mode == 1 and sp != (24, 16, 36) else 0), (mode, sp, took)
                 assert_bits(outs[mode], want, f"compose window mode {mode} ds={ds}")
             assert torch.equal(outs[1], outs[0])
         # Ad_star is unaffected by the switch (its window form was measured slower and is not shipped)
