@@ -78,9 +78,20 @@ void lago_set_stencil_tile(int on);
  * shape allows; a workgroup whose samples leave its window, and every other shape, uses the pair gathers through the
  * vector L1; 0: pair gathers only.  Same bits. */
 void lago_set_gather_window(int on);
-/* Number of launches so far in this process that took an LDS-window kernel (the tests use it to make sure a shape
- * meant to exercise that path does). */
-long long lago_gather_window_launches(void);
+/* Which implementation calls were dispatched to: number of launches so far in this process per path (telemetry; the
+ * tests use it to make sure a case meant to exercise a fast path really runs it).  -1 for an unknown id. */
+#define LAGO_PATH_GATHER_WINDOW 0  /* compose through the LDS window */
+#define LAGO_PATH_STENCIL_TILE 1   /* Ad_star row-tile kernel */
+#define LAGO_PATH_VECTOR_GATHER 2  /* slab-unrolled 3D gather kernels (interp_forward, compose, Ad_star) */
+#define LAGO_PATH_SPLAT_SHEAR 3    /* sheared-window splat */
+#define LAGO_PATH_SPLAT_SHEAR_MC 4 /* its geometry-once multi-channel form */
+#define LAGO_PATH_SPLAT_TILED 5    /* tiled LDS splat */
+#define LAGO_PATH_SPLAT_GLOBAL 6   /* global-atomics splat (the reference's form) */
+#define LAGO_PATH_FLUID_LDS 7      /* lago_fluid_metric: three hand-written FFT passes */
+#define LAGO_PATH_FLUID_2D 8       /* lago_fluid_metric: one fused 2D kernel */
+#define LAGO_PATH_FLUID_XPASS 9    /* lago_fluid_metric: rocFFT (y, z) plan + fused x pass */
+#define LAGO_PATH_FLUID_ROCFFT 10  /* lago_fluid_metric: rocFFT plan + operator kernel */
+long long lago_path_launches(int path);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
  * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
  * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z)

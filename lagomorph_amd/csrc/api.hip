@@ -9,6 +9,7 @@ namespace lago {
 static std::atomic<int> g_debug{0};
 std::atomic<int> g_splat_mode{1};
 std::atomic<int> g_interp_vec{1};
+std::atomic<long long> g_path_launches[LP_COUNT];
 std::atomic<int> g_launch_alt{1};
 std::atomic<unsigned> g_launch_seq{0};
 static thread_local char g_err[512] = "";
@@ -49,5 +50,8 @@ const char *lago_last_error(void) { return lago::g_err; }
 void lago_set_splat_mode(int mode) { lago::g_splat_mode = mode; }
 int lago_get_splat_mode(void) { return lago::g_splat_mode; }
 void lago_set_vector_kernels(int on) { lago::g_interp_vec = on ? 1 : 0; }
+long long lago_path_launches(int path) {
+    return path >= 0 && path < lago::LP_COUNT ? lago::g_path_launches[path].load() : -1;
+}
 void lago_set_launch_order(int alternate) { lago::g_launch_alt = alternate ? 1 : 0; }
 }

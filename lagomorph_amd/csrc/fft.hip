@@ -391,9 +391,11 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
     if (!out || !m || !work) return fail_invalid("fluid_metric: null pointer");
     // 2D float32 fields whose two component planes fit the LDS together: one kernel for the whole operator (fft3.hip)
     if (sizeof(R) == 4 && dim == 2 && g_fluid_xpass >= 2 && fluid2d_supported(nx, ny) && nn < (1ll << 31) &&
-        (((uintptr_t)out | (uintptr_t)m) & 15) == 0)
+        (((uintptr_t)out | (uintptr_t)m) & 15) == 0) {
+        note_path(LP_FLUID_2D);
         return fluid_metric_2d((float *)out, (const float *)m, inverse, (const float *)cosX, (const float *)sinX,
                                (const float *)cosY, (const float *)sinY, alpha, beta, gamma, nn, nx, ny, (hipStream_t)stream);
+    }
     // the table-based fast paths need a LUT generation to key their cached coefficient table on
     if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass >= 2 && fluid_native_supported(nx, ny, nz) &&
         (((uintptr_t)out | (uintptr_t)m | (uintptr_t)work) & 15) == 0) {  // 16-byte vector accesses
@@ -402,13 +404,17 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
                           (const float *)sinY, (const float *)cosZ, (const float *)sinZ, alpha, beta, gamma, nx, ny,
                           nz, 1, (hipStream_t)stream);
         if (rc != LAGO_OK) return rc;
+        note_path(LP_FLUID_LDS);
         return fluid_metric_native((float *)out, (const float *)m, (float *)work, tab->d, inverse, nn, nx, ny, nz,
                                    1.0 / ((double)nx * (double)ny * (double)nz), (hipStream_t)stream);
     }
-    if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass && fluid_xpass_supported(nx) && nn * 3 * nx < (1ll << 31))
+    if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass && fluid_xpass_supported(nx) && nn * 3 * nx < (1ll << 31)) {
+        note_path(LP_FLUID_XPASS);
         return fluid_metric_xpass((float *)out, (const float *)m, (float *)work, gen, inverse, (const float *)cosX,
                                   (const float *)sinX, (const float *)cosY, (const float *)sinY, (const float *)cosZ,
                                   (const float *)sinZ, alpha, beta, gamma, nn, nx, ny, nz, (hipStream_t)stream);
+    }
+    note_path(LP_FLUID_ROCFFT);
     const int n[3] = {(int)nx, (int)ny, (int)nz};
     FftPlan p;
     int rc = get_plan(p, dim, n, (int)(nn * dim), sizeof(R) == 8);

@@ -218,7 +218,6 @@ template __global__ void compose3_window_kernel<512, 8, true>(float *, const flo
 template __global__ void compose3_window_kernel<512, 8, false>(float *, const float *, const float *, double, double, Geom, GWGrid);
 
 std::atomic<int> g_gather_window{1};  // 1: LDS-window gathers where the shape allows (default); 0: pair gathers only
-std::atomic<long long> g_gather_window_launches{0};  // launches that took an LDS-window kernel (telemetry for the tests)
 
 template <typename R>
 static bool compose_window_launch(R *out, const R *u, const R *v, double ds, double dt, const Geom &g, int64_t nn,
@@ -232,7 +231,7 @@ static bool compose_window_launch(R *out, const R *u, const R *v, double ds, dou
             hipLaunchKernelGGL((compose3_window_kernel<NT, U, true>), dim3(w.total), dim3(NT), smem, s, out, u, v, ds, dt, g, w);
         else
             hipLaunchKernelGGL((compose3_window_kernel<NT, U, false>), dim3(w.total), dim3(NT), smem, s, out, u, v, ds, dt, g, w);
-        ++g_gather_window_launches;
+        note_path(LP_GATHER_WINDOW);
         return true;
     }
     return false;
@@ -260,6 +259,7 @@ static int compose_impl(R *out, const R *u, const R *v, double ds, double dt, in
             else
                 hipLaunchKernelGGL((compose3_unroll_kernel<R, U, false>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, u, v,
                                    ds, dt, g, nbx_u, (uint32_t)nb);
+            note_path(LP_VECTOR_GATHER);
             return finish_launch(s, "compose");
         }
     }
@@ -551,6 +551,7 @@ static bool ad_star_tile_launch(R *out, R *mphi, const R *phi, const R *m, const
     else if (zc == 4) LAGO_ADT(4);
     else return false;
 #undef LAGO_ADT
+    note_path(LP_STENCIL_TILE);
     return true;
 }
 
@@ -576,6 +577,7 @@ static int ad_star_impl(R *out, R *mphi, const R *phi, const R *m, int dim, int6
         if (nb < (1ull << 31)) {
             hipLaunchKernelGGL((ad_star3_unroll_kernel<R, U>), dim3((uint32_t)nb), dim3(kBlock), 0, s, out, mphi, phi, m, g,
                                nbx_u, (uint32_t)nb);
+            note_path(LP_VECTOR_GATHER);
             return finish_launch(s, "ad_star");
         }
     }
@@ -643,7 +645,6 @@ int lincomb_impl(R *out, int k, const R *x0, const R *x1, const R *x2, const R *
 extern "C" {
 void lago_set_stencil_tile(int on) { lago::g_stencil_tile = on ? 1 : 0; }
 void lago_set_gather_window(int on) { lago::g_gather_window = on ? 1 : 0; }
-long long lago_gather_window_launches(void) { return lago::g_gather_window_launches.load(); }
 int lago_lincomb_f32(float *out, int k, const float *x0, const float *x1, const float *x2, const float *x3, double c0,
                      double c1, double c2, double c3, int64_t n, void *stream) {
     return lago::lincomb_impl<float>(out, k, x0, x1, x2, x3, c0, c1, c2, c3, n, stream);

@@ -232,6 +232,7 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
                 if (unit) LAUNCH_U(false, true); else LAUNCH_U(false, false);
             }
 #undef LAUNCH_U
+            note_path(LP_VECTOR_GATHER);
             return finish_launch(s, "interp_forward");
         }
     }
@@ -291,6 +292,7 @@ static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R
         int rc = interp_backward_lds<R>(d_I, d_u, go, I, u, dt, (int)nc, nn, g, bc != 0, need_u != 0, umode, addgo, s);
         if (rc != 1) return rc;  // 1 = shape not supported by the tiled kernel, fall through
     }
+    note_path(LP_SPLAT_GLOBAL);
     if (dim == 3) {
         if (bc) launch_bwd<R, 3, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, umode, addgo, s);
         else launch_bwd<R, 3, false>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, umode, addgo, s);

@@ -1026,6 +1026,7 @@ static int interp_backward_shear(float *d_I, float *d_u, const float *go, const 
         if (unit) { if (bc) LAGO_SHEAR_MC(true, true); else LAGO_SHEAR_MC(true, false); }
         else { if (bc) LAGO_SHEAR_MC(false, true); else LAGO_SHEAR_MC(false, false); }
 #undef LAGO_SHEAR_MC
+        note_path(LP_SPLAT_SHEAR_MC);
         return finish_launch(s, "interp_backward (sheared-window splat)");
     }
     if (!make_shear(sg, g, nn, smem)) return 1;
@@ -1033,6 +1034,7 @@ static int interp_backward_shear(float *d_I, float *d_u, const float *go, const 
     else if (shear_nt >= 512) e = launch_shear<512>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
     else e = launch_shear<256>(d_I, d_u, go, I, u, dt, nc, sg, smem, bc, need_u, umode, addgo, s);
     if (e != hipSuccess) return fail_hip(e, "interp_backward (sheared-window splat)");
+    note_path(LP_SPLAT_SHEAR);
     return finish_launch(s, "interp_backward (sheared-window splat)");
 }
 
@@ -1182,6 +1184,7 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
         }
 #undef GOMC
         if (e != hipSuccess) return fail_hip(e, "interp_backward (tiled splat)");
+        note_path(LP_SPLAT_TILED);
         return finish_launch(s, "interp_backward (tiled splat)");
     }
 #define GO(B, U) \
@@ -1195,6 +1198,7 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     }
 #undef GO
     if (e != hipSuccess) return fail_hip(e, "interp_backward (tiled splat)");
+    note_path(LP_SPLAT_TILED);
     return finish_launch(s, "interp_backward (tiled splat)");
 }
 

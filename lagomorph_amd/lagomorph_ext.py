@@ -194,13 +194,17 @@ def set_stencil_tile(on):
     _lib.lago_set_stencil_tile(1 if on else 0)
 
 
-_lib.lago_gather_window_launches.restype = ctypes.c_longlong
-_lib.lago_gather_window_launches.argtypes = []
+_lib.lago_path_launches.restype = ctypes.c_longlong
+_lib.lago_path_launches.argtypes = [_int]
+PATHS = ("gather_window", "stencil_tile", "vector_gather", "splat_shear", "splat_shear_mc", "splat_tiled", "splat_global",
+         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
 
 
-def gather_window_launches():
-    """Launches so far that took an LDS-window kernel."""
-    return int(_lib.lago_gather_window_launches())
+def path_launches(name=None):
+    """Launches so far per implementation path (a dict), or of one path by name."""
+    if name is not None:
+        return int(_lib.lago_path_launches(PATHS.index(name)))
+    return {p: int(_lib.lago_path_launches(i)) for i, p in enumerate(PATHS)}
 
 
 def set_gather_window(on):

@@ -1,0 +1,84 @@
+"""Which kernel a call really runs.  Every fast path has a slower sibling that gives the same answer, so a parity test
+cannot tell them apart; `lago_path_launches` (include/lagomorph_hip.h) can.  These cases pin the dispatch of the
+BASELINE.json shapes and of the small shapes the parity tests use to exercise each path."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lm():
+    import lagomorph_amd
+
+    return lagomorph_amd
+
+
+def _delta(shim, f):
+    before = shim.path_launches()
+    f()
+    torch.cuda.synchronize()
+    after = shim.path_launches()
+    return {k: after[k] - before[k] for k in after if after[k] != before[k]}
+
+
+def _fields(n, c, sp, dtype=torch.float32):
+    g = torch.Generator(device="cuda").manual_seed(7)
+    return torch.randn((n, c) + sp, device="cuda", dtype=dtype, generator=g)
+
+
+@pytest.mark.parametrize("sp", [(128, 128, 128), (160, 160, 160), (32, 32, 32), (28, 32, 64)])
+def test_headline_operators_take_their_fast_paths(lm, sp):
+    """float32 3D at configs[1] / configs[4] extents (batch 1) and at the smallest shapes that qualify."""
+    shim = lm.lagomorph_ext
+    u, v = 0.5 * _fields(1, 3, sp), _fields(1, 3, sp)
+    assert _delta(shim, lambda: shim.compose(u, v, 1.0, -0.1)) == {"gather_window": 1}
+    # one 32^3 item is too small for the row tiles (make_row_tile wants full workgroups): it takes the direct kernel
+    assert _delta(shim, lambda: shim.Ad_star(u, v)) == {"vector_gather" if sp == (32, 32, 32) else "stencil_tile": 1}
+    I = _fields(1, 1, sp)
+    assert _delta(shim, lambda: shim.interp_forward(I, u, 1.0)) == {"vector_gather": 1}
+    go = _fields(1, 1, sp)
+    assert _delta(shim, lambda: shim.interp_backward(go, I, u, 1.0, True, True)) == {"splat_shear": 1}
+    go3 = _fields(1, 3, sp)
+    assert _delta(shim, lambda: shim.interp_backward(go3, v, u, -0.1, True, True)) == {"splat_shear_mc": 1}
+
+
+@pytest.mark.parametrize("sp,path", [((128, 128, 128), "fluid_lds"), ((160, 160, 160), "fluid_lds"), ((64, 96, 128), "fluid_lds"),
+                                     ((64, 40, 40), "fluid_xpass"), ((24, 20, 28), "fluid_rocfft"),
+                                     ((128, 128), "fluid_2d"), ((64, 256), "fluid_2d"), ((100, 100), "fluid_rocfft")])
+def test_fluid_metric_dispatch(lm, sp, path):
+    metric = lm.FluidMetric([0.1, 0.0, 0.01])
+    m = _fields(2, len(sp), sp)
+    assert _delta(lm.lagomorph_ext, lambda: metric.sharp(m)) == {path: 1}
+    assert _delta(lm.lagomorph_ext, lambda: metric.flat(m)) == {path: 1}
+
+
+def test_the_switches_select_the_slower_siblings(lm):
+    shim = lm.lagomorph_ext
+    sp = (32, 32, 32)
+    u, v = 0.5 * _fields(1, 3, sp), _fields(1, 3, sp)
+    try:
+        shim.set_gather_window(0)
+        assert _delta(shim, lambda: shim.compose(u, v, 1.0, -0.1)) == {"vector_gather": 1}
+        shim.set_stencil_tile(0)
+        assert _delta(shim, lambda: shim.Ad_star(u, v)) == {"vector_gather": 1}
+        shim.set_vector_kernels(0)
+        assert _delta(shim, lambda: shim.compose(u, v, 1.0, -0.1)) == {}
+        assert _delta(shim, lambda: shim.interp_backward(v, v, u, -0.1, True, True)) == {"splat_tiled": 1}
+        shim.set_splat_mode(0)
+        assert _delta(shim, lambda: shim.interp_backward(v, v, u, -0.1, True, True)) == {"splat_global": 1}
+    finally:
+        shim.set_gather_window(1)
+        shim.set_stencil_tile(1)
+        shim.set_vector_kernels(1)
+        shim.set_splat_mode(1)
+
+
+def test_float64_and_2d_take_the_general_kernels(lm):
+    shim = lm.lagomorph_ext
+    u, v = 0.5 * _fields(1, 3, (32, 32, 32), torch.float64), _fields(1, 3, (32, 32, 32), torch.float64)
+    assert _delta(shim, lambda: shim.compose(u, v, 1.0, -0.1)) == {"vector_gather": 1}
+    assert _delta(shim, lambda: shim.interp_backward(v, v, u, -0.1, True, True)) == {"splat_tiled": 1}
+    u2, v2 = 0.5 * _fields(1, 2, (64, 64)), _fields(1, 2, (64, 64))
+    assert _delta(shim, lambda: shim.compose(u2, v2, 1.0, -0.1)) == {}
+    assert _delta(shim, lambda: shim.interp_backward(v2, v2, u2, -0.1, True, True)) == {"splat_global": 1}

@@ -406,9 +406,9 @@ def test_lds_window_gather_same_bits(ext, case):
             outs = {}
             for mode in (0, 1):
                 shim.set_gather_window(mode)
-                before = shim.gather_window_launches()
+                before = shim.path_launches("gather_window")
                 outs[mode] = ext.compose(ud, vd, ds, dt)
-                took = shim.gather_window_launches() - before
+                took = shim.path_launches("gather_window") - before
                 # every case but the 0.56-fill one must really run the window kernel when it is on
                 assert took == (1 if mode == 1 and sp != (24, 16, 36) else 0), (mode, sp, took)
                 assert_bits(outs[mode], want, f"compose window mode {mode} ds={ds}")
