@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (c > 0) __syncthreads();  // channel c's window has landed
-            float r[U];
+            const BufRsrc ro = make_rsrc(on + (size_t)c * nv, plane);
 #pragma unroll
             for (int e = 0; e < U; ++e) {
                 float q[8];
@@ -194,16 +194,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
                 }
                 const float a = dsr * uu[c][e];
                 const float b = dtr * val;
-                r[e] = a + b;
+                // stored at once: holding the eight results back until the next window's loads are issued (one wait
+                // for both) cost four spilled values -- 134 MB of scratch writes per launch at 32 x 3 x 128^3, 11 % of
+                // the kernel's time
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a + b), ro, voff(e), 0, 0);
             }
             if (c < 2) {
                 __syncthreads();  // everyone has read channel c: the window is free
                 ld.issue(vn + (size_t)(c + 1) * nv, plane, gwin);
             }
-            // stores after the next window's loads: the wait in front of the next barrier then covers both at once
-            const BufRsrc ro = make_rsrc(on + (size_t)c * nv, plane);
-#pragma unroll
-            for (int e = 0; e < U; ++e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r[e]), ro, voff(e), 0, 0);
         }
     };
     // channel 0's window has landed behind this barrier (the compiler waits for the LDS-direct loads first)

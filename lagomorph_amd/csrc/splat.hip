@@ -817,7 +817,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
                     Z0 = (OG[it] & 1u) ? 4u : 0u;              // floor beyond the upper face: both cells are nz - 1 = zb + 1
                     Z1 = (OG[it] & 2u) ? 0u : 4u;              // floor below the lower face: both cells are 0 = zb
                 } else {
-                    const uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+                    uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+                    // opaque: otherwise the coordinates of this rare path, converted to double, are hoisted out of the
+                    // channel loop and SPILLED by every lane (ten dwords: 335 MB of scratch writes per launch at 8 x 3 x 128^3)
+                    asm volatile("" : "+v"(tt));
                     const uint32_t a = sg.d_TyTz.div(tt);
                     const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
                     const uint32_t b = sg.d_Tz.div(rr);
@@ -853,7 +856,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
                 gy = lg_fma(omv, lg_fma(omt, c3 - c0, t * (c2 - c1)), v * lg_fma(omt, c7 - c4, t * (c6 - c5)));
                 gz = lg_fma(omu, lg_fma(omt, c4 - c0, t * (c5 - c1)), uu * lg_fma(omt, c7 - c3, t * (c6 - c2)));
             } else {  // rows clamped (a sample outside the grid): position again, same expressions, same bits
-                const uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+                uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+                asm volatile("" : "+v"(tt));  // as above: nothing of this path may be hoisted out of the channel loop
                 const uint32_t a = sg.d_TyTz.div(tt);
                 const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
                 const uint32_t b = sg.d_Tz.div(rr);
@@ -1171,6 +1175,9 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
     const bool unit = unit_dt<R>(dt);
     // several channels with d_u wanted: the single-pass multi-channel form when one workgroup pass
     // covers the tile (1024 threads x 4 voxels for the default 4096-voxel tile)
+    // (float32 only: the float64 instantiations of this form need 125 spilled registers at 128 VGPRs; float64 takes the
+    // per-channel passes below)
+    if constexpr (sizeof(R) == 4)
     if (g_splat_mc && vec && need_u && nc > 1 && tg.tile_groups <= 1024u * V) {
         const int ntm = tg.tile_groups <= 256u * V ? 256 : (tg.tile_groups <= 512u * V ? 512 : 1024);
 #define GOMC(M, B)                                                                                                 \
