@@ -222,7 +222,17 @@ def test_fused_operators_128cubed(lm):
     assert torch.equal(ext.Ad_star(phi, m), two)
     three = ext.jacobian_times_vectorfield_forward(phi, m, False, True) - ext.jacobian_times_vectorfield_adjoint_forward(m, phi)
     assert torch.equal(ext.ad_star(phi, m), three)
-    assert torch.equal(ext.compose(phi, m, -0.1, 1.0), -0.1 * phi + 1.0 * ext.interp_forward(m, phi, -0.1))
+    before = ext.path_launches("gather_window")
+    comp = ext.compose(phi, m, -0.1, 1.0)
+    assert ext.path_launches("gather_window") == before + 1   # the LDS-window kernel, against the pair-gather interp:
+    assert torch.equal(comp, -0.1 * phi + 1.0 * ext.interp_forward(m, phi, -0.1))
+    # and one item against the oracle, bit for bit (a 4-voxel deformation: windows translated, a few strays)
+    p0, m0 = phi[:1].cpu().numpy(), m[:1].cpu().numpy()
+    want = np.float32(-0.1) * p0 + np.float32(1.0) * orc.interp_forward(m0, p0, -0.1)
+    assert np.array_equal(comp[:1].cpu().numpy(), want)
+    big = phi * 3.0                                            # 12 voxels, gradients up to ~1: many strays
+    comp = ext.compose(big, m, 1.0, -0.1)
+    assert torch.equal(comp, 1.0 * big + -0.1 * ext.interp_forward(m, big, 1.0))
     met = lm.FluidMetric([0.1, 0.0, 0.01])
     try:
         got = {}
