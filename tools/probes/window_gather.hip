@@ -95,6 +95,89 @@ __global__ __launch_bounds__(256) void k_pair(float *__restrict__ out, const flo
     }
 }
 
+// ---------------------------------------------------------------- K0p: pair gathers + an L2-warming wave
+// Hypothesis (profiles/r03_tcp_counters.md): the vector L1 returns in order, so gather hits queue behind the misses of
+// the streamed operands.  A fifth wave of every workgroup touches, through the SCALAR cache (a different path), the
+// lines a later workgroup of the same XCD will stream -- u of block b + 8 D, and the leading-edge slab of v -- so that
+// those become L2 hits.  Blocks go round-robin over the 8 XCDs, so b + 8 D shares b's L2.
+template <int U>
+__global__ __launch_bounds__(320) void k_pair_pf(float *__restrict__ out, const float *__restrict__ u,
+                                                 const float *__restrict__ v, float ds, float dt, int D, int vslab) {
+    if (threadIdx.x >= 256) {
+        if (D <= 0) return;
+        const unsigned nbx = (unsigned)(NV / (256 * U));
+        const unsigned tb = blockIdx.x + 8u * (unsigned)D;
+        if (tb >= gridDim.x) return;
+        const unsigned n = tb / nbx, bx = tb - n * nbx;
+        // 512 voxels x 3 channels of u: 16 lines of 128 B per channel; v the same range `vslab` slabs ahead
+        const char *ub = reinterpret_cast<const char *>(u + (size_t)n * 3 * NV + (size_t)bx * 256 * U);
+        const char *vb = reinterpret_cast<const char *>(v + (size_t)n * 3 * NV + (size_t)bx * 256 * U + (size_t)vslab * NY * NZ);
+        const bool vok = bx * 256 * U + (size_t)vslab * NY * NZ + 256 * U <= NV;
+        int acc = 0;
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            int t0[16], t1[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {  // 32 scalar loads in flight, then one wait
+                const char *pu = ub + (size_t)c * NV * 4 + l * 128;
+                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t0[l]) : "s"(pu) : "memory");
+                const char *pv = (vok ? vb : ub) + (size_t)c * NV * 4 + l * 128;
+                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t1[l]) : "s"(pv) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int l = 0; l < 16; ++l) acc += t0[l] + t1[l];
+        }
+        if (acc == 0x7fffffff) out[0] = 0.f;  // keep the loads
+        return;
+    }
+    const unsigned nbx = (unsigned)(NV / (256 * U));
+    const unsigned n = blockIdx.x / nbx, bx = blockIdx.x - n * nbx;
+    const float *un = u + (size_t)n * 3 * NV, *vn = v + (size_t)n * 3 * NV;
+    float *on = out + (size_t)n * 3 * NV;
+    unsigned s[U];
+    float uu[3][U];
+    Pt p[U];
+    unsigned o00[U], o01[U], o10[U], o11[U];
+    bool hi[U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+        s[e] = (bx * U + e) * 256 + threadIdx.x;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) uu[d][e] = un[(size_t)d * NV + s[e]];
+    }
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+        const int i = s[e] / (NY * NZ), r = s[e] - i * (NY * NZ), j = r / NZ, k = r - j * NZ;
+        p[e] = setup(i, j, k, uu[0][e], uu[1][e], uu[2][e]);
+        const int zb = min(p[e].fz, NZ - 2);
+        hi[e] = p[e].fz > zb;
+        o00[e] = (p[e].fx * NY + p[e].fy) * NZ + zb;
+        o01[e] = (p[e].fx * NY + p[e].cy) * NZ + zb;
+        o10[e] = (p[e].cx * NY + p[e].fy) * NZ + zb;
+        o11[e] = (p[e].cx * NY + p[e].cy) * NZ + zb;
+        if (p[e].cz == p[e].fz && !hi[e]) p[e].tz = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *vc = vn + (size_t)c * NV;
+        float o[U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const ull4 q00 = *reinterpret_cast<const ull4 *>(vc + o00[e]);
+            const ull4 q01 = *reinterpret_cast<const ull4 *>(vc + o01[e]);
+            const ull4 q10 = *reinterpret_cast<const ull4 *>(vc + o10[e]);
+            const ull4 q11 = *reinterpret_cast<const ull4 *>(vc + o11[e]);
+            auto lo = [&](ull4 q) { return __builtin_bit_cast(float, (unsigned)(hi[e] ? (q >> 32) : q)); };
+            auto hh = [&](ull4 q) { return __builtin_bit_cast(float, (unsigned)(q >> 32)); };
+            const float val = lerp8(p[e], lo(q00), hh(q00), lo(q01), hh(q01), lo(q10), hh(q10), lo(q11), hh(q11));
+            o[e] = ds * uu[c][e] + dt * val;
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e) on[(size_t)c * NV + s[e]] = o[e];
+    }
+}
+
 // ---------------------------------------------------------------- K1: LDS window
 constexpr int TX = 8, TY = 16, TZ = 32, H = 2;
 constexpr int WX = TX + 1 + 2 * H, WY = TY + 1 + 2 * H;  // 13 x 21 rows
@@ -258,6 +341,22 @@ int main(int argc, char **argv) {
     timeit("pair gathers, 256 thr, U=2", [&] {
         hipLaunchKernelGGL(k_pair<2>, dim3((unsigned)(N * NV / 512)), dim3(256), 0, 0, o0, u, v, ds, dt);
     });
+    for (int vs = 1; vs >= 0; --vs)
+        for (int D : {0, 1, 2, 4, 8, 16, 32}) {
+            char name[96];
+            snprintf(name, sizeof name, "pair gathers + L2-warming wave, D=%d, v slab +%d", D, vs);
+            timeit(name, [&] {
+                hipLaunchKernelGGL(k_pair_pf<2>, dim3((unsigned)(N * NV / 512)), dim3(320), 0, 0, o1, u, v, ds, dt, D, vs);
+            });
+            if (D == 4) {
+                std::vector<float> a(3 * NV), b(3 * NV);
+                CK(hipMemcpy(a.data(), o0 + (size_t)(N - 1) * 3 * NV, 3 * NV * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(b.data(), o1 + (size_t)(N - 1) * 3 * NV, 3 * NV * 4, hipMemcpyDeviceToHost));
+                size_t bad = 0;
+                for (size_t i = 0; i < 3 * NV; ++i) bad += a[i] != b[i];
+                printf("  %zu values differ from the plain pair form\n", bad);
+            }
+        }
     const unsigned tiles = (NX / TX) * (NY / TY) * (NZ / TZ);
     std::vector<float> h0(3 * NV), h1(3 * NV);
     auto compare = [&](const char *name) {
