@@ -61,7 +61,15 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_kernel(fl::
 
 // Planes whose LDS image leaves room for ONE workgroup per CU only (160 x 160: 104 KB) have nobody to hide their
 // global loads behind: a grid of one persistent workgroup per CU walks the planes and requests plane p + grid into
-// registers (7 float4 per thread) before it transforms plane p.
+// registers (7 float4 per thread) while it transforms plane p.  Two details of that loop, both measured
+// (tools/probes/zy_probe.hip, profiles/r03_zy_passes.md):
+//  * the loads are spread over the transform's phases (one or two per phase) instead of issued together, so that their
+//    issue time hides behind other waves' LDS work;
+//  * the prefetched registers are waited for BEFORE the store phase (`settle`: an empty asm that takes them as
+//    operands).  hipcc counts loads and stores in one counter and waits vmcnt(0) at the next fill, i.e. for this
+//    plane's stores to be acknowledged; with the wait in front of the stores the fill finds nothing pending.
+__device__ __forceinline__ void settle(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 template <int NY, int NZ>
 __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_persist_kernel(fl::ZYArgs a) {
     using K = ZYK<NY, NZ>;
@@ -76,10 +84,21 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_persist_ker
         const size_t p = at(pq);
         K::fwd_fill(threadIdx.x, v, P);
         __syncthreads();
-        if (pq + gridDim.x < a.total) K::fwd_load(threadIdx.x, a.in + at(pq + gridDim.x) * (size_t)(K::NY * K::NZ), v);
+        const bool more = pq + gridDim.x < a.total;
+        const float4 *nin = reinterpret_cast<const float4 *>(a.in + (more ? at(pq + gridDim.x) : p) * (size_t)(K::NY * K::NZ));
         float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
 #pragma unroll
         for (int ph = 1; ph < K::NPH; ++ph) {
+            constexpr int NS = K::NPH - 2;   // phases the loads are spread over
+            if (ph <= NS && more) {
+#pragma unroll
+                for (int k = (ph - 1) * K::KV / NS; k < ph * K::KV / NS; ++k)
+                    if (threadIdx.x + k * K::THREADS < K::F4) v[k] = nin[threadIdx.x + k * K::THREADS];
+            }
+            if (ph == K::NPH - 1) {
+#pragma unroll
+                for (int k = 0; k < K::KV; ++k) settle(v[k]);
+            }
             K::fwd_phase(ph, threadIdx.x, nullptr, mainp, nyqp, P, tw);
             __syncthreads();
         }
@@ -93,21 +112,36 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
     K::fill_twiddles(threadIdx.x, tw);
     float4 v[K::KV];
-    float2 fb[K::KV];
+    float4 c0;
     auto at = [&](size_t q) { return a.rev ? (size_t)a.total - 1 - q : q; };   // launch direction (common.hpp)
     size_t pq = blockIdx.x;
-    K::inv_load(threadIdx.x, a.main_ + at(pq) * (size_t)(K::NY * K::NZH), a.nyq + at(pq) * (size_t)K::NY, v, fb);
+    K::inv_load(threadIdx.x, a.main_ + at(pq) * (size_t)(K::NY * K::NZH), a.nyq + at(pq) * (size_t)K::NY, v, c0);
     for (; pq < a.total; pq += gridDim.x) {
         const size_t p = at(pq);
-        K::inv_fill(threadIdx.x, v, fb, P);
+        K::inv_fill(threadIdx.x, v, c0, P);
         __syncthreads();
-        if (pq + gridDim.x < a.total) {
-            const size_t pn = at(pq + gridDim.x);
-            K::inv_load(threadIdx.x, a.main_ + pn * (size_t)(K::NY * K::NZH), a.nyq + pn * (size_t)K::NY, v, fb);
-        }
+        const bool more = pq + gridDim.x < a.total;
+        const size_t pn = more ? at(pq + gridDim.x) : p;
+        const float2 *nmain = a.main_ + pn * (size_t)(K::NY * K::NZH), *nnyq = a.nyq + pn * (size_t)K::NY;
         float *out = a.out + p * (size_t)(K::NY * K::NZ);
 #pragma unroll
         for (int ph = 1; ph < K::NPH_INV; ++ph) {
+            constexpr int NS = K::NPH_INV - 2;
+            if (ph <= NS && more) {
+#pragma unroll
+                for (int k = (ph - 1) * K::KV / NS; k < ph * K::KV / NS; ++k)
+                    if (threadIdx.x + k * K::THREADS < K::F4)
+                        v[k] = reinterpret_cast<const float4 *>(nmain)[threadIdx.x + k * K::THREADS];
+                if (ph == 1 && threadIdx.x < K::NY) {
+                    const float2 x = nmain[threadIdx.x * K::NZH], y = nnyq[threadIdx.x];
+                    c0 = make_float4(x.x, x.y, y.x, y.y);
+                }
+            }
+            if (ph == K::NPH_INV - 1) {
+#pragma unroll
+                for (int k = 0; k < K::KV; ++k) settle(v[k]);
+                settle(c0);
+            }
             K::inv_phase(ph, threadIdx.x, out, nullptr, nullptr, P, tw);
             __syncthreads();
         }

@@ -13,8 +13,10 @@
 //   zy inverse : mirror image of zy forward.
 //
 // Layout of the spectrum between the passes (the caller's `work` buffer, nn*3*nx*ny*(nz/2+1)
-// complex): a "main" block [n][c][x][ky][kz < nz/2] followed by the Nyquist plane
-// [n][c][x][ky] (kz = nz/2).  Splitting the odd 65th column off keeps every row a multiple of
+// complex): a "main" block [n][c][x][r][q < nz/2] followed by the Nyquist plane [n][c][x][r]
+// (kz = nz/2), where row r holds ky = freq_at(r) and column q holds kz = freq_at(q): the
+// digit-reversed order the transforms leave in LDS is kept in memory as well (the x pass is
+// indifferent to it; its coefficient table is laid out the same way).  Splitting the odd 65th column off keeps every row a multiple of
 // 128 bytes: measured on MI355X (tools/probes/seg_copy.hip), 128 B-aligned segments at a 64 KB
 // stride stream at the speed of contiguous memory, while the 520 B rows of the usual
 // nz/2+1 layout cost 3x on the write side (partial cache lines).
@@ -42,6 +44,13 @@ LAGO_HD float2 cmul(float2 a, float2 b) {
 }
 LAGO_HD float2 cmulc(float2 a, float2 b) {  // a * conj(b)
     return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+LAGO_HD int wave_uniform(int v) {  // v is the same in every lane of the wave: keep it (and what follows from it) on the scalar unit
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
 }
 LAGO_HD int brev(int v, int bits) { return bits ? (int)(__builtin_bitreverse32((uint32_t)v) >> (32 - bits)) : 0; }
 
@@ -81,19 +90,36 @@ LAGO_HD int freq_at(int p) {  // frequency held at position p
     return S::R * brev(p & (S::M - 1), S::L2) + (p >> S::L2);
 }
 
-// radix-2 levels are grouped three at a time, from the largest half down
-constexpr int stage_top(int logn, int g) {
-    int top = logn - 1;
-    for (int k = 0; k < g; ++k) top -= (top + 1 >= 3 ? 3 : top + 1);
+// Stage plan of a transform N = R * 2^L2.  The radix-2 levels run in registers in groups of at most FOUR (16 points per
+// work item), from the largest half down; where that saves a stage (L2 = 5: 96 = 3*32 and 160 = 5*32 points) the
+// radix-R level takes the top radix-2 level with it (a radix-2R stage on 2R points).  80 = 5*16, 128 and 160 points are
+// two stages, 64 two, 256 two -- every stage is one read and one write of the tile in LDS, which is what the passes
+// are bound by once their HBM traffic is hidden (tools/probes/zy_probe.hip).
+constexpr bool plan_fuse(int r, int l2) { return r > 1 && l2 == 5; }
+constexpr int plan_lr(int r, int l2) { return l2 - (plan_fuse(r, l2) ? 1 : 0); }      // radix-2 levels left to the groups
+constexpr int group_count(int lr) { return (lr + 3) / 4; }
+constexpr int group_s(int lr, int g) {       // levels of group g: as even as possible, the larger groups first
+    const int n = group_count(lr);
+    return g >= n ? 0 : lr / n + (g < lr % n ? 1 : 0);
+}
+constexpr int group_top(int lr, int g) {     // log2 of the largest half of group g
+    int top = lr - 1;
+    for (int k = 0; k < g; ++k) top -= group_s(lr, k);
     return top;
 }
-constexpr int stage_s(int logn, int g) {
-    const int top = stage_top(logn, g);
-    return top < 0 ? 0 : (top + 1 >= 3 ? 3 : top + 1);
-}
-constexpr int stage_count2(int logn) { return (logn + 2) / 3; }
 template <class S>
-constexpr int stage_count() { return (S::R > 1 ? 1 : 0) + stage_count2(S::L2); }
+constexpr int stage_count() { return (S::R > 1 ? 1 : 0) + group_count(plan_lr(S::R, S::L2)); }
+
+// a * exp(-2 pi i k / 16) (CONJ: a * exp(+2 pi i k / 16)), 0 <= k < 8; k is a constant after unrolling
+template <bool CONJ>
+LAGO_HD float2 mul_root16(float2 a, int k) {
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    if (k == 0) return a;
+    if (k == 4) return CONJ ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    const float cs = k == 1 ? c1 : k == 2 ? h : k == 3 ? s1 : k == 5 ? -s1 : k == 6 ? -h : -c1;
+    const float sn = k == 1 ? s1 : k == 2 ? h : k == 3 ? c1 : k == 5 ? c1 : k == 6 ? h : s1;
+    return CONJ ? cmul(a, make_float2(cs, sn)) : cmulc(a, make_float2(cs, sn));
+}
 
 // A family of NB * NL transforms of S::N points in LDS: element i of transform (b, lane) is
 // buf[b*BS + i*ES + lane*LS].  tw[t] = exp(-2 pi i t / LTW), 0 <= t < LTW, with S::N dividing LTW.
@@ -104,13 +130,14 @@ struct Xf {
     static_assert(LTW_ % S_::N == 0, "the twiddle table must hold the N-th roots of unity");
 };
 
-// Radix-2 stage G of the 2^L2-point sub-transforms of family X: S = stage_s levels (halves 2^TOP .. 2^(TOP-S+1)) on
+// Radix-2 group G of the 2^L2-point sub-transforms of family X: S = group_s levels (halves 2^TOP .. 2^(TOP-S+1)) on
 // 2^S elements spaced 2^(TOP-S+1) apart, in registers.  FWD: decimation in frequency; !FWD: decimation in time
-// with conjugated twiddles.
+// with conjugated twiddles.  The twiddle of level l at element offset low + m' H is exp(-2 pi i low / 2^(lhalf+1))
+// -- ONE table read per level -- times the constant exp(-2 pi i m' / 2^(S-l)), a 16th root of unity.
 template <class X, int G, bool FWD>
 LAGO_HD void radix2_stage(float2 *buf, const float2 *tw, int tid) {
     using Sq = typename X::S;
-    constexpr int TOP = stage_top(Sq::L2, G), S = stage_s(Sq::L2, G);
+    constexpr int LR = plan_lr(Sq::R, Sq::L2), TOP = group_top(LR, G), S = group_s(LR, G);
     if constexpr (S > 0) {
         constexpr int M = Sq::M, R = 1 << S, LH = TOP - S + 1, H = 1 << LH;
         constexpr int PER = M / R, ITEMS = X::NB * Sq::R * PER * X::NL;
@@ -131,20 +158,26 @@ LAGO_HD void radix2_stage(float2 *buf, const float2 *tw, int tid) {
                 const int l = FWD ? ll : S - 1 - ll;
                 const int hm = R >> (l + 1);
                 const int lhalf = LH + (S - 1 - l);
+                // H == 1 (the last group: low = 0): the twiddles are the constants alone, no table read
+                const float2 wl = H == 1 ? make_float2(1.f, 0.f) : tw[low * (X::LTW >> (lhalf + 1))];   // exp(-2 pi i low / 2^(lhalf+1))
 #pragma unroll
-                for (int m = 0; m < R; ++m) {
-                    if (m & hm) continue;
-                    const int jj = low + (m & (hm - 1)) * H;
-                    const float2 wv = tw[jj * (X::LTW >> (lhalf + 1))];   // exp(-2 pi i jj / 2^(lhalf+1))
-                    const float2 a = v[m];
-                    if (FWD) {
-                        const float2 bb = v[m + hm];
-                        v[m] = make_float2(a.x + bb.x, a.y + bb.y);
-                        v[m + hm] = cmul(make_float2(a.x - bb.x, a.y - bb.y), wv);
-                    } else {
-                        const float2 bb = cmulc(v[m + hm], wv);
-                        v[m] = make_float2(a.x + bb.x, a.y + bb.y);
-                        v[m + hm] = make_float2(a.x - bb.x, a.y - bb.y);
+                for (int mp = 0; mp < hm; ++mp) {
+                    const int k16 = mp * (16 >> (S - l));
+                    const float2 wv = H == 1 ? wl : mul_root16<false>(wl, k16);
+#pragma unroll
+                    for (int hi = 0; hi < (R >> 1) / hm; ++hi) {
+                        const int m = hi * 2 * hm + mp;
+                        const float2 a = v[m];
+                        if (FWD) {
+                            const float2 bb = v[m + hm];
+                            const float2 d = make_float2(a.x - bb.x, a.y - bb.y);
+                            v[m] = make_float2(a.x + bb.x, a.y + bb.y);
+                            v[m + hm] = H == 1 ? mul_root16<false>(d, k16) : cmul(d, wv);
+                        } else {
+                            const float2 bb = H == 1 ? mul_root16<true>(v[m + hm], k16) : cmulc(v[m + hm], wv);
+                            v[m] = make_float2(a.x + bb.x, a.y + bb.y);
+                            v[m + hm] = make_float2(a.x - bb.x, a.y - bb.y);
+                        }
                     }
                 }
             }
@@ -185,32 +218,81 @@ LAGO_HD void dft_small(float2 *v) {
     }
 }
 
+// exp(-2 pi i k / (2 R)), 0 < k < R: the twiddle of the radix-R level half a sub-transform further on
+template <int R>
+LAGO_HD float2 root_2r(int k) {
+    if (R == 3) {   // 6th roots
+        return k == 1 ? make_float2(0.5f, -0.86602540378443864676f) : make_float2(-0.5f, -0.86602540378443864676f);
+    }
+    // 10th roots
+    return k == 1 ? make_float2(0.80901699437494742410f, -0.58778525229247312917f)
+         : k == 2 ? make_float2(0.30901699437494742410f, -0.95105651629515357212f)
+         : k == 3 ? make_float2(-0.30901699437494742410f, -0.95105651629515357212f)
+                  : make_float2(-0.80901699437494742410f, -0.58778525229247312917f);
+}
+
 // The radix-R level: x[m + M r] -> y[k1][m] = (sum_r x[m + M r] W_R^(r k1)) W_N^(m k1), stored at k1*M + m
-// (forward); the inverse undoes it.
+// (forward); the inverse undoes it.  FUSED (plan_fuse): one work item takes m and m + M/2 and also runs the top
+// radix-2 level of the M-point sub-transforms on them, y'[k1][m] = A + B, y'[k1][m + M/2] = (A - B) W_M^m; the
+// twiddles of the second half are those of the first times the constants exp(-2 pi i k1 / 2R).
 template <class X, bool FWD>
 LAGO_HD void radixR_stage(float2 *buf, const float2 *tw, int tid) {
     using Sq = typename X::S;
     if constexpr (Sq::R > 1) {
-        constexpr int R = Sq::R, M = Sq::M, ITEMS = X::NB * M * X::NL, TWS = X::LTW / Sq::N;
+        constexpr bool FUSED = plan_fuse(Sq::R, Sq::L2);
+        constexpr int R = Sq::R, M = Sq::M, MW = FUSED ? M / 2 : M, ITEMS = X::NB * MW * X::NL, TWS = X::LTW / Sq::N;
         for (int w = tid; w < ITEMS; w += X::NT) {
             const int lane = w % X::NL;
             const int q = w / X::NL;
-            const int m = q & (M - 1), b = q >> Sq::L2;
+            const int m = q % MW, b = q / MW;
             float2 *p = buf + b * X::BS + m * X::ES + lane * X::LS;
-            float2 v[R];
+            float2 v[R], u[FUSED ? R : 1], wk[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = p[r * M * X::ES];
+            if (FUSED) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) u[r] = p[(r * M + M / 2) * X::ES];
+            }
+#pragma unroll
+            for (int k1 = 1; k1 < R; ++k1) wk[k1] = tw[m * k1 * TWS];
+            const float2 wm = FUSED ? tw[m * R * TWS] : make_float2(1.f, 0.f);   // W_M^m
             if (FWD) {
                 dft_small<R, -1>(v);
 #pragma unroll
-                for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul(v[k1], tw[m * k1 * TWS]);
-            } else {
+                for (int k1 = 1; k1 < R; ++k1) v[k1] = cmul(v[k1], wk[k1]);
+                if (FUSED) {
+                    dft_small<R, -1>(u);
 #pragma unroll
-                for (int k1 = 1; k1 < R; ++k1) v[k1] = cmulc(v[k1], tw[m * k1 * TWS]);
+                    for (int k1 = 1; k1 < R; ++k1) u[k1] = cmul(u[k1], cmul(wk[k1], root_2r<R>(k1)));
+#pragma unroll
+                    for (int k1 = 0; k1 < R; ++k1) {
+                        const float2 a = v[k1], bb = u[k1];
+                        v[k1] = make_float2(a.x + bb.x, a.y + bb.y);
+                        u[k1] = cmul(make_float2(a.x - bb.x, a.y - bb.y), wm);
+                    }
+                }
+            } else {
+                if (FUSED) {
+#pragma unroll
+                    for (int k1 = 0; k1 < R; ++k1) {
+                        const float2 a = v[k1], bb = cmulc(u[k1], wm);
+                        v[k1] = make_float2(a.x + bb.x, a.y + bb.y);
+                        u[k1] = make_float2(a.x - bb.x, a.y - bb.y);
+                    }
+#pragma unroll
+                    for (int k1 = 1; k1 < R; ++k1) u[k1] = cmulc(u[k1], cmul(wk[k1], root_2r<R>(k1)));
+                    dft_small<R, +1>(u);
+                }
+#pragma unroll
+                for (int k1 = 1; k1 < R; ++k1) v[k1] = cmulc(v[k1], wk[k1]);
                 dft_small<R, +1>(v);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) p[r * M * X::ES] = v[r];
+            if (FUSED) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) p[(r * M + M / 2) * X::ES] = u[r];
+            }
         }
     }
 }
@@ -266,7 +348,7 @@ LAGO_HD void fluid_bin(const float *c, float2 &X, float2 &Y, float2 &Z, float sc
 // block, or 16 ky of the Nyquist plane); thread = (row group, bin lane).
 struct XArgs {
     float2 *main_, *nyq;        // split spectrum (see the header comment)
-    const float *tabM, *tabN;   // coefficients [kx][ky][kz < nzh][6] and [kx][ky][6]
+    const float *tabM, *tabN;   // coefficients [kx][r][q < nzh][6] and [kx][r][6], (r, q) as in the spectrum
     int ny, nzh, nch, items_per_n;
     int nn, ipw;                // batch size; batch items one workgroup runs through with the same coefficients
     float scale;
@@ -383,9 +465,11 @@ struct ZYArgs {
     int rev;           // launch direction (common.hpp): planes descending
 };
 
-// threads per plane: 1024 once a plane has at least 2048 float4 (two per thread), else 512; the load / store phases
-// guard the last pass when the plane does not divide (160 x 80 / 2 = 6400 float4 over 1024 threads)
-constexpr int zy_threads(int ny, int nzh) { return ny * nzh / 2 >= 2048 ? 1024 : 512; }
+// threads per plane: 1024 for the planes that are alone on their CU (above 80 KB of LDS: the persistent kernels of
+// fft3.hip, 128 VGPRs per thread), 512 for the others -- two or more workgroups share a CU and a four-level group is 16
+// points per work item: 512 items at 128 x 64 complex, and more than the 64 VGPRs a 1024-thread pair could have; the
+// load / store phases guard the last pass when the plane does not divide (160 x 80 / 2 = 6400 float4 over 1024 threads)
+constexpr int zy_threads(int ny, int nzh) { return (size_t)ny * (nzh + 1) * 8 > 80 * 1024 ? 1024 : 512; }
 
 template <class SY, class SZH, int NT = zy_threads(SY::N, SZH::N)>
 struct ZY {
@@ -400,6 +484,21 @@ struct ZY {
     static constexpr size_t SMEM = (size_t)(NY * PZ + LTW) * sizeof(float2);
     static constexpr int THREADS = NT;
     static_assert(KV >= 1 && NZH % 2 == 0, "rows must hold whole float4");
+
+    // Work split of the real-FFT split / merge phases: a wave takes 64 consecutive rows y (lanes) and every SLOTS-th k
+    // from k0 on, so k is uniform in the wave.
+    struct RowsK {
+        static constexpr int CH = (NY + 63) / 64, SLOTS = (NT / 64) / CH;
+        static_assert(SLOTS >= 1, "fewer waves than 64-row chunks");
+        int y, k0;
+        bool active;
+        LAGO_HD RowsK(int tid) {
+            const int wave = wave_uniform(tid >> 6);
+            k0 = wave / CH;
+            y = (wave % CH) * 64 + (tid & 63);
+            active = k0 < SLOTS && y < NY;
+        }
+    };
 
     LAGO_HD static void fill_twiddles(int tid, float2 *tw) {
         for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
@@ -421,30 +520,32 @@ struct ZY {
             P[y * PZ + j + 1] = make_float2(v[k].z, v[k].w);
         }
     }
-    LAGO_HD static void inv_load(int tid, const float2 *mainp, const float2 *nyqp, float4 (&v)[KV], float2 (&fb)[KV]) {
+    // Column 0 of the inverse carries FA + i FB (FB = the Nyquist column): thread r < NY fetches both bins of its
+    // row (c0 = (main[r][0], nyq[r])) and writes the packed value; the float4 owner of (r, 0..1) leaves it alone.
+    LAGO_HD static void inv_load(int tid, const float2 *mainp, const float2 *nyqp, float4 (&v)[KV], float4 &c0) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k)
+            if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
+        if (tid < NY) {
+            const float2 a = mainp[tid * NZH], b = nyqp[tid];
+            c0 = make_float4(a.x, a.y, b.x, b.y);
+        }
+    }
+    LAGO_HD static void inv_fill(int tid, const float4 (&v)[KV], const float4 &c0, float2 *P) {
 #pragma unroll
         for (int k = 0; k < KV; ++k) {
             if (tid + k * NT >= F4) continue;
-            v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
-            const int e = (tid + k * NT) * 2;
-            if (e % NZH == 0) fb[k] = nyqp[e / NZH];
+            const int e = (tid + k * NT) * 2, r = e / NZH, c = e % NZH;   // the spectrum lies in memory as it lies in LDS
+            float2 *row = P + r * PZ;
+            if (c != 0) row[c] = make_float2(v[k].x, v[k].y);
+            row[c + 1] = make_float2(v[k].z, v[k].w);
         }
+        // pack FA + i FB: the inverse y transform then returns (X[0](y), X[NZH](y))
+        if (tid < NY) P[tid * PZ] = make_float2(c0.x - c0.w, c0.y + c0.z);
     }
-    LAGO_HD static void inv_fill(int tid, const float4 (&v)[KV], const float2 (&fb)[KV], float2 *P) {
-#pragma unroll
-        for (int k = 0; k < KV; ++k) {
-            if (tid + k * NT >= F4) continue;
-            const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
-            float2 *row = P + pos_of<SY>(ky) * PZ;
-            float2 a = make_float2(v[k].x, v[k].y);
-            if (kz == 0)  // pack FA + i FB: the inverse y transform then returns (X[0](y), X[NZH](y))
-                a = make_float2(a.x - fb[k].y, a.y + fb[k].x);
-            row[pos_of<SZH>(kz)] = a;
-            row[pos_of<SZH>(kz + 1)] = make_float2(v[k].z, v[k].w);
-        }
-    }
+    static_assert(NT >= NY, "one thread per row packs column 0");
 
-    // -- forward: real plane -> main[ky][kz], nyq[ky]
+    // -- forward: real plane -> main[r][c], nyq[r]: bin (ky, kz) at row pos_of<SY>(ky), column pos_of<SZH>(kz)
     LAGO_HD static void fwd_phase(int ph, int tid, const float *in, float2 *mainp, float2 *nyqp, float2 *P,
                                   float2 *tw) {
         if (ph == 0) {
@@ -459,9 +560,11 @@ struct ZY {
             // X[k] = E + w^k O, conj X[NZH-k] = E - w^k O, E = (Z[k] + conj Z[NZH-k])/2,
             // O = -i (Z[k] - conj Z[NZH-k])/2, w = exp(-2 pi i / NZ).  Z[k] sits at column pos_of(k).
             // X[0] and X[NZH] are real: they share column 0 as (X[0], X[NZH]).
-            for (int w = tid; w < (NZH / 2 + 1) * NY; w += NT) {
-                const int y = w % NY, k = w / NY;
-                float2 *row = P + y * PZ;
+            // lanes over 64 consecutive rows, k the same in every lane of a wave (RowsK): its positions, its
+            // twiddle index and the two special cases cost scalar instructions
+            RowsK rk(tid);
+            if (rk.active) for (int k = rk.k0; k < NZH / 2 + 1; k += RowsK::SLOTS) {
+                float2 *row = P + rk.y * PZ;
                 if (k == 0) {
                     const float2 z = row[0];
                     row[0] = make_float2(z.x + z.y, z.x - z.y);
@@ -496,36 +599,38 @@ struct ZY {
                 pm[NZH] = make_float2(FB.x, -FB.y);
             }
         } else {
+            // the spectrum goes to memory in the order it has in LDS (row r holds ky = freq_at<SY>(r), column c holds
+            // kz = freq_at<SZH>(c)): no index arithmetic here nor in the inverse's fill
 #pragma unroll
             for (int k = 0; k < KV; ++k) {
                 if (tid + k * NT >= F4) continue;
-                const int e = (tid + k * NT) * 2, ky = e / NZH, kz = e % NZH;
-                const float2 *row = P + pos_of<SY>(ky) * PZ;
-                const float2 a = row[pos_of<SZH>(kz)], c = row[pos_of<SZH>(kz + 1)];
-                reinterpret_cast<float4 *>(mainp)[tid + k * NT] = make_float4(a.x, a.y, c.x, c.y);
+                const int e = (tid + k * NT) * 2, r = e / NZH, c = e % NZH;
+                const float2 *row = P + r * PZ;
+                const float2 a = row[c], cc = row[c + 1];
+                reinterpret_cast<float4 *>(mainp)[tid + k * NT] = make_float4(a.x, a.y, cc.x, cc.y);
             }
-            for (int ky = tid; ky < NY; ky += NT) nyqp[ky] = P[pos_of<SY>(ky) * PZ + NZH];
+            for (int r = tid; r < NY; r += NT) nyqp[r] = P[r * PZ + NZH];
         }
     }
 
-    // -- inverse: main[ky][kz], nyq[ky] -> real plane (unnormalised: NY * NZ times the original)
+    // -- inverse: main[r][c], nyq[r] -> real plane (unnormalised: NY * NZ times the original)
     LAGO_HD static void inv_phase(int ph, int tid, float *out, const float2 *mainp, const float2 *nyqp, float2 *P,
                                   float2 *tw) {
         if (ph == 0) {
             fill_twiddles(tid, tw);
             float4 v[KV];
-            float2 fb[KV];
-            inv_load(tid, mainp, nyqp, v, fb);
-            inv_fill(tid, v, fb, P);
+            float4 c0;
+            inv_load(tid, mainp, nyqp, v, c0);
+            inv_fill(tid, v, c0, P);
         } else if (ph <= GY) {
             run_stage<TY, false>(ph - 1, P, tw, tid);
         } else if (ph == GY + 1) {
             // merge X back into the half-length transform (twice it: the missing factor 2 of the
             // real inverse): 2E = X[k] + conj X[NZH-k], 2O = (X[k] - conj X[NZH-k]) conj(w^k),
             // Z[k] = 2E + i 2O, Z[NZH-k] = conj(2E) + i conj(2O)
-            for (int w = tid; w < (NZH / 2 + 1) * NY; w += NT) {
-                const int y = w % NY, k = w / NY;
-                float2 *row = P + y * PZ;
+            RowsK rk(tid);
+            if (rk.active) for (int k = rk.k0; k < NZH / 2 + 1; k += RowsK::SLOTS) {
+                float2 *row = P + rk.y * PZ;
                 if (k == 0) {
                     const float2 x = row[0];
                     row[0] = make_float2(x.x + x.y, x.x - x.y);

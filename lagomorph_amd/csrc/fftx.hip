@@ -27,6 +27,14 @@ __device__ __forceinline__ float fx_safe_sqrt(float x) {
 }
 __device__ __forceinline__ float fx_recip(float x) { return (float)(1. / (double)x); }
 
+// frequency held at position p of a digit-reversed n-point spectrum, n = R * 2^L2 (fft_lds.hpp: freq_at<Sz<R, L2>>)
+__device__ __forceinline__ int freq_at_rt(int p, int n) {
+    const int l2 = __builtin_ctz((unsigned)n), r = n >> l2;
+    const int low = p & ((1 << l2) - 1);
+    const int br = l2 ? (int)(__builtin_bitreverse32((uint32_t)low) >> (32 - l2)) : 0;
+    return r * br + (p >> l2);
+}
+
 // One lane per frequency bin (kx, ky, kz): coefficients of cuda/metric.cu:240-270 in the layout
 // tab[bin][6] = {L00 L10 L11 L20 L21 L22} (flat) or {ooG00 G10 ooG11 G20 G21 ooG22} (sharp).
 template <bool INV>
@@ -37,8 +45,12 @@ __global__ __launch_bounds__(kBlock) void fluid_coef_kernel(float *__restrict__ 
                                                             double gamma, Geom g, int split) {
     const Vox v = locate(g);
     if (!v.valid) return;
-    const float wx = cosX[v.i], wy = cosY[v.j], wz = cosZ[v.k];
-    const float sx = sinX[v.i], sy = sinY[v.j], sz = sinZ[v.k];
+    // split layout: (v.j, v.k) are POSITIONS (r, q) of the zy passes' digit-reversed spectrum (fft_lds.hpp), the bin
+    // they hold is (freq_at(r), freq_at(q)); the spare column q = nzh is the Nyquist bin
+    const int nzh = g.nz - 1;
+    const int ky = split ? freq_at_rt(v.j, g.ny) : v.j, kz = split && v.k < nzh ? freq_at_rt(v.k, nzh) : v.k;
+    const float wx = cosX[v.i], wy = cosY[ky], wz = cosZ[kz];
+    const float sx = sinX[v.i], sy = sinY[ky], sz = sinZ[kz];
     const float lambda = (float)__builtin_fma(alpha, (double)(wx + wy + wz), gamma);
     const float l00 = (float)__builtin_fma(-beta, (double)wx, (double)lambda);
     const float l11 = (float)__builtin_fma(-beta, (double)wy, (double)lambda);
@@ -52,8 +64,7 @@ __global__ __launch_bounds__(kBlock) void fluid_coef_kernel(float *__restrict__ 
     const float L20 = lg_fma(l20, l22, lg_fma(l00, l20, l10 * l21));
     const float L21 = lg_fma(l21, l22, lg_fma(l10, l20, l11 * l21));
     const float L22 = lg_fma(l22, l22, lg_fma(l20, l20, l21 * l21));
-    // split: [kx][ky][kz < nzc-1] followed by the Nyquist plane [kx][ky] (fft_lds.hpp)
-    const int nzh = g.nz - 1;
+    // split: [kx][r][q < nzc-1] followed by the Nyquist plane [kx][r] (fft_lds.hpp)
     float *t = !split ? tab + (size_t)v.s * 6
                : v.k < nzh ? tab + (((size_t)v.i * g.ny + v.j) * nzh + v.k) * 6
                            : tab + ((size_t)g.nx * g.ny * nzh + (size_t)v.i * g.ny + v.j) * 6;

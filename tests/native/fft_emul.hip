@@ -76,6 +76,16 @@ static int run_case() {
                 tabNw[bb * 6 + e] = tabNw[a * 6 + e];
             }
         }
+    // the passes keep the spectrum in the order the transforms leave in LDS (row r = pos_of(ky), column q = pos_of(kz));
+    // the x pass takes its coefficient table in the same order
+    std::vector<float> tabP(tab.size());
+    for (int kx = 0; kx < NX; ++kx)
+        for (int ky = 0; ky < NY; ++ky) {
+            const size_t src = (size_t)kx * NY + ky, dst = (size_t)kx * NY + pos_of<SY>(ky);
+            for (int kz = 0; kz < NZH; ++kz)
+                for (int e = 0; e < 6; ++e) tabP[(dst * NZH + pos_of<SZH>(kz)) * 6 + e] = tabMw[(src * NZH + kz) * 6 + e];
+            for (int e = 0; e < 6; ++e) tabP[((size_t)NX * NY * NZH + dst) * 6 + e] = tabNw[src * 6 + e];
+        }
     const float *tabM = tabMw, *tabN = tabNw;
     const float scale = 1.0f / ((float)NX * NY * NZ);
 
@@ -98,7 +108,8 @@ static int run_case() {
             for (int ky = 0; ky < NY; ++ky)
                 for (int kz = 0; kz <= NZH; ++kz) {
                     const size_t pl = (size_t)1 * NX + x;
-                    const float2 g = kz < NZH ? mainb[(pl * NY + ky) * NZH + kz] : nyqb[pl * NY + ky];
+                    const size_t rr = pos_of<SY>(ky);
+                    const float2 g = kz < NZH ? mainb[(pl * NY + rr) * NZH + pos_of<SZH>(kz)] : nyqb[pl * NY + rr];
                     const cd r = a[((size_t)x * NY + ky) * NZ + kz];
                     err2d = std::max(err2d, std::abs(cd(g.x, g.y) - r));
                     ref2d = std::max(ref2d, std::abs(r));
@@ -106,7 +117,7 @@ static int run_case() {
     }
     // x pass
     XArgs xa;
-    xa.main_ = mainb; xa.nyq = nyqb; xa.tabM = tabM; xa.tabN = tabN;
+    xa.main_ = mainb; xa.nyq = nyqb; xa.tabM = tabP.data(); xa.tabN = tabP.data() + (size_t)NX * NY * NZH * 6;
     xa.ny = NY; xa.nzh = NZH; xa.nch = NZH / 16; xa.items_per_n = NY * xa.nch + NY / 16;
     xa.nn = NN; xa.ipw = 1; xa.scale = scale; xa.total = (uint32_t)(NN * xa.items_per_n);
     std::vector<typename Xp::Regs> regs(256);
@@ -170,6 +181,10 @@ int main() {
     bad += run_case<Sz<5, 5>, Sz<1, 5>, Sz<5, 4>, true>();    // 160 x 32 x 160
     bad += run_case<Sz<1, 6>, Sz<5, 5>, Sz<1, 5>, false>();   // 64 x 160 x 64
     bad += run_case<Sz<1, 6>, Sz<3, 5>, Sz<5, 4>, true>();    // 64 x 96 x 160
+    // four-level groups (256 = two groups of four, 128 = 4 + 3) and the unfused radix-3 level in front of 3 + 3 levels
+    bad += run_case<Sz<1, 8>, Sz<1, 5>, Sz<1, 5>, false>();   // 256 x 32 x 64
+    bad += run_case<Sz<1, 5>, Sz<3, 6>, Sz<1, 7>, true>();    // 32 x 192 x 256
+    bad += run_case<Sz<1, 5>, Sz<1, 7>, Sz<3, 5>, false>();   // 32 x 128 x 192
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }
