@@ -111,14 +111,13 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
     extern __shared__ __align__(16) unsigned char lago_smem[];
     float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
     K::fill_twiddles(threadIdx.x, tw);
-    float4 v[K::KV];
-    float4 c0;
+    float4 v[K::KVX];
     auto at = [&](size_t q) { return a.rev ? (size_t)a.total - 1 - q : q; };   // launch direction (common.hpp)
     size_t pq = blockIdx.x;
-    K::inv_load(threadIdx.x, a.main_ + at(pq) * (size_t)(K::NY * K::NZH), a.nyq + at(pq) * (size_t)K::NY, v, c0);
+    K::inv_load(threadIdx.x, a.main_ + at(pq) * (size_t)(K::NY * K::NZH), a.nyq + at(pq) * (size_t)K::NY, v);
     for (; pq < a.total; pq += gridDim.x) {
         const size_t p = at(pq);
-        K::inv_fill(threadIdx.x, v, c0, P);
+        K::inv_fill(threadIdx.x, v, P);
         __syncthreads();
         const bool more = pq + gridDim.x < a.total;
         const size_t pn = more ? at(pq + gridDim.x) : p;
@@ -132,15 +131,11 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
                 for (int k = (ph - 1) * K::KV / NS; k < ph * K::KV / NS; ++k)
                     if (threadIdx.x + k * K::THREADS < K::F4)
                         v[k] = reinterpret_cast<const float4 *>(nmain)[threadIdx.x + k * K::THREADS];
-                if (ph == 1 && threadIdx.x < K::NY) {
-                    const float2 x = nmain[threadIdx.x * K::NZH], y = nnyq[threadIdx.x];
-                    c0 = make_float4(x.x, x.y, y.x, y.y);
-                }
+                if (ph == NS) K::inv_load_c0(threadIdx.x, nmain, nnyq, v);   // after the plane's own use of that slot
             }
             if (ph == K::NPH_INV - 1) {
 #pragma unroll
-                for (int k = 0; k < K::KV; ++k) settle(v[k]);
-                settle(c0);
+                for (int k = 0; k < K::KVX; ++k) settle(v[k]);
             }
             K::inv_phase(ph, threadIdx.x, out, nullptr, nullptr, P, tw);
             __syncthreads();

@@ -520,18 +520,26 @@ struct ZY {
             P[y * PZ + j + 1] = make_float2(v[k].z, v[k].w);
         }
     }
-    // Column 0 of the inverse carries FA + i FB (FB = the Nyquist column): thread r < NY fetches both bins of its
-    // row (c0 = (main[r][0], nyq[r])) and writes the packed value; the float4 owner of (r, 0..1) leaves it alone.
-    LAGO_HD static void inv_load(int tid, const float2 *mainp, const float2 *nyqp, float4 (&v)[KV], float4 &c0) {
+    // Column 0 of the inverse carries FA + i FB (FB = the Nyquist column): one thread per row r fetches both bins of
+    // the row, c0 = (main[r][0], nyq[r]), and writes the packed value; the float4 owner of (r, 0..1) leaves it alone.
+    // c0 rides in the LAST float4 slot, which only the first F4 % NT threads need for the plane itself: threads
+    // C0T .. C0T + NY - 1 use theirs for c0 (no extra registers: the persistent kernels of fft3.hip sit at the 128 a
+    // 1024-thread workgroup may have); where the plane fills the last slot completely, one more slot is appended.
+    static constexpr bool C0_SHARES = F4 % NT != 0 && F4 % NT + NY <= NT;
+    static constexpr int KVX = KV + (C0_SHARES ? 0 : 1), C0T = C0_SHARES ? F4 % NT : 0;
+    LAGO_HD static void inv_load_c0(int tid, const float2 *mainp, const float2 *nyqp, float4 (&v)[KVX]) {
+        if (tid >= C0T && tid < C0T + NY) {
+            const float2 a = mainp[(tid - C0T) * NZH], b = nyqp[tid - C0T];
+            v[KVX - 1] = make_float4(a.x, a.y, b.x, b.y);
+        }
+    }
+    LAGO_HD static void inv_load(int tid, const float2 *mainp, const float2 *nyqp, float4 (&v)[KVX]) {
 #pragma unroll
         for (int k = 0; k < KV; ++k)
             if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
-        if (tid < NY) {
-            const float2 a = mainp[tid * NZH], b = nyqp[tid];
-            c0 = make_float4(a.x, a.y, b.x, b.y);
-        }
+        inv_load_c0(tid, mainp, nyqp, v);
     }
-    LAGO_HD static void inv_fill(int tid, const float4 (&v)[KV], const float4 &c0, float2 *P) {
+    LAGO_HD static void inv_fill(int tid, const float4 (&v)[KVX], float2 *P) {
 #pragma unroll
         for (int k = 0; k < KV; ++k) {
             if (tid + k * NT >= F4) continue;
@@ -541,7 +549,10 @@ struct ZY {
             row[c + 1] = make_float2(v[k].z, v[k].w);
         }
         // pack FA + i FB: the inverse y transform then returns (X[0](y), X[NZH](y))
-        if (tid < NY) P[tid * PZ] = make_float2(c0.x - c0.w, c0.y + c0.z);
+        if (tid >= C0T && tid < C0T + NY) {
+            const float4 c0 = v[KVX - 1];
+            P[(tid - C0T) * PZ] = make_float2(c0.x - c0.w, c0.y + c0.z);
+        }
     }
     static_assert(NT >= NY, "one thread per row packs column 0");
 
@@ -618,10 +629,9 @@ struct ZY {
                                   float2 *tw) {
         if (ph == 0) {
             fill_twiddles(tid, tw);
-            float4 v[KV];
-            float4 c0;
-            inv_load(tid, mainp, nyqp, v, c0);
-            inv_fill(tid, v, c0, P);
+            float4 v[KVX];
+            inv_load(tid, mainp, nyqp, v);
+            inv_fill(tid, v, P);
         } else if (ph <= GY) {
             run_stage<TY, false>(ph - 1, P, tw, tid);
         } else if (ph == GY + 1) {
