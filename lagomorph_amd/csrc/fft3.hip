@@ -345,7 +345,7 @@ static hipError_t zy_launch(const fl::ZYArgs &a, bool inverse, hipStream_t s) {
     static_assert(K::SMEM <= 160 * 1024, "plane does not fit the LDS");
     // one workgroup per CU (plane above 80 KB) and the next plane's registers fit beside the transform's (not the
     // 256-point rows / columns, which spill): persistent grid with register prefetch
-    constexpr bool kPersist = K::SMEM > 80 * 1024 && K::KV <= 8 && NY < 256 && NZ < 256;
+    constexpr bool kPersist = K::SMEM > 80 * 1024 && K::KV <= 8 && NY < 256 && NZ < 256 && !(NY == 128 && NZ == 192);   // (128, 192: six full slots + the column-0 slot: 16 spilled registers)
     if constexpr (kPersist) if (g_zy_persist) {
         const uint32_t grid = std::min<uint32_t>(a.total, 256u);
         if (inverse) {

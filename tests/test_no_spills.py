@@ -17,7 +17,9 @@ import check_spills  # noqa: E402
 ALLOWED = [  # (pattern on the demangled name, spilled VGPRs allowed)
     (r"lago::splat_tiled_kernel<float, [03], (true|false), true, 1024, 4, true>", 2),   # multi-channel general splat: affine / regrid callers only
     (r"lago::splat_tiled_kernel<double, [03], (true|false), true, 1024, 4, false>", 4),  # float64 general splat
-    (r"lago::zy_inverse_persist_kernel<(128, 192|160, 192|192, 160)>", 4),              # 192-point planes: not a BASELINE shape
+    # persistent zy passes of mixed planes (not BASELINE shapes; 160 x 160 itself must be clean): re-deriving the per-plane
+    # indices instead (no spill) measured 2-4 % SLOWER than these few spilled registers (tools/ab_fft_libs.py, round 3)
+    (r"lago::zy_(forward|inverse)_persist_kernel<(128, 160|160, 192|192, 160)>", 7),
 ]
 
 

@@ -13,7 +13,7 @@ from bench import time_op
 tag = sys.argv[1] if len(sys.argv) > 1 else "lib"
 dev = torch.device("cuda")
 met = lm.FluidMetric([0.1, 0.0, 0.01])
-cases = (((128, 128, 128), 32), ((160, 160, 160), 8), ((128, 128, 128), 8), ((192, 160, 96), 4))
+cases = (((128, 128, 128), 32), ((160, 160, 160), 8), ((128, 128, 128), 8), ((192, 160, 96), 4), ((96, 160, 192), 4), ((96, 128, 160), 4))
 if "ONLY" in os.environ:   # e.g. ONLY=0,1 under the profiler (kernel names do not tell batch sizes apart)
     cases = [cases[int(i)] for i in os.environ["ONLY"].split(",")]
 for shape, B in cases:
