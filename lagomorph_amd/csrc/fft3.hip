@@ -314,6 +314,57 @@ __global__ __launch_bounds__(NT) void fluid_xpass2_kernel(fl::XArgs a) {
     }
 }
 
+// The x pass as a persistent grid (two workgroups per CU): each workgroup walks a contiguous run of (bin tile, batch
+// item) pairs -- batch items innermost, so the coefficients stay in registers until the bin tile changes -- and
+// requests the next tile into registers, spread over the phases of the current one; the prefetched registers are
+// settled before the store phase (see zy_forward_persist_kernel).  One-shot workgroups, two per CU, overlap their
+// load / compute / store only by chance: 388 -> ... us at 32 x 3 x 128^3 (tools/ab_fluid.py).
+template <int NX, bool INV, int NT>
+__global__ __launch_bounds__(NT) void fluid_xpass2_persist_kernel(fl::XArgs a) {
+    using K = fl::XPass<typename SzOf<NX>::T, INV, NT>;
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    float2 *buf = reinterpret_cast<float2 *>(lago_smem), *tw = buf + 3 * K::NX * K::KCP;
+    const uint32_t T = (uint32_t)a.nn * (uint32_t)a.items_per_n;
+    const uint32_t q0 = (uint32_t)((uint64_t)blockIdx.x * T / gridDim.x), q1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * T / gridDim.x);
+    if (q0 >= q1) return;
+    auto at = [&](uint32_t q) {   // pair number q of the launch: bin tile q / nn, batch item q % nn
+        const uint32_t qq = a.rev ? T - 1u - q : q;
+        return K::locate(a, qq % (uint32_t)a.nn, qq / (uint32_t)a.nn);
+    };
+    K::fill_twiddles(threadIdx.x, tw);
+    typename K::Regs r;
+    float4 v[K::KLD];
+    typename K::Block b = at(q0);
+    const float *tb_held = nullptr;
+#pragma unroll
+    for (int k = 0; k < K::KLD; ++k) K::load_one(threadIdx.x, b, v, k);
+    for (uint32_t q = q0; q < q1; ++q) {
+        K::fill(threadIdx.x, v, buf);
+        if (b.tb != tb_held) {   // workgroup-uniform: a new bin tile
+            K::load_coef(threadIdx.x, r, b);
+            tb_held = b.tb;
+        }
+        __syncthreads();
+        const bool more = q + 1 < q1;
+        const typename K::Block bn = more ? at(q + 1) : b;
+#pragma unroll
+        for (int ph = 1; ph < K::NPH; ++ph) {
+            constexpr int NS = K::NPH - 2;   // phases the loads are spread over
+            if (ph <= NS && more) {
+#pragma unroll
+                for (int k = (ph - 1) * K::KLD / NS; k < ph * K::KLD / NS; ++k) K::load_one(threadIdx.x, bn, v, k);
+            }
+            if (ph == K::NPH - 1) {
+#pragma unroll
+                for (int k = 0; k < K::KLD; ++k) settle(v[k]);
+            }
+            K::phase(ph, threadIdx.x, r, b, buf, tw, a.scale, false);
+            __syncthreads();
+        }
+        b = bn;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 
 // (ny, nz) planes the zy passes are instantiated for: every pair of {64, 96, 128, 160, 192} (160^3 is the volume of
@@ -383,16 +434,38 @@ static hipError_t zy_dispatch(int64_t ny, int64_t nz, const fl::ZYArgs &a, bool 
     return hipErrorInvalidValue;
 }
 
+std::atomic<int> g_xpass_persist{1};  // 1: persistent x-pass grid (two workgroups per CU) once the launch has enough pairs
+
 template <int NX, int NT>
 static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t s) {
+    using K0 = fl::XPass<typename SzOf<NX>::T, false, NT>;
+    // persistent: tiles that fit a CU twice, and at least four (bin tile, batch item) pairs per workgroup
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / K0::SMEM), grid = 256u * per_cu;
+    const uint64_t pairs = (uint64_t)a.nn * (uint64_t)a.items_per_n;
+    // (192 points: 263 VGPRs, one 256-thread workgroup per CU -- stays with the one-shot workgroups)
+    const bool persist = g_xpass_persist && per_cu >= 2 && NX <= 160 && pairs >= 4ull * grid && pairs < (1ull << 32);
     if (inverse) {
         using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
+        if (persist) {
+            auto k = fluid_xpass2_persist_kernel<NX, true, NT>;
+            hipError_t e = allow_smem(k, K::SMEM);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(NT), K::SMEM, s, a);
+            return hipSuccess;
+        }
         auto k = fluid_xpass2_kernel<NX, true, NT>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
     } else {
         using K = fl::XPass<typename SzOf<NX>::T, false, NT>;
+        if (persist) {
+            auto k = fluid_xpass2_persist_kernel<NX, false, NT>;
+            hipError_t e = allow_smem(k, K::SMEM);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(NT), K::SMEM, s, a);
+            return hipSuccess;
+        }
         auto k = fluid_xpass2_kernel<NX, false, NT>;
         hipError_t e = allow_smem(k, K::SMEM);
         if (e != hipSuccess) return e;
@@ -483,3 +556,4 @@ extern "C" void lago_debug_fluid_stage_mask(int m) { lago::g_native_stage_mask =
 extern "C" void lago_set_fluid_xpass_ipw(int n) { lago::g_xpass_ipw = n; }
 extern "C" void lago_set_fluid_zy_persist(int on) { lago::g_zy_persist = on; }
 extern "C" void lago_set_fluid_xpass_wide(int on) { lago::g_xpass_wide = on; }
+extern "C" void lago_set_fluid_xpass_persist(int on) { lago::g_xpass_persist = on; }

@@ -376,7 +376,9 @@ struct XPass {
     struct Regs { float coef[NOP][6]; };
 
     LAGO_HD static Block locate(const XArgs &a, uint32_t blk) {
-        const uint32_t n = blk / (uint32_t)a.items_per_n * (uint32_t)a.ipw, item = blk % (uint32_t)a.items_per_n;
+        return locate(a, blk / (uint32_t)a.items_per_n * (uint32_t)a.ipw, blk % (uint32_t)a.items_per_n);
+    }
+    LAGO_HD static Block locate(const XArgs &a, uint32_t n, uint32_t item) {   // batch item n, bin tile `item`
         const uint32_t nmain = (uint32_t)a.ny * a.nch;
         Block b;
         if (item < nmain) {
@@ -395,36 +397,49 @@ struct XPass {
         return b;
     }
 
+    // The load phase in pieces -- tile into registers, coefficients into registers, registers into LDS -- so that a
+    // persistent workgroup can request its next tile while it transforms the current one (fft3.hip).
+    LAGO_HD static void load_one(int tid, const Block &b, float4 (&v)[KLD], int k) {
+        const int rg = tid >> 3, l8 = tid & 7;
+        v[k] = *reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8);
+    }
+    LAGO_HD static void load_coef(int tid, Regs &r, const Block &b) {
+        const int kc = tid & (KL - 1), row0 = tid / KL;
+#pragma unroll
+        for (int i = 0; i < NOP; ++i) {
+            const float *t = b.tb + (size_t)freq_at<SX>(row0 + i * RG) * b.tks + kc * 6;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const float2 c2 = *reinterpret_cast<const float2 *>(t + 2 * e);
+                r.coef[i][2 * e] = c2.x;
+                r.coef[i][2 * e + 1] = c2.y;
+            }
+        }
+    }
+    LAGO_HD static void fill(int tid, const float4 (&v)[KLD], float2 *buf) {
+        const int rg = tid >> 3, l8 = tid & 7;
+#pragma unroll
+        for (int k = 0; k < KLD; ++k) {
+            float2 *d = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
+            d[0] = make_float2(v[k].x, v[k].y);
+            d[1] = make_float2(v[k].z, v[k].w);
+        }
+    }
+    LAGO_HD static void fill_twiddles(int tid, float2 *tw) {
+        for (int t = tid; t < NX; t += NT) tw[t] = twiddle(t, NX);
+    }
+
     // `first`: the workgroup's first batch item -- twiddles and coefficients are loaded then and kept
     LAGO_HD static void phase(int ph, int tid, Regs &r, const Block &b, float2 *buf, float2 *tw, float scale,
                               bool first = true) {
         if (ph == 0) {
-            if (first)
-                for (int t = tid; t < NX; t += NT) tw[t] = twiddle(t, NX);
-            const int rg = tid >> 3, l8 = tid & 7;
+            if (first) fill_twiddles(tid, tw);
             float4 v[KLD];
 #pragma unroll
-            for (int k = 0; k < KLD; ++k)
-                v[k] = *reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8);
+            for (int k = 0; k < KLD; ++k) load_one(tid, b, v, k);
             // coefficient prefetch for the operator phase (consumed after the forward stages)
-            const int kc = tid & (KL - 1), row0 = tid / KL;
-#pragma unroll
-            for (int i = 0; i < NOP; ++i) {
-                if (!first) break;
-                const float *t = b.tb + (size_t)freq_at<SX>(row0 + i * RG) * b.tks + kc * 6;
-#pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    const float2 c2 = *reinterpret_cast<const float2 *>(t + 2 * e);
-                    r.coef[i][2 * e] = c2.x;
-                    r.coef[i][2 * e + 1] = c2.y;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KLD; ++k) {
-                float2 *d = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
-                d[0] = make_float2(v[k].x, v[k].y);
-                d[1] = make_float2(v[k].z, v[k].w);
-            }
+            if (first) load_coef(tid, r, b);
+            fill(tid, v, buf);
         } else if (ph <= G) {
             run_stage<T, true>(ph - 1, buf, tw, tid);
         } else if (ph == G + 1) {

@@ -85,7 +85,7 @@ _lib.lago_set_vector_kernels.argtypes = [_int]
 _lib.lago_set_splat_shear.argtypes = [_int] * 8
 _lib.lago_set_fluid_xpass.argtypes = [_int]
 for _name in ("lago_set_launch_order", "lago_set_stencil_tile", "lago_set_gather_window", "lago_set_splat_mc", "lago_set_splat_shear_mc", "lago_set_fluid_xpass_ipw", "lago_set_fluid_zy_persist",
-              "lago_set_fluid_xpass_wide"):
+              "lago_set_fluid_xpass_wide", "lago_set_fluid_xpass_persist"):
     getattr(_lib, _name).argtypes = [_int]
 
 
@@ -174,9 +174,10 @@ def set_splat_shear_mc(mode):
     _lib.lago_set_splat_shear_mc(int(mode))
 
 
-def set_fluid_tuning(xpass_ipw=0, zy_persist=1, xpass_wide=1):
+def set_fluid_tuning(xpass_ipw=0, zy_persist=1, xpass_wide=1, xpass_persist=1):
     """FFT-pass fluid metric: batch items per x-pass workgroup (0 = by launch size), persistent zy kernels for
-    planes above 80 KB, 512-thread x pass for the 256-point tile.  Speed only."""
+    planes above 80 KB, 512-thread x pass for the 256-point tile, persistent prefetching x-pass grid.  Speed only."""
+    _lib.lago_set_fluid_xpass_persist(1 if xpass_persist else 0)
     _lib.lago_set_fluid_xpass_ipw(int(xpass_ipw))
     _lib.lago_set_fluid_zy_persist(1 if zy_persist else 0)
     _lib.lago_set_fluid_xpass_wide(1 if xpass_wide else 0)

@@ -20,8 +20,9 @@ met = lm.FluidMetric([0.1, 0.0, 0.01])
 ref = None
 for r in range(2):
     for persist in (1,):
-        for ipw in (0, 10, 11):   # 10 / 11: automatic items per workgroup with 256-thread / wide x-pass workgroups
+        for ipw in (0, 10, 11, 20):   # 10 / 11: automatic items per workgroup with 256-thread / wide x-pass workgroups; 20: one-shot x-pass workgroups
             lib.lago_set_fluid_zy_persist(persist)
+            lib.lago_set_fluid_xpass_persist(0 if ipw == 20 else 1)
             lib.lago_set_fluid_xpass_wide(0 if ipw == 10 else 1)
             lib.lago_set_fluid_xpass_ipw(0 if ipw >= 10 else ipw)
             out = met.sharp(m)
@@ -33,3 +34,4 @@ for r in range(2):
 lib.lago_set_fluid_zy_persist(1)
 lib.lago_set_fluid_xpass_ipw(0)
 lib.lago_set_fluid_xpass_wide(1)
+lib.lago_set_fluid_xpass_persist(1)
