@@ -434,16 +434,18 @@ static hipError_t zy_dispatch(int64_t ny, int64_t nz, const fl::ZYArgs &a, bool 
     return hipErrorInvalidValue;
 }
 
-std::atomic<int> g_xpass_persist{1};  // 1: persistent x-pass grid (two workgroups per CU) once the launch has enough pairs
+std::atomic<int> g_xpass_persist{1};  // 1: persistent x-pass grid (two workgroups per CU) once the launch has enough pairs; 2: always
 
 template <int NX, int NT>
 static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t s) {
     using K0 = fl::XPass<typename SzOf<NX>::T, false, NT>;
     // persistent: tiles that fit a CU twice, and at least four (bin tile, batch item) pairs per workgroup
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / K0::SMEM), grid = 256u * per_cu;
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / K0::SMEM);
     const uint64_t pairs = (uint64_t)a.nn * (uint64_t)a.items_per_n;
+    const int mode = g_xpass_persist;   // 2 (tests): whatever the size of the launch
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(256u * per_cu, pairs);
     // (192 points: 263 VGPRs, one 256-thread workgroup per CU -- stays with the one-shot workgroups)
-    const bool persist = g_xpass_persist && per_cu >= 2 && NX <= 160 && pairs >= 4ull * grid && pairs < (1ull << 32);
+    const bool persist = mode && per_cu >= 2 && NX <= 160 && (mode >= 2 || pairs >= 4ull * grid) && pairs < (1ull << 32);
     if (inverse) {
         using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
         if (persist) {

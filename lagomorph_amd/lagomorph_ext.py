@@ -177,7 +177,7 @@ def set_splat_shear_mc(mode):
 def set_fluid_tuning(xpass_ipw=0, zy_persist=1, xpass_wide=1, xpass_persist=1):
     """FFT-pass fluid metric: batch items per x-pass workgroup (0 = by launch size), persistent zy kernels for
     planes above 80 KB, 512-thread x pass for the 256-point tile, persistent prefetching x-pass grid.  Speed only."""
-    _lib.lago_set_fluid_xpass_persist(1 if xpass_persist else 0)
+    _lib.lago_set_fluid_xpass_persist(int(xpass_persist))
     _lib.lago_set_fluid_xpass_ipw(int(xpass_ipw))
     _lib.lago_set_fluid_zy_persist(1 if zy_persist else 0)
     _lib.lago_set_fluid_xpass_wide(1 if xpass_wide else 0)

@@ -636,6 +636,31 @@ def test_persistent_zy_passes_any_plane_count(ext, batch):
     assert torch.equal(got, plain)
 
 
+@pytest.mark.parametrize("shape,batch", [((64, 64, 64), 1), ((64, 96, 64), 3), ((128, 64, 96), 2), ((160, 64, 64), 5),
+                                         ((96, 32, 128), 7)])
+@pytest.mark.parametrize("inverse", [True, False])
+def test_persistent_x_pass_any_pair_count(ext, shape, batch, inverse):
+    """The x pass as a persistent grid: each workgroup walks a contiguous run of (bin tile, batch item) pairs with its
+    next tile prefetched and its coefficients held until the bin tile changes.  Forced on (mode 2) for launches with
+    fewer pairs than workgroups, runs that end inside a bin tile, runs of one pair, both launch directions: against
+    the oracle, and bit for bit against the one-shot workgroups."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(batch + shape[0])
+    m = rnd(rng, (batch, 3) + shape, torch.float32)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    op = met.sharp if inverse else met.flat
+    ext._lib.lago_set_fluid_xpass_persist(0)
+    try:
+        plain = op(dev(m))
+        ext._lib.lago_set_fluid_xpass_persist(2)
+        got = [op(dev(m)) for _ in range(2)]   # two calls: both launch directions (common.hpp: next_direction)
+    finally:
+        ext._lib.lago_set_fluid_xpass_persist(1)
+    assert_close(got[0], orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse), torch.float32, "persistent x pass vs oracle")
+    assert torch.equal(got[0], plain) and torch.equal(got[1], plain)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["near_identity", "rotation", "zoom", "flip"])
 @pytest.mark.parametrize("bc", [False, True])
