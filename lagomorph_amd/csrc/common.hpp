@@ -72,9 +72,8 @@ inline void note_path(int p) { g_path_launches[p].fetch_add(1, std::memory_order
 // Unsigned division by a runtime-constant divisor (n < 2^31): q = (mulhi(n, m) + n) >> l.
 struct FastDiv {
     uint32_t d, m, l;
-    FastDiv() : d(1), m(1), l(0) {}
-    explicit FastDiv(uint32_t dd) : d(dd) {
-        l = 0;
+    __host__ __device__ constexpr FastDiv() : d(1), m(1), l(0) {}
+    __host__ __device__ constexpr explicit FastDiv(uint32_t dd) : d(dd), m(0), l(0) {
         while ((1ull << l) < dd) ++l;
         m = (uint32_t)(((1ull << 32) * ((1ull << l) - dd)) / dd + 1);
     }

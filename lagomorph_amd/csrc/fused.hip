@@ -217,6 +217,7 @@ template __global__ void compose3_window_kernel<512, 8, true>(float *, const flo
 template __global__ void compose3_window_kernel<512, 8, false>(float *, const float *, const float *, double, double, Geom, GWGrid);
 
 std::atomic<int> g_gather_window{1};  // 1: LDS-window gathers where the shape allows (default); 0: pair gathers only
+std::atomic<int> g_tile_cube{1};      // 1: 128^3 / 160^3 volumes take the instantiations with compile-time geometry
 
 template <typename R>
 static bool compose_window_launch(R *out, const R *u, const R *v, double ds, double dt, const Geom &g, int64_t nn,
@@ -226,6 +227,8 @@ static bool compose_window_launch(R *out, const R *u, const R *v, double ds, dou
         if (!make_gwgrid(w, g, nn) || ((uintptr_t)v & 15u)) return false;
         constexpr int NT = 512, U = 8;
         const size_t smem = GW::lds_bytes<NT>();
+        // (compiling the geometry of 128^3 / 160^3 volumes in, as ad_star3_tile_kernel does, costs this kernel 2-15
+        // spilled registers at its 128: not done)
         if (unit_dt<R>(ds))
             hipLaunchKernelGGL((compose3_window_kernel<NT, U, true>), dim3(w.total), dim3(NT), smem, s, out, u, v, ds, dt, g, w);
         else
@@ -445,12 +448,28 @@ __global__ __launch_bounds__(kBlock) void ad_star3_unroll_kernel(R *__restrict__
 // / (TX TY) halo dwords per voxel through the vector-memory path instead of 24 + 3 + 18 (31.5 instead of 45 for the
 // 2 x 4-row tile of a 128-voxel row).  The momentum gathers are issued before the barrier, so their latency and the
 // staging overlap.  Arithmetic and its order are those of ad_star3_unroll_kernel: same bits.
-template <typename R, int NT, int U, int RI, int ZC>
+// CUBE > 0: the volume is CUBE^3 and the tile the one make_row_tile picks for it (checked by the host) -- the geometry
+// is a compile-time constant, which removes most of the scalar instructions of the tile / halo-row decode (about as
+// many scalar as vector instructions per wave in the generic form: both issue ports of a SIMD are equally loaded).
+template <typename R, int NT, int U, int RI, int ZC, int CUBE = 0>
 __global__ __launch_bounds__(NT) void ad_star3_tile_kernel(R *__restrict__ out, R *__restrict__ mphi,
                                                            const R *__restrict__ phi, const R *__restrict__ m, Geom g,
                                                            RowTile t) {
     extern __shared__ __align__(16) unsigned char lago_smem[];
     R *lds = reinterpret_cast<R *>(lago_smem);
+    if constexpr (CUBE > 0) {
+        constexpr int rows = NT * U / CUBE, TY = rows / 2;   // 2 x TY rows (2 x 4 at 128, 2 x 3 at 160)
+        g.nx = g.ny = g.nz = CUBE;
+        g.nvox = (uint32_t)CUBE * CUBE * CUBE;
+        t.TX = 2; t.TY = TY; t.RY = TY + 2; t.P = CUBE + 2;
+        t.nhrows = 2u * TY + 4u;
+        t.plane = 4u * (TY + 2) * (CUBE + 2);
+        t.ntx = CUBE / 2; t.nty = (CUBE + TY - 1) / TY;
+        t.tiles_per_item = t.ntx * t.nty;
+        t.tile_vox = 2u * TY * CUBE;
+        t.d_tiles = FastDiv(t.tiles_per_item); t.d_nty = FastDiv(t.nty); t.d_nz = FastDiv((uint32_t)CUBE);
+        t.d_TY = FastDiv((uint32_t)TY); t.d_nhrows = FastDiv(t.nhrows);
+    }
     const uint32_t Lb = block_order(blockIdx.x, t.total, g.rev);
     const uint32_t n = t.d_tiles.div(Lb);
     const uint32_t r = Lb - n * t.tiles_per_item;
@@ -544,6 +563,20 @@ static bool ad_star_tile_launch(R *out, R *mphi, const R *phi, const R *m, const
     const int zc = (g.nz + 63) / 64;
 #define LAGO_ADT(ZC)                                                                                               \
     hipLaunchKernelGGL((ad_star3_tile_kernel<R, NT, U, RI, ZC>), dim3(t.total), dim3(NT), smem, s, out, mphi, phi, m, g, t)
+    if constexpr (sizeof(R) == 4) {
+        // the two benchmark volumes with their geometry compiled in
+        const bool cube = g.nx == g.ny && g.ny == g.nz && t.TX == 2 && g_tile_cube;
+        if (cube && g.nz == 128 && t.TY == 4) {
+            hipLaunchKernelGGL((ad_star3_tile_kernel<R, NT, U, RI, 2, 128>), dim3(t.total), dim3(NT), smem, s, out, mphi, phi, m, g, t);
+            note_path(LP_STENCIL_TILE);
+            return true;
+        }
+        if (cube && g.nz == 160 && t.TY == 3) {
+            hipLaunchKernelGGL((ad_star3_tile_kernel<R, NT, U, RI, 3, 160>), dim3(t.total), dim3(NT), smem, s, out, mphi, phi, m, g, t);
+            note_path(LP_STENCIL_TILE);
+            return true;
+        }
+    }
     if (zc == 1) LAGO_ADT(1);
     else if (zc == 2) LAGO_ADT(2);
     else if (zc == 3) LAGO_ADT(3);
@@ -642,7 +675,10 @@ int lincomb_impl(R *out, int k, const R *x0, const R *x1, const R *x2, const R *
 }  // namespace lago
 
 extern "C" {
-void lago_set_stencil_tile(int on) { lago::g_stencil_tile = on ? 1 : 0; }
+void lago_set_stencil_tile(int on) {   // 0: direct kernels; 1: row tiles (default); 3: row tiles without the compile-time-geometry instantiations
+    lago::g_stencil_tile = on ? 1 : 0;
+    lago::g_tile_cube = on == 3 ? 0 : 1;
+}
 void lago_set_gather_window(int on) { lago::g_gather_window = on ? 1 : 0; }
 int lago_lincomb_f32(float *out, int k, const float *x0, const float *x1, const float *x2, const float *x3, double c0,
                      double c1, double c2, double c3, int64_t n, void *stream) {

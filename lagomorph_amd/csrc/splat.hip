@@ -873,6 +873,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
             ruy[it] = lg_fma(gy, diff, ruy[it]);
             ruz[it] = lg_fma(gz, diff, ruz[it]);
         }
+        // The next channel's grad_out values (requested at the top of this channel) are waited for HERE, in front of the
+        // flush: loads and atomics count in one in-order counter, so a wait placed behind the flush -- where the values
+        // are consumed -- would also wait for every flush atomic to be acknowledged (~1 us with all CUs flushing)
+        // before the next channel's gathers could even be issued.
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) asm volatile("" : "+v"(pgv[it]));
         __syncthreads();
         // flush touched cells (one wave per window row, lanes along z) and re-zero them for the next channel
         {

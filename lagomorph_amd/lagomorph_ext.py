@@ -191,8 +191,9 @@ def set_launch_order(alternate):
 
 def set_stencil_tile(on):
     """1 (default): LDS row-tile stencil kernels (Ad_star, jacobian_times_vectorfield_backward) where shapes allow;
-    0: the direct one-lane-per-voxel kernels.  Same bits."""
-    _lib.lago_set_stencil_tile(1 if on else 0)
+    0: the direct one-lane-per-voxel kernels; 3: row tiles without the compile-time-geometry instantiations for 128^3 /
+    160^3 volumes.  Same bits."""
+    _lib.lago_set_stencil_tile(int(on))
 
 
 _lib.lago_path_launches.restype = ctypes.c_longlong

@@ -242,3 +242,25 @@ def test_fused_operators_128cubed(lm):
     finally:
         ext.set_fluid_mode(2)
     assert (got[2] - got[0]).abs().max().item() <= 2e-5 * got[0].abs().max().item()
+
+
+@pytest.mark.parametrize("S", [128, 160])
+def test_ad_star_compile_time_geometry_same_bits(lm, S):
+    """128^3 and 160^3 volumes run ad_star3_tile_kernel with the geometry compiled in (fewer scalar instructions):
+    same bits as the generic row-tile kernel (set_stencil_tile(3)), the direct kernel (0) and the unfused sequence,
+    with and without the saved resampled momentum."""
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device="cuda").manual_seed(S)
+    sh = (2, 3, S, S, S)
+    phi = smooth(sh, 6.0, g)
+    phi = phi * (4.0 / phi.abs().max())
+    m = torch.randn(sh, device="cuda", generator=g)
+    want = ext.jacobian_times_vectorfield_forward(phi, ext.interp_forward(m, phi, 1.0), True, False)
+    try:
+        for mode in (1, 3, 0):
+            ext.set_stencil_tile(mode)
+            assert torch.equal(ext.Ad_star(phi, m), want), mode
+            out, kept = ext.Ad_star(phi, m, save_resampled=True)
+            assert torch.equal(out, want) and torch.equal(kept, ext.interp_forward(m, phi, 1.0)), mode
+    finally:
+        ext.set_stencil_tile(1)
