@@ -653,7 +653,7 @@ def main():
         # separately): all four candidates move 36 algorithmic bytes per voxel at C = 3
         cands = {
             "Ad_star": ("ad_star3_tile_kernel<float,512,2,5,2>", "lago::ad_star3_tile_kernel<float"),
-            "compose": ("compose3_unroll_kernel<float,2,false>", "lago::compose3_unroll_kernel<float"),
+            "compose": ("compose3_window_kernel<512,8,false>", "lago::compose3_window_kernel<512"),
             "interp_forward": ("interp_fwd3_unroll_kernel<float,false,2,true> (C=3)", "lago::interp_fwd3_unroll_kernel<float"),
             "jacobian_times_vectorfield_forward": ("jtv_fwd_kernel<float,3,true,false>", "lago::jtv_fwd_kernel<float, 3, true"),
         }

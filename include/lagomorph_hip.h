@@ -117,7 +117,7 @@ void lago_set_fluid_xpass_ipw(int items);
 void lago_set_fluid_zy_persist(int on);
 void lago_set_fluid_xpass_wide(int on);
 /* x pass as a persistent grid of two workgroups per CU that prefetch their next tile (default 1; taken when the
- * launch has at least four (bin tile, batch item) pairs per workgroup; 2: whatever its size; 0: one-shot workgroups).
+ * launch has at least eight (bin tile, batch item) pairs per workgroup; 2: whatever its size; 0: one-shot workgroups).
  * Same bits under every setting. */
 void lago_set_fluid_xpass_persist(int on);
 

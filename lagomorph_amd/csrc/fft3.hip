@@ -28,6 +28,9 @@ template <> struct SzOf<256> { using T = fl::Sz<1, 8>; };
 
 template <int NY, int NZ>
 using ZYK = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T>;
+// the fused 2D kernel holds BOTH component planes: above 80 KB of LDS it has its CU to itself and runs 1024 threads
+template <int NY, int NZ>
+using ZYK2D = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T, (2 * NY * (NZ / 2 + 1) * 8 > 80 * 1024 ? 1024 : 512)>;
 
 template <int NY, int NZ>
 __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_kernel(fl::ZYArgs a) {
@@ -163,11 +166,11 @@ __device__ __forceinline__ R fl2d_safe_sqrt(R x) {  // cuda/metric.cu:14-18
 }
 
 template <int NY, int NZ, bool INV>
-__global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void fluid2d_kernel(float *__restrict__ out, const float *__restrict__ m,
+__global__ __launch_bounds__((ZYK2D<NY, NZ>::THREADS)) void fluid2d_kernel(float *__restrict__ out, const float *__restrict__ m,
                                                                        const float *__restrict__ cosX, const float *__restrict__ sinX,
                                                                        const float *__restrict__ cosY, const float *__restrict__ sinY,
                                                                        double alpha, double beta, double gamma, float scale) {
-    using K = ZYK<NY, NZ>;
+    using K = ZYK2D<NY, NZ>;
     using SY = typename SzOf<NY>::T;
     using SZH = typename SzOf<NZ / 2>::T;
     constexpr int NT = K::THREADS, PZ = K::PZ, NZH = K::NZH;
@@ -257,7 +260,7 @@ template <int NY, int NZ>
 static hipError_t fluid2d_launch(float *out, const float *m, int inverse, const float *cosX, const float *sinX,
                                  const float *cosY, const float *sinY, double alpha, double beta, double gamma,
                                  int64_t nn, hipStream_t s) {
-    using K = ZYK<NY, NZ>;
+    using K = ZYK2D<NY, NZ>;
     constexpr size_t smem = (size_t)(2 * NY * K::PZ + K::LTW) * sizeof(float2);
     static_assert(smem <= 160 * 1024, "two planes do not fit the LDS");
     const float scale = (float)(1.0 / ((double)NY * (double)NZ));
@@ -439,13 +442,14 @@ std::atomic<int> g_xpass_persist{1};  // 1: persistent x-pass grid (two workgrou
 template <int NX, int NT>
 static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t s) {
     using K0 = fl::XPass<typename SzOf<NX>::T, false, NT>;
-    // persistent: tiles that fit a CU twice, and at least four (bin tile, batch item) pairs per workgroup
+    // persistent: tiles that fit a CU twice, and at least eight (bin tile, batch item) pairs per workgroup (below that the
+    // one-shot workgroups are as fast or faster: 142 against 146 us per sharp at 4 x 128^3, tools/ab_fluid.py)
     const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / K0::SMEM);
     const uint64_t pairs = (uint64_t)a.nn * (uint64_t)a.items_per_n;
     const int mode = g_xpass_persist;   // 2 (tests): whatever the size of the launch
     const uint32_t grid = (uint32_t)std::min<uint64_t>(256u * per_cu, pairs);
     // (192 points: 263 VGPRs, one 256-thread workgroup per CU -- stays with the one-shot workgroups)
-    const bool persist = mode && per_cu >= 2 && NX <= 160 && (mode >= 2 || pairs >= 4ull * grid) && pairs < (1ull << 32);
+    const bool persist = mode && per_cu >= 2 && NX <= 160 && (mode >= 2 || pairs >= 8ull * grid) && pairs < (1ull << 32);
     if (inverse) {
         using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
         if (persist) {
