@@ -70,7 +70,8 @@ void lago_set_vector_kernels(int on);
  * ascending.  Same results (scatter-add outputs differ in their last bits, as between any two runs). */
 void lago_set_launch_order(int alternate);
 /* 1 (default): the 3D Jacobian / stencil terms of Ad_star and jacobian_times_vectorfield_backward are taken from an
- * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows; 0: every
+ * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows -- 128^3 and 160^3
+ * volumes through instantiations with their geometry compiled in; 3: row tiles without those instantiations; 0: every
  * neighbour is loaded from global memory.  Same bits. */
 void lago_set_stencil_tile(int on);
 /* 1 (default): float32 3D trilinear gathers of smooth fields (compose) stage the source block of a
