@@ -6,6 +6,7 @@
 // voxel, last axis fastest: u / grad_out / out / d_u stream as 256-byte
 // wavefront rows, the 8 (4) lerp corners are gathers served by L1/L2.
 #include "common.hpp"
+#include "gather_window.hpp"
 
 namespace lago {
 
@@ -97,6 +98,132 @@ __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restric
         for (int e = 0; e < U; ++e)
             if (ok[e]) on[(size_t)c * nv + s[e]] = o[e];
     }
+}
+
+// LDS-window variant (gather_window.hpp; compose3_window_kernel of fused.hip is the three-channel form with the
+// axpy): the nc channels of I go through one 48 KB window in turn, the displacement stays in registers.  Same
+// expressions as Lerp3: bit-identical to interp_fwd3_unroll_kernel; samples whose corners leave the window take them
+// with that kernel's pair gathers, lane by lane.
+template <int NT, int U, bool UNIT, bool BC>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void interp3_window_kernel(
+    float *__restrict__ out, const float *__restrict__ I, const float *__restrict__ u, double dt, int nc, Geom g, GWGrid w) {
+    extern __shared__ float gwin[];
+    constexpr int XS = NT / 512;
+    static_assert(XS * U == GW::TX && NT == 512, "tile shape");
+    const GWTile tl = gw_tile(w, g.rev);
+    const size_t nv = g.nvox;
+    const uint32_t plane = g.nvox * 4u;
+    const float *un = u + (size_t)tl.n * 3 * nv;
+    const float *In = BC ? I : I + (size_t)tl.n * nc * nv;
+    float *on = out + (size_t)tl.n * nc * nv;
+    const int lz = threadIdx.x & 31, ly = (threadIdx.x >> 5) & 15, lxb = threadIdx.x >> 9;
+    const int j = tl.y0 + ly, k = tl.z0 + lz;
+
+    GWOrigin o;
+    {
+        const int cxi = min(tl.x0 + GW::TX / 2, g.nx - 1), cyi = min(tl.y0 + GW::TY / 2, g.ny - 1),
+                  czi = min(tl.z0 + GW::TZ / 2, g.nz - 1);
+        const uint32_t cs = ((uint32_t)cxi * (uint32_t)g.ny + (uint32_t)cyi) * (uint32_t)g.nz + (uint32_t)czi;
+        o = gw_origin(tl, g, lg_floor(sample_pos_t<float, UNIT>(cxi, dt, un[cs])),
+                      lg_floor(sample_pos_t<float, UNIT>(cyi, dt, un[nv + cs])),
+                      lg_floor(sample_pos_t<float, UNIT>(czi, dt, un[2 * nv + cs])));
+    }
+    GWLoader<NT> ld;
+    ld.plan(o, g);
+    ld.issue(In, plane, gwin);
+
+    const bool row_ok = j < g.ny && k < g.nz;
+    const uint32_t off0 = (((uint32_t)(tl.x0 + lxb) * (uint32_t)g.ny + (uint32_t)j) * (uint32_t)g.nz + (uint32_t)k) * 4u;
+    const uint32_t estep = (uint32_t)XS * (uint32_t)g.ny * (uint32_t)g.nz * 4u;
+    auto voff = [&](int e) { return row_ok && tl.x0 + lxb + XS * e < g.nx ? off0 + (uint32_t)e * estep : GW::kOutside; };
+    GWLerp L[U];
+    uint32_t outm = 0;  // bit e: sample e has a corner outside the window
+    float uu[3][U];
+    {
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) uu[d][e] = buf_load1<float>(make_rsrc(un + (size_t)d * nv, plane), voff(e));
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const int i = tl.x0 + lxb + XS * e;
+            const bool in = L[e].setup(sample_pos_t<float, UNIT>(i, dt, uu[0][e]), sample_pos_t<float, UNIT>(j, dt, uu[1][e]),
+                                       sample_pos_t<float, UNIT>(k, dt, uu[2][e]), g, o);
+            outm |= (in | (voff(e) == GW::kOutside)) ? 0u : 1u << e;
+            __builtin_amdgcn_sched_barrier(0);  // one sample at a time (registers), as in compose3_window_kernel
+        }
+    }
+    auto channels = [&](auto stray) {
+        constexpr bool STRAY = decltype(stray)::value;
+        for (int c = 0; c < nc; ++c) {
+            if (c > 0) {
+                // channel c's window must have landed: in this rolled loop the LDS-direct loads were issued on the other
+                // side of the back edge, so the wait is spelled out (in compose3_window_kernel's unrolled loop hipcc
+                // inserts it in front of the barrier by itself)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            const float *Ic = In + (size_t)c * nv;
+            const BufRsrc ro = make_rsrc(on + (size_t)c * nv, plane);
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                float q[8];
+                L[e].fetch(gwin, q);
+                float val = L[e].value_of(q);
+                if constexpr (STRAY) {
+                    const bool mine = outm & (1u << e);
+                    if (__builtin_amdgcn_ballot_w64(mine) != 0) {  // wave-uniform
+                        if (mine) {
+                            const int i = tl.x0 + lxb + XS * e;
+                            Lerp3<float, false> P;
+                            P.setup(sample_pos_t<float, UNIT>(i, dt, uu[0][e]), sample_pos_t<float, UNIT>(j, dt, uu[1][e]),
+                                    sample_pos_t<float, UNIT>(k, dt, uu[2][e]), g.nx, g.ny, g.nz);
+                            val = P.value(Ic);
+                        }
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ro, voff(e), 0, 0);
+            }
+            if (c + 1 < nc) {
+                __syncthreads();  // everyone has read channel c: the window is free
+                ld.issue(Ic + nv, plane, gwin);
+            }
+        }
+    };
+    // channel 0's window has landed behind this barrier (the compiler waits for the LDS-direct loads first)
+    if (__syncthreads_or(outm != 0))
+        channels(std::true_type{});
+    else
+        channels(std::false_type{});
+}
+
+// (explicit instantiations: hipcc 7.2 drops the host stub of a variant that is only named in the `else` of a launch)
+template __global__ void interp3_window_kernel<512, 8, true, true>(float *, const float *, const float *, double, int, Geom, GWGrid);
+template __global__ void interp3_window_kernel<512, 8, true, false>(float *, const float *, const float *, double, int, Geom, GWGrid);
+template __global__ void interp3_window_kernel<512, 8, false, true>(float *, const float *, const float *, double, int, Geom, GWGrid);
+template __global__ void interp3_window_kernel<512, 8, false, false>(float *, const float *, const float *, double, int, Geom, GWGrid);
+
+extern std::atomic<int> g_gather_window;   // fused.hip
+
+template <typename R>
+static bool interp_window_launch(R *out, const R *I, const R *u, double dt, int nc, bool bc, const Geom &g, int64_t nn,
+                                 hipStream_t s) {
+    if constexpr (sizeof(R) == 4) {
+        GWGrid w;
+        if (!make_gwgrid(w, g, nn) || ((uintptr_t)I & 15u)) return false;
+        constexpr int NT = 512, U = 8;
+        const size_t smem = GW::lds_bytes<NT>();
+        const bool unit = unit_dt<R>(dt);
+#define LAGO_IW(UN, B) \
+    hipLaunchKernelGGL((interp3_window_kernel<NT, U, UN, B>), dim3(w.total), dim3(NT), smem, s, out, I, u, dt, nc, g, w)
+        if (unit) { if (bc) LAGO_IW(true, true); else LAGO_IW(true, false); }
+        else { if (bc) LAGO_IW(false, true); else LAGO_IW(false, false); }
+#undef LAGO_IW
+        note_path(LP_GATHER_WINDOW);
+        return true;
+    }
+    return false;
 }
 
 // ------------------------------------------------------------------ backward, global atomics
@@ -218,6 +345,11 @@ static int interp_forward_impl(R *out, const R *I, const R *u, double dt, int di
     if (!out || !I || !u) return fail_invalid("interp_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     constexpr int U = 2;
+    // several channels: through the LDS window (-11 ... -21 % at C = 3); ONE channel does not pay for the window's setup
+    // and barrier (81 -> 79 us at 8 x 128^3, slower at 10-voxel deformations and for a broadcast image: tools/ab_interp_window.py)
+    if (dim == 3 && g_interp_vec && g_gather_window && nc >= 2 && g.nvox >= 32768u &&
+        interp_window_launch<R>(out, I, u, dt, (int)nc, bc != 0, g, nn, s))
+        return finish_launch(s, "interp_forward");
     if (dim == 3 && g_interp_vec && g.nz >= 2 && kBlock / g.nz + 1 < g.ny && g.nvox >= 4u * U * kBlock) {
         const uint32_t nbx_u = (g.nvox + U * kBlock - 1) / (U * kBlock);
         const uint64_t nb = (uint64_t)nbx_u * (uint64_t)nn;

@@ -36,7 +36,8 @@ def test_headline_operators_take_their_fast_paths(lm, sp):
     # one 32^3 item is too small for the row tiles (make_row_tile wants full workgroups): it takes the direct kernel
     assert _delta(shim, lambda: shim.Ad_star(u, v)) == {"vector_gather" if sp == (32, 32, 32) else "stencil_tile": 1}
     I = _fields(1, 1, sp)
-    assert _delta(shim, lambda: shim.interp_forward(I, u, 1.0)) == {"vector_gather": 1}
+    assert _delta(shim, lambda: shim.interp_forward(I, u, 1.0)) == {"vector_gather": 1}     # one channel: pair gathers
+    assert _delta(shim, lambda: shim.interp_forward(v, u, 1.0)) == {"gather_window": 1}     # several: through the LDS window
     go = _fields(1, 1, sp)
     assert _delta(shim, lambda: shim.interp_backward(go, I, u, 1.0, True, True)) == {"splat_shear": 1}
     go3 = _fields(1, 3, sp)

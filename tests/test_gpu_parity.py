@@ -426,6 +426,36 @@ def test_lds_window_gather_same_bits(ext, case):
         shim.set_gather_window(1)
 
 
+@pytest.mark.parametrize("case", WINDOW_CASES, ids=[f"{c[0]}-a{c[1]}-s{c[2]}-r{c[3]}" for c in WINDOW_CASES])
+@pytest.mark.parametrize("nc,bc", [(2, False), (2, True), (3, False), (4, True)])
+def test_lds_window_interp_forward_same_bits(ext, case, nc, bc):
+    """interp_forward of two or more channels through the LDS window (interp3_window_kernel: the channels in turn through
+    one window, broadcast or per-item images) == the pair-gather kernel == the oracle, bit for bit, over the window cases
+    of compose.  (One channel stays on the pair gathers: the window does not pay there.)"""
+    import lagomorph_amd.lagomorph_ext as shim
+
+    sp, amp, shift, rough = case
+    rng = np.random.default_rng((hash(case) + 7 * nc + bc) % 2**31)
+    u = _smooth_disp(rng, 3, sp, amp, shift, rough)
+    u.reshape(-1)[::997] = np.round(u.reshape(-1)[::997])  # exact-integer positions
+    I = rnd(rng, ((1 if bc else 3), nc) + sp, torch.float32)
+    ud, Id = dev(u), dev(I)
+    try:
+        for dt in (1.0, -1.0, 0.7):
+            want = orc.interp_forward(I, u, dt)
+            outs = {}
+            for mode in (0, 1):
+                shim.set_gather_window(mode)
+                before = shim.path_launches("gather_window")
+                outs[mode] = ext.interp_forward(Id, ud, dt)
+                took = shim.path_launches("gather_window") - before
+                assert took == (1 if mode == 1 and sp != (24, 16, 36) else 0), (mode, sp, took)
+                assert_bits(outs[mode], want, f"interp_forward window mode {mode} dt={dt}")
+            assert torch.equal(outs[1], outs[0])
+    finally:
+        shim.set_gather_window(1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp", [(8, 6, 10), (7, 5, 9), (16, 16, 16), (12, 10), (9, 7)])
 @pytest.mark.parametrize("inverse", [True, False])
