@@ -62,20 +62,19 @@ __global__ __launch_bounds__(K::THREADS) void zy_inv(fl::ZYArgs a, int never) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *P = reinterpret_cast<float2 *>(smem), *tw = P + K::NY * K::PZ;
     K::fill_twiddles(threadIdx.x, tw);
-    float4 v[K::KV];
-    float4 c0;
+    float4 v[K::KVX];
     size_t pq = blockIdx.x;
-    K::inv_load(threadIdx.x, a.main_ + pq * (size_t)(K::NY * K::NZH), a.nyq + pq * (size_t)K::NY, v, c0);
+    K::inv_load(threadIdx.x, a.main_ + pq * (size_t)(K::NY * K::NZH), a.nyq + pq * (size_t)K::NY, v);
     for (; pq < a.total; pq += gridDim.x) {
         const size_t p = pq;
-        K::inv_fill(threadIdx.x, v, c0, P);
+        K::inv_fill(threadIdx.x, v, P);
         __syncthreads();
         const bool more = pq + gridDim.x < a.total;
         const float2 *nmain = a.main_ + (pq + gridDim.x) * (size_t)(K::NY * K::NZH), *nnyq = a.nyq + (pq + gridDim.x) * (size_t)K::NY;
         if (MODE != 5 && (MODE != 2 || never))
             if (more) {
                 const size_t pn = pq + gridDim.x;
-                K::inv_load(threadIdx.x, a.main_ + pn * (size_t)(K::NY * K::NZH), a.nyq + pn * (size_t)K::NY, v, c0);
+                K::inv_load(threadIdx.x, a.main_ + pn * (size_t)(K::NY * K::NZH), a.nyq + pn * (size_t)K::NY, v);
             }
         float *out = a.out + p * (size_t)(K::NY * K::NZ);
 #pragma unroll
@@ -87,15 +86,11 @@ __global__ __launch_bounds__(K::THREADS) void zy_inv(fl::ZYArgs a, int never) {
 #pragma unroll
                 for (int k = (ph - 1) * K::KV / NS; k < ph * K::KV / NS; ++k)
                     if (threadIdx.x + k * K::THREADS < K::F4) v[k] = reinterpret_cast<const float4 *>(nmain)[threadIdx.x + k * K::THREADS];
-                if (ph == 1 && threadIdx.x < K::NY) {
-                    const float2 x = nmain[threadIdx.x * K::NZH], y = nnyq[threadIdx.x];
-                    c0 = make_float4(x.x, x.y, y.x, y.y);
-                }
+                if (ph == NS) K::inv_load_c0(threadIdx.x, nmain, nnyq, v);
             }
             if (MODE >= 4 && ph == K::NPH_INV - 1) {
 #pragma unroll
-                for (int k = 0; k < K::KV; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
-                asm volatile("" : "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(c0.w));
+                for (int k = 0; k < K::KVX; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
             }
             K::inv_phase(ph, threadIdx.x, out, nullptr, nullptr, P, tw);
             __syncthreads();
@@ -106,6 +101,24 @@ __global__ __launch_bounds__(K::THREADS) void zy_inv(fl::ZYArgs a, int never) {
 __global__ __launch_bounds__(K::THREADS) void zy_fwd_plain(fl::ZYArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *P = reinterpret_cast<float2 *>(smem), *tw = P + K::NY * K::PZ;
+    const size_t p = blockIdx.x;
+#pragma unroll
+    for (int ph = 0; ph < K::NPH; ++ph) {
+        K::fwd_phase(ph, threadIdx.x, a.in + p * (size_t)(K::NY * K::NZ), a.main_ + p * (size_t)(K::NY * K::NZH),
+                     a.nyq + p * (size_t)K::NY, P, tw);
+        if (ph + 1 < K::NPH) __syncthreads();
+    }
+}
+
+// 128 x 128 planes, one workgroup per plane (two per CU), the second workgroup of every CU optionally started late:
+// does breaking the lock-step of a launch with few rounds help?  (usage: zy_probe <batch> 128)
+using K128 = fl::ZY<fl::Sz<1, 7>, fl::Sz<1, 6>>;
+__global__ __launch_bounds__(K128::THREADS) void zy128_fwd_plain(fl::ZYArgs a, int sleeps, int every) {
+    using K = K128;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *P = reinterpret_cast<float2 *>(smem), *tw = P + K::NY * K::PZ;
+    if ((blockIdx.x / every) & 1)
+        for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     const size_t p = blockIdx.x;
 #pragma unroll
     for (int ph = 0; ph < K::NPH; ++ph) {
@@ -126,8 +139,29 @@ static float time_us(F launch, int iters = 20) {
     return ms * 1e3f / iters;
 }
 
+static int main128(int nn) {
+    using K = K128;
+    const uint32_t planes = (uint32_t)nn * 3 * 128;
+    const size_t nreal = (size_t)planes * K::NY * K::NZ, nc = (size_t)planes * K::NY * (K::NZH + 1);
+    float *in; float2 *work;
+    CK(hipMalloc(&in, nreal * 4)); CK(hipMalloc(&work, nc * 8));
+    CK(hipMemset(in, 0, nreal * 4)); CK(hipMemset(work, 0, nc * 8));
+    fl::ZYArgs a;
+    a.in = in; a.out = nullptr; a.main_ = work; a.nyq = work + (size_t)planes * K::NY * K::NZH; a.total = planes; a.rev = 0;
+    const double bytes = (double)nreal * 4 + (double)nc * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(zy128_fwd_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    printf("128 x 128 planes: %u (batch %d), %d threads, LDS %zu B\n", planes, nn, K::THREADS, (size_t)K::SMEM);
+    for (int every : {256, 1})
+        for (int sleeps : {0, 1, 2, 3, 4}) {
+            float t = time_us([&] { hipLaunchKernelGGL(zy128_fwd_plain, dim3(planes), dim3(K::THREADS), K::SMEM, 0, a, sleeps, every); });
+            printf("late start of every other %s: %d x s_sleep(127)  %7.1f us  %5.2f TB/s\n", every == 1 ? "workgroup      " : "256 workgroups ", sleeps, t, bytes / (t * 1e-6) / 1e12);
+        }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const int nn = argc > 1 ? atoi(argv[1]) : 8;
+    if (argc > 2 && atoi(argv[2]) == 128) return main128(nn);
     const uint32_t planes = (uint32_t)nn * 3 * 160;
     const size_t nreal = (size_t)planes * K::NY * K::NZ, nc = (size_t)planes * K::NY * (K::NZH + 1);
     float *in, *out; float2 *work;
