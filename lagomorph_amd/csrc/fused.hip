@@ -115,11 +115,11 @@ __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__
 // Same expressions as compose3_unroll_kernel; samples whose corners leave the window take them with that kernel's
 // pair gathers.
 template <int NT, int U, bool UNIT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void compose3_window_kernel(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void compose3_window_kernel(
     float *__restrict__ out, const float *__restrict__ u, const float *__restrict__ v, double ds, double dt, Geom g, GWGrid w) {
     extern __shared__ float gwin[];
-    constexpr int XS = NT / 512;
-    static_assert(XS * U == GW::TX && (NT == 512 || NT == 1024), "tile shape");  // 1024 x 4 has 64 VGPRs: measured slower
+    constexpr int XS = NT / (32 * GW::TY);
+    static_assert(XS * U == GW::TX && NT % (32 * GW::TY) == 0, "tile shape");  // 1024 x 4 has 64 VGPRs: measured slower
     const GWTile tl = gw_tile(w, g.rev);
     const size_t nv = g.nvox;
     const uint32_t plane = g.nvox * 4u;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
     const float *vn = v + (size_t)tl.n * 3 * nv;
     float *on = out + (size_t)tl.n * 3 * nv;
     const float dsr = (float)ds, dtr = (float)dt;
-    const int lz = threadIdx.x & 31, ly = (threadIdx.x >> 5) & 15, lxb = threadIdx.x >> 9;
+    const int lz = threadIdx.x & 31, ly = (threadIdx.x >> 5) & (GW::TY - 1), lxb = threadIdx.x / (32 * GW::TY);
     const int j = tl.y0 + ly, k = tl.z0 + lz;
 
     // window origin from the tile's centre voxel (uniform loads), then start moving channel 0
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
 }
 
 // (explicit instantiations: hipcc 7.2 drops the host stub of a variant that is only named in the `else` of a launch)
-template __global__ void compose3_window_kernel<512, 8, true>(float *, const float *, const float *, double, double, Geom, GWGrid);
-template __global__ void compose3_window_kernel<512, 8, false>(float *, const float *, const float *, double, double, Geom, GWGrid);
+template __global__ void compose3_window_kernel<GW::NT, 8, true>(float *, const float *, const float *, double, double, Geom, GWGrid);
+template __global__ void compose3_window_kernel<GW::NT, 8, false>(float *, const float *, const float *, double, double, Geom, GWGrid);
 
 std::atomic<int> g_gather_window{1};  // 1: LDS-window gathers where the shape allows (default); 0: pair gathers only
 std::atomic<int> g_tile_cube{1};      // 1: 128^3 / 160^3 volumes take the instantiations with compile-time geometry
@@ -225,7 +225,7 @@ static bool compose_window_launch(R *out, const R *u, const R *v, double ds, dou
     if constexpr (sizeof(R) == 4) {
         GWGrid w;
         if (!make_gwgrid(w, g, nn) || ((uintptr_t)v & 15u)) return false;
-        constexpr int NT = 512, U = 8;
+        constexpr int NT = GW::NT, U = 8;
         const size_t smem = GW::lds_bytes<NT>();
         // (compiling the geometry of 128^3 / 160^3 volumes in, as ad_star3_tile_kernel does, costs this kernel 2-15
         // spilled registers at its 128: not done)

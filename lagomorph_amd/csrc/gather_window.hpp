@@ -21,7 +21,11 @@
 namespace lago {
 
 struct GW {
-    static constexpr int TX = 8, TY = 16, TZ = 32, H = 2, HZ = 4;
+#ifndef LAGO_GW_TY
+#define LAGO_GW_TY 16
+#endif
+    static constexpr int TX = 8, TY = LAGO_GW_TY, TZ = 32, H = 2, HZ = 4;
+    static constexpr int NT = 32 * TY;   // threads of a workgroup: lane = z, TY rows of y, one x slab, TX voxels per lane along x
     static constexpr int WX = TX + 1 + 2 * H, WY = TY + 1 + 2 * H, WZC = 11, WZ = 4 * WZC;
     static constexpr int NCHUNK = WX * WY * WZC;
     static constexpr uint32_t kOutside = 0x80000000u;  // beyond any plane (nvox * 8 < 2^32): reads 0

@@ -105,18 +105,18 @@ __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restric
 // expressions as Lerp3: bit-identical to interp_fwd3_unroll_kernel; samples whose corners leave the window take them
 // with that kernel's pair gathers, lane by lane.
 template <int NT, int U, bool UNIT, bool BC>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT / 128))) void interp3_window_kernel(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void interp3_window_kernel(
     float *__restrict__ out, const float *__restrict__ I, const float *__restrict__ u, double dt, int nc, Geom g, GWGrid w) {
     extern __shared__ float gwin[];
-    constexpr int XS = NT / 512;
-    static_assert(XS * U == GW::TX && NT == 512, "tile shape");
+    constexpr int XS = NT / (32 * GW::TY);
+    static_assert(XS * U == GW::TX && NT % (32 * GW::TY) == 0, "tile shape");
     const GWTile tl = gw_tile(w, g.rev);
     const size_t nv = g.nvox;
     const uint32_t plane = g.nvox * 4u;
     const float *un = u + (size_t)tl.n * 3 * nv;
     const float *In = BC ? I : I + (size_t)tl.n * nc * nv;
     float *on = out + (size_t)tl.n * nc * nv;
-    const int lz = threadIdx.x & 31, ly = (threadIdx.x >> 5) & 15, lxb = threadIdx.x >> 9;
+    const int lz = threadIdx.x & 31, ly = (threadIdx.x >> 5) & (GW::TY - 1), lxb = threadIdx.x / (32 * GW::TY);
     const int j = tl.y0 + ly, k = tl.z0 + lz;
 
     GWOrigin o;
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 128, NT
 }
 
 // (explicit instantiations: hipcc 7.2 drops the host stub of a variant that is only named in the `else` of a launch)
-template __global__ void interp3_window_kernel<512, 8, true, true>(float *, const float *, const float *, double, int, Geom, GWGrid);
-template __global__ void interp3_window_kernel<512, 8, true, false>(float *, const float *, const float *, double, int, Geom, GWGrid);
-template __global__ void interp3_window_kernel<512, 8, false, true>(float *, const float *, const float *, double, int, Geom, GWGrid);
-template __global__ void interp3_window_kernel<512, 8, false, false>(float *, const float *, const float *, double, int, Geom, GWGrid);
+template __global__ void interp3_window_kernel<GW::NT, 8, true, true>(float *, const float *, const float *, double, int, Geom, GWGrid);
+template __global__ void interp3_window_kernel<GW::NT, 8, true, false>(float *, const float *, const float *, double, int, Geom, GWGrid);
+template __global__ void interp3_window_kernel<GW::NT, 8, false, true>(float *, const float *, const float *, double, int, Geom, GWGrid);
+template __global__ void interp3_window_kernel<GW::NT, 8, false, false>(float *, const float *, const float *, double, int, Geom, GWGrid);
 
 extern std::atomic<int> g_gather_window;   // fused.hip
 
@@ -212,7 +212,7 @@ static bool interp_window_launch(R *out, const R *I, const R *u, double dt, int 
     if constexpr (sizeof(R) == 4) {
         GWGrid w;
         if (!make_gwgrid(w, g, nn) || ((uintptr_t)I & 15u)) return false;
-        constexpr int NT = 512, U = 8;
+        constexpr int NT = GW::NT, U = 8;
         const size_t smem = GW::lds_bytes<NT>();
         const bool unit = unit_dt<R>(dt);
 #define LAGO_IW(UN, B) \
