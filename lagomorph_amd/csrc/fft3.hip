@@ -2,9 +2,11 @@
 // The transforms and the per-frequency operator are in fft_lds.hpp (host-verifiable phase
 // functions); this file holds the kernels around them and the launch logic.
 //
-//   zy_forward_kernel : grid = nn*3*nx planes, 512 threads, LDS = ny*(nz/2+1)*8 B
-//   fluid_xpass2_kernel: grid = nn*(ny*(nz/32) + ny/16) tiles of 3 x nx x 16 bins, 256 threads
-//   zy_inverse_kernel : grid = nn*3*nx planes
+//   zy_forward_kernel : grid = nn*3*nx planes, 512 threads, LDS = ny*(nz/2+1)*8 B (planes below 80 KB: two per CU);
+//                       zy_forward_persist_kernel: one persistent 1024-thread workgroup per CU for larger planes
+//   fluid_xpass2_kernel: grid = nn*(ny*(nz/32) + ny/16) tiles of 3 x nx x 16 bins, 256 threads;
+//                       fluid_xpass2_persist_kernel: two persistent workgroups per CU once the launch is large
+//   zy_inverse_kernel : grid = nn*3*nx planes (and its persistent form)
 //
 // HBM traffic per call: 6 passes of 4 B/voxel-component (read m, write+read+write+read the
 // spectrum, write out) + the coefficient table, against 14 for rocFFT's 3D plan + operator.

@@ -24,8 +24,8 @@
 // All transforms are decimation-in-frequency forward (natural -> digit-reversed order) and
 // decimation-in-time inverse (digit-reversed -> natural): one radix-3 or radix-5 level for the
 // lengths 3*2^a / 5*2^a (96, 160, 192: the 160^3 volumes of BASELINE configs[4]), then radix-2 levels
-// three at a time in registers; the permuted positions are undone for free when a tile is read from /
-// written to LDS.
+// four at a time in registers (the stage plan below); the digit-reversed order is never undone, in LDS or in
+// memory.
 //
 // Every phase between two workgroup barriers is a function of (phase, thread id) only, so the
 // same code runs on the host with a loop over thread ids (tests/native/fft_emul.hip): the
@@ -71,8 +71,8 @@ constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 
 // A transform length N = R * 2^L2 with R in {1, 3, 5} (64, 96, 128, 160, 192, 256, ...).
 // Forward = decimation in frequency: one radix-R level (R > 1), then the radix-2 levels of the R sub-transforms of
-// 2^L2 points, three at a time in registers.  Frequency k = R*k2 + k1 ends up at position k1*2^L2 + bitrev(k2):
-// the order is never undone in memory, readers and writers of a tile permute for free.  Inverse = the same data
+// 2^L2 points, up to four at a time in registers (stage plan below).  Frequency k = R*k2 + k1 ends up at position
+// k1*2^L2 + bitrev(k2): the order is never undone, in LDS or in memory.  Inverse = the same data
 // flow backwards (decimation in time, conjugated twiddles).
 template <int R_, int L2_>
 struct Sz {
