@@ -39,7 +39,7 @@ __global__ __launch_bounds__(K::THREADS) void zy_fwd(fl::ZYArgs a, int never) {
         float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
 #pragma unroll
         for (int ph = 1; ph < K::NPH; ++ph) {
-            if (MODE == 1 && ph < K::NPH - 1) continue;
+            if ((MODE == 1 || MODE >= 3) && ph < K::NPH - 1) continue;
             if (MODE == 2 && ph == K::NPH - 1 && !never) continue;
             if (MODE == 5 && more && ph < K::NPH - 1) {
                 constexpr int NS = K::NPH - 2;
@@ -128,8 +128,103 @@ __global__ __launch_bounds__(K128::THREADS) void zy128_fwd_plain(fl::ZYArgs a, i
     }
 }
 
+// The persistent x pass of the library (fft3.hip: fluid_xpass2_persist_kernel) at 128 points with parts switched off:
+// mode 0 as shipped, 1 memory only (load, fill, store), 2 LDS only (no global loads after the first, no stores),
+// 3 memory only with the stores going to a second buffer (out of place), 4 memory only with every tile one contiguous
+// 48 KB block (what a tile-major spectrum layout would give).
+// usage: zy_probe <batch> x
+using KX = fl::XPass<fl::Sz<1, 7>, true, 256>;
+template <int MODE>
+__global__ __launch_bounds__(256) void xpass_probe(fl::XArgs a, int never, float2 *second) {
+    using K = KX;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *buf = reinterpret_cast<float2 *>(smem), *tw = buf + 3 * K::NX * K::KCP;
+    const uint32_t T = (uint32_t)a.nn * (uint32_t)a.items_per_n;
+    const uint32_t q0 = (uint32_t)((uint64_t)blockIdx.x * T / gridDim.x), q1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * T / gridDim.x);
+    if (q0 >= q1) return;
+    auto at = [&](uint32_t q) {
+        typename K::Block bb = K::locate(a, q % (uint32_t)a.nn, q / (uint32_t)a.nn);
+        if (MODE == 4) { bb.xs = 16; bb.base = a.main_ + (size_t)q * 3 * K::NX * 16; }
+        return bb;
+    };
+    K::fill_twiddles(threadIdx.x, tw);
+    typename K::Regs r;
+    float4 v[K::KLD];
+    typename K::Block b = at(q0);
+    const float *tb_held = nullptr;
+#pragma unroll
+    for (int k = 0; k < K::KLD; ++k) K::load_one(threadIdx.x, b, v, k);
+    for (uint32_t q = q0; q < q1; ++q) {
+        K::fill(threadIdx.x, v, buf);
+        if (b.tb != tb_held) { K::load_coef(threadIdx.x, r, b); tb_held = b.tb; }
+        __syncthreads();
+        const bool more = q + 1 < q1;
+        const typename K::Block bn = more ? at(q + 1) : b;
+#pragma unroll
+        for (int ph = 1; ph < K::NPH; ++ph) {
+            constexpr int NS = K::NPH - 2;
+            if (ph <= NS && more && (MODE != 2 || never)) {
+#pragma unroll
+                for (int k = (ph - 1) * K::KLD / NS; k < ph * K::KLD / NS; ++k) K::load_one(threadIdx.x, bn, v, k);
+            }
+            if (ph == K::NPH - 1) {
+#pragma unroll
+                for (int k = 0; k < K::KLD; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
+            }
+            if ((MODE == 1 || MODE >= 3) && ph < K::NPH - 1) continue;
+            if (MODE == 2 && ph == K::NPH - 1 && !never) continue;
+            if (MODE == 3 && ph == K::NPH - 1) {
+                typename K::Block bo = b;
+                bo.base = second + (b.base - a.main_);
+                K::phase(ph, threadIdx.x, r, bo, buf, tw, a.scale, false);
+            } else
+                K::phase(ph, threadIdx.x, r, b, buf, tw, a.scale, false);
+            __syncthreads();
+        }
+        b = bn;
+    }
+}
+
+template <typename F> static float time_us(F launch, int iters);
+template <typename F> static float time_us(F launch) { return time_us(launch, 20); }
+static int mainx(int nn) {
+    using K = KX;
+    const int nx = 128, ny = 128, nzh = 64;
+    const size_t nmain = (size_t)nn * 3 * nx * ny * nzh, nnyq = (size_t)nn * 3 * nx * ny;
+    float2 *work; float *tab;
+    CK(hipMalloc(&work, (nmain + nnyq) * 8)); CK(hipMemset(work, 0, (nmain + nnyq) * 8));
+    const size_t ntab = (size_t)nx * ny * (nzh + 1) * 6;
+    CK(hipMalloc(&tab, ntab * 4)); CK(hipMemset(tab, 0, ntab * 4));
+    fl::XArgs a;
+    a.main_ = work; a.nyq = work + nmain; a.tabM = tab; a.tabN = tab + (size_t)nx * ny * nzh * 6;
+    a.ny = ny; a.nzh = nzh; a.nch = nzh / 16; a.items_per_n = ny * a.nch + ny / 16; a.nn = nn; a.ipw = 1; a.scale = 1.f;
+    a.total = (uint32_t)(nn * a.items_per_n); a.rev = 0;
+    const double bytes = 2.0 * (double)(nmain + nnyq) * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(xpass_probe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(xpass_probe<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(xpass_probe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    printf("x pass, 128 points, batch %d: %u (bin tile, batch item) pairs, %d phases, LDS %zu B, %.0f MB of spectrum traffic\n", nn,
+           a.total, K::NPH, (size_t)K::SMEM, bytes / 1e6);
+    float t;
+    t = time_us([&] { hipLaunchKernelGGL(xpass_probe<0>, dim3(512), dim3(256), K::SMEM, 0, a, 0, nullptr); });
+    printf("%-44s %7.1f us  %5.2f TB/s\n", "persistent x pass as shipped", t, bytes / (t * 1e-6) / 1e12);
+    t = time_us([&] { hipLaunchKernelGGL(xpass_probe<1>, dim3(512), dim3(256), K::SMEM, 0, a, 0, nullptr); });
+    printf("%-44s %7.1f us  %5.2f TB/s\n", "memory only (load, fill, store)", t, bytes / (t * 1e-6) / 1e12);
+    t = time_us([&] { hipLaunchKernelGGL(xpass_probe<2>, dim3(512), dim3(256), K::SMEM, 0, a, 0, nullptr); });
+    printf("%-44s %7.1f us  %5.2f TB/s\n", "LDS only (fill, stages, operator)", t, bytes / (t * 1e-6) / 1e12);
+    float2 *second;
+    CK(hipMalloc(&second, (nmain + nnyq) * 8));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(xpass_probe<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(xpass_probe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    t = time_us([&] { hipLaunchKernelGGL(xpass_probe<3>, dim3(512), dim3(256), K::SMEM, 0, a, 0, second); });
+    printf("%-44s %7.1f us  %5.2f TB/s\n", "memory only, out of place", t, bytes / (t * 1e-6) / 1e12);
+    t = time_us([&] { hipLaunchKernelGGL(xpass_probe<4>, dim3(512), dim3(256), K::SMEM, 0, a, 0, nullptr); });
+    printf("%-44s %7.1f us  %5.2f TB/s\n", "memory only, contiguous 48 KB tiles", t, bytes / (t * 1e-6) / 1e12);
+    return 0;
+}
+
 template <typename F>
-static float time_us(F launch, int iters = 20) {
+static float time_us(F launch, int iters) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i) launch();
     CK(hipEventRecord(e0));
@@ -161,6 +256,7 @@ static int main128(int nn) {
 
 int main(int argc, char **argv) {
     const int nn = argc > 1 ? atoi(argv[1]) : 8;
+    if (argc > 2 && argv[2][0] == 'x') return mainx(nn);
     if (argc > 2 && atoi(argv[2]) == 128) return main128(nn);
     const uint32_t planes = (uint32_t)nn * 3 * 160;
     const size_t nreal = (size_t)planes * K::NY * K::NZ, nc = (size_t)planes * K::NY * (K::NZH + 1);
