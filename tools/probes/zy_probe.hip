@@ -39,7 +39,7 @@ __global__ __launch_bounds__(K::THREADS) void zy_fwd(fl::ZYArgs a, int never) {
         float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
 #pragma unroll
         for (int ph = 1; ph < K::NPH; ++ph) {
-            if ((MODE == 1 || MODE >= 3) && ph < K::NPH - 1) continue;
+            if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5) && ph < K::NPH - 1) continue;
             if (MODE == 2 && ph == K::NPH - 1 && !never) continue;
             if (MODE == 5 && more && ph < K::NPH - 1) {
                 constexpr int NS = K::NPH - 2;
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(K128::THREADS) void zy128_fwd_plain(fl::ZYArgs a, i
 // The persistent x pass of the library (fft3.hip: fluid_xpass2_persist_kernel) at 128 points with parts switched off:
 // mode 0 as shipped, 1 memory only (load, fill, store), 2 LDS only (no global loads after the first, no stores),
 // 3 memory only with the stores going to a second buffer (out of place), 4 memory only with every tile one contiguous
-// 48 KB block (what a tile-major spectrum layout would give).
+// 48 KB block (what a tile-major spectrum layout would give); 5 / 6: memory only / everything with the pairs dealt
+// round-robin (workgroup w takes pairs w, w + grid, ...; chunk fastest: neighbouring workgroups read the neighbouring
+// 128-byte pieces of the same rows at the same time) instead of one contiguous run per workgroup.
 // usage: zy_probe <batch> x
 using KX = fl::XPass<fl::Sz<1, 7>, true, 256>;
 template <int MODE>
@@ -140,10 +142,14 @@ __global__ __launch_bounds__(256) void xpass_probe(fl::XArgs a, int never, float
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *buf = reinterpret_cast<float2 *>(smem), *tw = buf + 3 * K::NX * K::KCP;
     const uint32_t T = (uint32_t)a.nn * (uint32_t)a.items_per_n;
-    const uint32_t q0 = (uint32_t)((uint64_t)blockIdx.x * T / gridDim.x), q1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * T / gridDim.x);
+    constexpr bool RR = MODE >= 5;
+    const uint32_t q0 = RR ? 0u : (uint32_t)((uint64_t)blockIdx.x * T / gridDim.x);
+    const uint32_t q1 = RR ? (T - blockIdx.x + gridDim.x - 1) / gridDim.x : (uint32_t)((uint64_t)(blockIdx.x + 1) * T / gridDim.x);
     if (q0 >= q1) return;
     auto at = [&](uint32_t q) {
-        typename K::Block bb = K::locate(a, q % (uint32_t)a.nn, q / (uint32_t)a.nn);
+        const uint32_t pr = blockIdx.x + q * gridDim.x;   // round-robin pair number (RR)
+        typename K::Block bb = RR ? K::locate(a, pr / (uint32_t)a.items_per_n, pr % (uint32_t)a.items_per_n)
+                                  : K::locate(a, q % (uint32_t)a.nn, q / (uint32_t)a.nn);
         if (MODE == 4) { bb.xs = 16; bb.base = a.main_ + (size_t)q * 3 * K::NX * 16; }
         return bb;
     };
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void xpass_probe(fl::XArgs a, int never, float
 #pragma unroll
                 for (int k = 0; k < K::KLD; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));
             }
-            if ((MODE == 1 || MODE >= 3) && ph < K::NPH - 1) continue;
+            if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5) && ph < K::NPH - 1) continue;
             if (MODE == 2 && ph == K::NPH - 1 && !never) continue;
             if (MODE == 3 && ph == K::NPH - 1) {
                 typename K::Block bo = b;
@@ -220,6 +226,12 @@ static int mainx(int nn) {
     printf("%-44s %7.1f us  %5.2f TB/s\n", "memory only, out of place", t, bytes / (t * 1e-6) / 1e12);
     t = time_us([&] { hipLaunchKernelGGL(xpass_probe<4>, dim3(512), dim3(256), K::SMEM, 0, a, 0, nullptr); });
     printf("%-44s %7.1f us  %5.2f TB/s\n", "memory only, contiguous 48 KB tiles", t, bytes / (t * 1e-6) / 1e12);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(xpass_probe<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(xpass_probe<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::SMEM));
+    t = time_us([&] { hipLaunchKernelGGL(xpass_probe<5>, dim3(512), dim3(256), K::SMEM, 0, a, 0, nullptr); });
+    printf("%-44s %7.1f us  %5.2f TB/s\n", "memory only, pairs dealt round-robin", t, bytes / (t * 1e-6) / 1e12);
+    t = time_us([&] { hipLaunchKernelGGL(xpass_probe<6>, dim3(512), dim3(256), K::SMEM, 0, a, 0, nullptr); });
+    printf("%-44s %7.1f us  %5.2f TB/s\n", "everything, pairs dealt round-robin", t, bytes / (t * 1e-6) / 1e12);
     return 0;
 }
 
