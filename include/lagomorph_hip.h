@@ -67,7 +67,12 @@ void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nth
 void lago_set_vector_kernels(int on);
 /* 1 (default): every launch of the large kernels walks its workgroups in the opposite direction of the launch before
  * it, so that a consumer starts on what its producer wrote last -- still in the 256 MB Infinity Cache; 0: always
- * ascending.  Same results (scatter-add outputs differ in their last bits, as between any two runs). */
+ * ascending.  Same results (scatter-add outputs differ in their last bits, as between any two runs).  The direction
+ * is taken from ONE process-wide launch counter (every entry point that builds a launch geometry advances it, small
+ * launches and calls that fail a later argument check included), so "opposite to its producer" holds for the chains
+ * of large kernels the library itself issues back to back, and the last bits of scatter-add outputs (d_I) depend on
+ * how many launches came before -- as they depend on the hardware's atomic ordering anyway; every other output is
+ * bit-identical in both directions. */
 void lago_set_launch_order(int alternate);
 /* 1 (default): the 3D Jacobian / stencil terms of Ad_star and jacobian_times_vectorfield_backward are taken from an
  * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows -- 128^3 and 160^3
@@ -271,6 +276,11 @@ int lago_fluid_metric_f64(double *out, const double *m, double *work, int64_t lu
 /* Drops every cached coefficient table (buffers still read by enqueued kernels are freed after them). */
 void lago_fluid_cache_clear(void);
 int lago_fluid_cache_entries(void);
+/* rocFFT fallback plans (float64, 2D planes beyond the LDS, extents outside 2^a / 3*2^a / 5*2^a): how many are cached
+ * and how many of them are currently verified by the spot check against a direct DFT (csrc/fft.hip: creating a plan
+ * marks every plan unverified again; a check on an all-zero field or during stream capture proves nothing and leaves
+ * the plan unverified).  Telemetry for the tests. */
+int lago_fft_plan_state(int *plans, int *verified);
 
 #ifdef __cplusplus
 }

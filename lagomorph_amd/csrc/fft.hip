@@ -77,8 +77,10 @@ static const size_t kCoefCacheBytes = (size_t)1 << 30;  // at most 1 GiB of tabl
 struct FftPlan {
     int dim, n[3], batch, dbl, device;
     hipfftHandle fwd, inv;
-    int verified;   // the plan's first transforms were spot-checked against a direct DFT (below)
+    int verified;   // the plan's transforms were spot-checked against a direct DFT (below) since the last plan creation
+    unsigned epoch; // value of g_plan_epoch when `verified` was last reset
 };
+static unsigned g_plan_epoch = 0;   // bumped by every plan creation (under g_plan_mu)
 static std::vector<FftPlan> g_plans;
 static std::mutex g_plan_mu;
 
@@ -105,18 +107,36 @@ static int get_plan(FftPlan &out, int dim, const int *n, int batch, int dbl) {
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftPlanMany(R2C)");
     r = hipfftPlanMany(&p.inv, dim, nn, nullptr, 1, 0, nullptr, 1, 0, dbl ? HIPFFT_Z2D : HIPFFT_C2R, batch);
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftPlanMany(C2R)");
+    // the failure this guards against depends on which other plans exist: every cached plan is checked again
+    ++g_plan_epoch;
+    for (FftPlan &q : g_plans) { q.verified = 0; q.epoch = g_plan_epoch; }
+    p.epoch = g_plan_epoch;
     g_plans.push_back(p);
     out = p;
     return LAGO_OK;
 }
 
-// ---- first-use spot check of a rocFFT plan ---------------------------------------------------------------------
+// ---- spot check of a rocFFT plan -------------------------------------------------------------------------------
 // rocFFT (ROCm 7.2) was caught returning a batched 2D real transform 60 % wrong once plans for other shapes existed
 // (tools/probes/rocfft_2d_repro.py reproduces it with torch alone).  A third-party wrong answer must not reach the
-// caller silently: the FIRST forward and inverse execution of every cached plan is compared, for the first and the last
+// caller silently: the first forward and inverse execution of every cached plan is compared, for the first and the last
 // transform of the batch, with a direct DFT at six frequencies / six voxels (double accumulation; a few milliseconds
-// and one stream synchronisation, once per plan).  A mismatch fails the call with a message naming the shape.
+// and one stream synchronisation).  A mismatch fails the call with a message naming the shape.
+//  * The observed failure depends on which OTHER plans exist, so creating a plan marks every cached plan unverified
+//    again (get_plan): each is re-checked on its next use.
+//  * The deviation is judged against a GLOBAL scale, not against the sampled values (a centred object on a zero
+//    background has corner voxels nine orders below its peak; a single sinusoid has empty bins): forward
+//    |dev_k| <= tol (|X_k| + ||x||_2) -- the root-mean-square bin of a transform is ||x||_2 by Parseval and a float
+//    FFT's error per bin is about eps log2(N) of that -- inverse |dev_r| <= tol (|x_r| + sqrt(sum_k w_k |X_k|^2)), the
+//    root-mean-square output voxel.  tol = 1e-3 / 1e-9: three orders above the rounding noise, two to three below
+//    any wrong transform.  A zero scale (m == 0: the first atlas iteration) proves nothing and leaves the plan
+//    unverified.
+//  * While the stream is being captured into a graph the check is skipped (it synchronises) and the plan stays
+//    unverified; the scratch buffer is persistent (no hipMalloc / hipFree per check) and every value the host needs
+//    arrives with ONE asynchronous copy.
 constexpr int kSpot = 6;
+constexpr int kSpotSlots = 2 * kSpot;          // two batch members x kSpot samples
+constexpr int kSpotDoubles = kSpotSlots * 6;   // per slot: want re, want im, got re, got im, sum of squares, index
 
 struct SpotGeom {
     int dim, n[3], nzc;          // extents (2D: n[2] = 1); bins of the last axis in the half spectrum
@@ -124,7 +144,7 @@ struct SpotGeom {
     int member[2];               // the two transforms of the batch that are checked
 };
 
-__device__ __forceinline__ void spot_pick(const SpotGeom &g, int q, int (&k)[3]) {
+__host__ __device__ inline void spot_pick(const SpotGeom &g, int q, int (&k)[3]) {
     // frequencies / voxels: the origin, one step along each axis, two generic ones (the last axis stays inside the half spectrum)
     const int pick[kSpot][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {g.n[0] / 2, g.n[1] / 3, 0}, {3, 5, 2}};
     for (int d = 0; d < 3; ++d) k[d] = pick[q][d] % (g.n[d] > 0 ? g.n[d] : 1);
@@ -134,14 +154,28 @@ __device__ __forceinline__ void spot_pick(const SpotGeom &g, int q, int (&k)[3])
     if (k[last] >= g.nzc) k[last] = g.nzc - 1;
 }
 
-// forward: X[k] = sum_x x[r] exp(-2 pi i k.r / n) of the real input, for (member, q); out[(mi*kSpot+q)*2 + {0,1}]
+__device__ __forceinline__ double spot_block_sum(double v, double *sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// forward, after work = R2C(x): X[k] = sum_r x[r] exp(-2 pi i k.r / n) of the real input for (member, q), the bin rocFFT
+// wrote there, and sum x^2 of the member
 template <typename R>
-__global__ __launch_bounds__(256) void spot_forward_kernel(double *out, const R *x, SpotGeom g) {
+__global__ __launch_bounds__(256) void spot_forward_kernel(double *out, const R *x, const R *work, SpotGeom g) {
+    __shared__ double sh[256];
     const int mi = blockIdx.x / kSpot, q = blockIdx.x % kSpot;
     int k[3];
     spot_pick(g, q, k);
     const R *xm = x + (size_t)g.member[mi] * g.plane;
-    double re = 0, im = 0;
+    double re = 0, im = 0, sq = 0;
     const long long n12 = (long long)g.n[1] * g.n[2];
     for (long long e = threadIdx.x; e < g.plane; e += 256) {
         const long long i0 = e / n12, r = e - i0 * n12, i1 = r / g.n[2], i2 = r - i1 * g.n[2];
@@ -150,21 +184,25 @@ __global__ __launch_bounds__(256) void spot_forward_kernel(double *out, const R 
         const double v = (double)xm[e];
         re += v * cos(ph);
         im += v * sin(ph);
+        sq += v * v;
     }
-    __shared__ double sr[256], si[256];
-    sr[threadIdx.x] = re; si[threadIdx.x] = im;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) { sr[threadIdx.x] += sr[threadIdx.x + st]; si[threadIdx.x] += si[threadIdx.x + st]; }
-        __syncthreads();
+    re = spot_block_sum(re, sh);
+    im = spot_block_sum(im, sh);
+    sq = spot_block_sum(sq, sh);
+    if (threadIdx.x == 0) {
+        const long long idx = g.dim == 3 ? ((long long)k[0] * g.n[1] + k[1]) * g.nzc + k[2] : (long long)k[0] * g.nzc + k[1];
+        const R *got = work + ((size_t)g.member[mi] * g.cplane + idx) * 2;
+        double *o = out + blockIdx.x * 6;
+        o[0] = re; o[1] = im; o[2] = (double)got[0]; o[3] = (double)got[1]; o[4] = sq; o[5] = (double)idx;
     }
-    if (threadIdx.x == 0) { out[blockIdx.x * 2] = sr[0]; out[blockIdx.x * 2 + 1] = si[0]; }
 }
 
-// inverse (unnormalised C2R): x[r] = sum over the half spectrum of w(k_last) Re(X[k] exp(+2 pi i k.r / n)), w = 1 on
-// the two self-conjugate planes of the last axis, 2 elsewhere -- the value a correct C2R returns at voxel r
+// inverse (unnormalised C2R), before out = C2R(X): x[r] = sum over the half spectrum of w(k_last) Re(X[k] exp(+2 pi i k.r / n)),
+// w = 1 on the two self-conjugate planes of the last axis, 2 elsewhere -- the value a correct C2R returns at voxel r --
+// and sum_k w |X_k|^2 (the mean square of the output, Parseval)
 template <typename R>
 __global__ __launch_bounds__(256) void spot_inverse_kernel(double *out, const R *X, SpotGeom g) {
+    __shared__ double sh[256];
     const int mi = blockIdx.x / kSpot, q = blockIdx.x % kSpot;
     int r3[3];
     spot_pick(g, q, r3);
@@ -173,7 +211,7 @@ __global__ __launch_bounds__(256) void spot_inverse_kernel(double *out, const R 
     const R *Xm = X + (size_t)g.member[mi] * g.cplane * 2;
     const int nl = g.n[last];
     const long long c12 = g.dim == 3 ? (long long)g.n[1] * g.nzc : (long long)g.nzc;
-    double acc = 0;
+    double acc = 0, sq = 0;
     for (long long e = threadIdx.x; e < g.cplane; e += 256) {
         int kk[3] = {0, 0, 0};
         if (g.dim == 3) { kk[0] = (int)(e / c12); const long long r = e - kk[0] * c12; kk[1] = (int)(r / g.nzc); kk[2] = (int)(r - (long long)kk[1] * g.nzc); }
@@ -185,20 +223,25 @@ __global__ __launch_bounds__(256) void spot_inverse_kernel(double *out, const R 
         ph *= 2.0 * 3.14159265358979323846;
         const double xr = (double)Xm[2 * e], xi = (double)Xm[2 * e + 1];
         acc += w * (xr * cos(ph) - xi * sin(ph));
+        sq += w * (xr * xr + xi * xi);
     }
-    __shared__ double sa[256];
-    sa[threadIdx.x] = acc;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sa[threadIdx.x] += sa[threadIdx.x + st];
-        __syncthreads();
-    }
+    acc = spot_block_sum(acc, sh);
+    sq = spot_block_sum(sq, sh);
     if (threadIdx.x == 0) {
         long long idx = 0;
         for (int d = 0; d < g.dim; ++d) idx = idx * g.n[d] + r3[d];
-        out[blockIdx.x * 2] = sa[0];
-        out[blockIdx.x * 2 + 1] = (double)idx;   // which voxel (read back by the host to pick the value to compare)
+        double *o = out + blockIdx.x * 6;
+        o[0] = acc; o[1] = 0; o[4] = sq; o[5] = (double)idx;
     }
+}
+// ... and after it: the voxels rocFFT wrote
+template <typename R>
+__global__ void spot_inverse_got_kernel(double *out, const R *x, SpotGeom g) {
+    const int i = threadIdx.x;
+    if (i >= kSpotSlots) return;
+    double *o = out + i * 6;
+    o[2] = (double)x[(size_t)g.member[i / kSpot] * g.plane + (long long)o[5]];
+    o[3] = 0;
 }
 
 static SpotGeom spot_geom(int dim, const int *n, int batch) {
@@ -217,82 +260,102 @@ static SpotGeom spot_geom(int dim, const int *n, int batch) {
 static void mark_verified(const FftPlan &p) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     for (FftPlan &q : g_plans)
-        if (q.fwd == p.fwd) q.verified = 1;
+        if (q.fwd == p.fwd && q.epoch == p.epoch) q.verified = 1;   // (a plan created meanwhile reset it: check again)
 }
 
-// after `work = R2C(m)`: compare.  Returns LAGO_OK or a failure.
-template <typename R>
-static int spot_check_forward(const FftPlan &p, const R *m, const R *work, hipStream_t s) {
-    const SpotGeom g = spot_geom(p.dim, p.n, p.batch);
-    double *d = nullptr;
-    LAGO_HIP_TRY(hipMalloc((void **)&d, 2 * kSpot * 2 * sizeof(double)));
-    hipLaunchKernelGGL((spot_forward_kernel<R>), dim3(2 * kSpot), dim3(256), 0, s, d, m, g);
-    double want[2 * kSpot * 2];
-    hipError_t e = hipMemcpyAsync(want, d, sizeof(want), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
-    if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
-    double scale = 0, worst = 0;
-    R got[2];
-    for (int i = 0; i < 2 * kSpot; ++i) {
-        const int mi = i / kSpot, q = i % kSpot;
-        // the bin's index in the half spectrum (host replica of spot_pick)
-        const int pick[kSpot][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {g.n[0] / 2, g.n[1] / 3, 0}, {3, 5, 2}};
-        int k[3];
-        for (int dd = 0; dd < 3; ++dd) k[dd] = pick[q][dd] % (g.n[dd] > 0 ? g.n[dd] : 1);
-        const int last = g.dim - 1;
-        if (q == 4) k[last] = g.nzc - 1;
-        if (q == 3 && g.dim == 2) { k[1] = 1 % g.nzc; k[2] = 0; }
-        if (k[last] >= g.nzc) k[last] = g.nzc - 1;
-        long long idx = g.dim == 3 ? ((long long)k[0] * g.n[1] + k[1]) * g.nzc + k[2] : (long long)k[0] * g.nzc + k[1];
-        e = hipMemcpy(got, work + ((size_t)g.member[mi] * g.cplane + idx) * 2, 2 * sizeof(R), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
-        const double dr = (double)got[0] - want[2 * i], di = (double)got[1] - want[2 * i + 1];
-        worst = std::max(worst, std::sqrt(dr * dr + di * di));
-        scale = std::max(scale, std::sqrt(want[2 * i] * want[2 * i] + want[2 * i + 1] * want[2 * i + 1]));
+// One check at a time (first uses are rare): the scratch buffer is shared.  Heap-allocated once per device, never freed.
+static std::mutex g_spot_mu;
+static double *spot_scratch(int device) {
+    static double *buf[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    if (!buf[device] && hipMalloc((void **)&buf[device], kSpotDoubles * sizeof(double)) != hipSuccess) buf[device] = nullptr;
+    return buf[device];
+}
+// does this execution take part in the check?  (not while the stream is captured: the check synchronises)
+static bool spot_wanted(const FftPlan &p, hipStream_t s) {
+    if (p.verified) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusNone;
+}
+
+// the judgement shared by both directions: 1 right, 0 nothing to judge by (zero input), -1 wrong
+static int spot_judge(const double *v, bool dbl, double &worst, double &scale) {
+    const double tol = dbl ? 1e-9 : 1e-3;
+    int verdict = 0;
+    worst = scale = 0;
+    for (int i = 0; i < kSpotSlots; ++i) {
+        const double *o = v + i * 6;
+        const double rms = std::sqrt(o[4]);
+        if (!(rms > 0)) continue;   // this member is identically zero: any transform returns zeros
+        const double dr = o[2] - o[0], di = o[3] - o[1];
+        const double dev = std::sqrt(dr * dr + di * di), ref = std::sqrt(o[0] * o[0] + o[1] * o[1]) + rms;
+        if (!(dev <= tol * ref)) {   // (also catches NaN)
+            if (verdict >= 0 || dev / ref > worst / scale) { worst = dev; scale = ref; }
+            verdict = -1;
+        } else if (verdict == 0) {
+            verdict = 1;
+        }
     }
-    const double tol = (sizeof(R) == 4 ? 1e-3 : 1e-9) * std::max(scale, 1e-30);
-    if (worst > tol)
-        return fail_invalid("fluid_metric: rocFFT returned a WRONG forward transform for %dD extents %d x %d x %d, batch %d "
-                            "(spot check against a direct DFT: deviation %.3g of %.3g); see tools/probes/rocfft_2d_repro.py",
-                            p.dim, p.n[0], p.n[1], p.dim == 3 ? p.n[2] : 1, p.batch, worst, scale);
-    return LAGO_OK;
+    return verdict;
 }
 
-// before `out = C2R(work)`: the expected voxel values; after it: compare
+// Scoped first-use check of one fluid_metric call.  forward(): after `work = R2C(m)`; inverse_prepare(): before
+// `out = C2R(work)`; inverse_compare(): after it.  All three are no-ops when the plan is verified or the stream is
+// being captured.  verdicts: both directions right -> the plan is marked verified.
 template <typename R>
-struct SpotInverse {
-    double want[2 * kSpot * 2];
+struct SpotCheck {
+    const FftPlan &p;
+    hipStream_t s;
+    bool on;
+    int fwd_verdict = 0;
     SpotGeom g;
-    int prepare(const FftPlan &p, const R *work, hipStream_t s) {
+    double *d = nullptr;
+    std::unique_lock<std::mutex> lk;
+    SpotCheck(const FftPlan &plan, hipStream_t stream) : p(plan), s(stream), on(spot_wanted(plan, stream)) {
+        if (!on) return;
+        lk = std::unique_lock<std::mutex>(g_spot_mu);
+        d = spot_scratch(p.device);
+        if (!d) { on = false; lk.unlock(); return; }   // no scratch: the plan stays unverified
         g = spot_geom(p.dim, p.n, p.batch);
-        double *d = nullptr;
-        LAGO_HIP_TRY(hipMalloc((void **)&d, sizeof(want)));
-        hipLaunchKernelGGL((spot_inverse_kernel<R>), dim3(2 * kSpot), dim3(256), 0, s, d, work, g);
-        hipError_t e = hipMemcpyAsync(want, d, sizeof(want), hipMemcpyDeviceToHost, s);
+    }
+    int fetch(double (&v)[kSpotDoubles]) {
+        hipError_t e = hipMemcpyAsync(v, d, sizeof(v), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void)hipFree(d);
         if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
         return LAGO_OK;
     }
-    int compare(const FftPlan &p, const R *out, hipStream_t s) {
-        hipError_t e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
-        double scale = 0, worst = 0;
-        for (int i = 0; i < 2 * kSpot; ++i) {
-            R got;
-            const long long idx = (long long)want[2 * i + 1];
-            e = hipMemcpy(&got, out + (size_t)g.member[i / kSpot] * g.plane + idx, sizeof(R), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) return fail_hip(e, "fluid_metric (rocFFT spot check)");
-            worst = std::max(worst, std::fabs((double)got - want[2 * i]));
-            scale = std::max(scale, std::fabs(want[2 * i]));
-        }
-        const double tol = (sizeof(R) == 4 ? 1e-3 : 1e-9) * std::max(scale, 1e-30);
-        if (worst > tol)
-            return fail_invalid("fluid_metric: rocFFT returned a WRONG inverse transform for %dD extents %d x %d x %d, "
-                                "batch %d (spot check against a direct DFT: deviation %.3g of %.3g); see "
-                                "tools/probes/rocfft_2d_repro.py", p.dim, p.n[0], p.n[1], p.dim == 3 ? p.n[2] : 1, p.batch,
-                                worst, scale);
+    int wrong(const char *dir, double worst, double scale) {
+        return fail_invalid("fluid_metric: rocFFT returned a WRONG %s transform for %dD extents %d x %d x %d, batch %d "
+                            "(spot check against a direct DFT: deviation %.3g against a scale of %.3g); see "
+                            "tools/probes/rocfft_2d_repro.py", dir, p.dim, p.n[0], p.n[1], p.dim == 3 ? p.n[2] : 1, p.batch,
+                            worst, scale);
+    }
+    int forward(const R *m, const R *work) {
+        if (!on) return LAGO_OK;
+        hipLaunchKernelGGL((spot_forward_kernel<R>), dim3(kSpotSlots), dim3(256), 0, s, d, m, work, g);
+        double v[kSpotDoubles];
+        int rc = fetch(v);
+        if (rc != LAGO_OK) return rc;
+        double worst, scale;
+        fwd_verdict = spot_judge(v, sizeof(R) == 8, worst, scale);
+        return fwd_verdict < 0 ? wrong("forward", worst, scale) : LAGO_OK;
+    }
+    int inverse_prepare(const R *work) {
+        if (!on) return LAGO_OK;
+        hipLaunchKernelGGL((spot_inverse_kernel<R>), dim3(kSpotSlots), dim3(256), 0, s, d, work, g);
+        return LAGO_OK;
+    }
+    int inverse_compare(const R *out) {
+        if (!on) return LAGO_OK;
+        hipLaunchKernelGGL((spot_inverse_got_kernel<R>), dim3(1), dim3(64), 0, s, d, out, g);
+        double v[kSpotDoubles];
+        int rc = fetch(v);
+        if (rc != LAGO_OK) return rc;
+        double worst, scale;
+        const int verdict = spot_judge(v, sizeof(R) == 8, worst, scale);
+        if (verdict < 0) return wrong("inverse", worst, scale);
+        if (verdict > 0 && fwd_verdict > 0) mark_verified(p);
         return LAGO_OK;
     }
 };
@@ -357,25 +420,17 @@ static int fluid_metric_xpass(float *out, const float *m, float *work, int64_t g
     if (rc != LAGO_OK) return rc;
     hipfftResult r = exec_on(p.fwd, s, [&] { return hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work); });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecR2C(2D)");
-    const bool check = !p.verified;   // first use of this plan: spot-check rocFFT against a direct DFT
-    if (check) {
-        rc = spot_check_forward<float>(p, m, work, s);
-        if (rc != LAGO_OK) return rc;
-    }
+    SpotCheck<float> spot(p, s);   // an unverified plan: spot-check rocFFT against a direct DFT
+    rc = spot.forward(m, work);
+    if (rc != LAGO_OK) return rc;
     rc = fluid_xpass_launch(work, tab->d, inverse, nn, nx, ny, nzc, 1.0 / ((double)nx * (double)ny * (double)nz), s);
     if (rc != LAGO_OK) return rc;
-    SpotInverse<float> spot;
-    if (check) {
-        rc = spot.prepare(p, work, s);
-        if (rc != LAGO_OK) return rc;
-    }
+    rc = spot.inverse_prepare(work);
+    if (rc != LAGO_OK) return rc;
     r = exec_on(p.inv, s, [&] { return hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out); });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExecC2R(2D)");
-    if (check) {
-        rc = spot.compare(p, out, s);
-        if (rc != LAGO_OK) return rc;
-        mark_verified(p);
-    }
+    rc = spot.inverse_compare(out);
+    if (rc != LAGO_OK) return rc;
     return finish_launch(s, "fluid_metric");
 }
 
@@ -425,32 +480,24 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
                               : hipfftExecD2Z(p.fwd, (hipfftDoubleReal *)m, (hipfftDoubleComplex *)work);
     });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExec(forward)");
-    const bool check = !p.verified;   // first use of this plan: spot-check rocFFT against a direct DFT
-    if (check) {
-        rc = spot_check_forward<R>(p, m, work, s);
-        if (rc != LAGO_OK) return rc;
-    }
+    SpotCheck<R> spot(p, s);   // an unverified plan: spot-check rocFFT against a direct DFT
+    rc = spot.forward(m, work);
+    if (rc != LAGO_OK) return rc;
     // half-spectrum extents: the last axis keeps n/2 + 1 bins
     const int64_t cx = nx, cy = dim == 2 ? ny / 2 + 1 : ny, cz = dim == 3 ? nz / 2 + 1 : 1;
     const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
     rc = fluid_operator_impl<R>(work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, cx, cy,
                                 cz, stream, scale);
     if (rc != LAGO_OK) return rc;
-    SpotInverse<R> spot;
-    if (check) {
-        rc = spot.prepare(p, work, s);
-        if (rc != LAGO_OK) return rc;
-    }
+    rc = spot.inverse_prepare(work);
+    if (rc != LAGO_OK) return rc;
     r = exec_on(p.inv, s, [&] {
         return sizeof(R) == 4 ? hipfftExecC2R(p.inv, (hipfftComplex *)work, (hipfftReal *)out)
                               : hipfftExecZ2D(p.inv, (hipfftDoubleComplex *)work, (hipfftDoubleReal *)out);
     });
     if (r != HIPFFT_SUCCESS) return fail_fft(r, "hipfftExec(inverse)");
-    if (check) {
-        rc = spot.compare(p, out, s);
-        if (rc != LAGO_OK) return rc;
-        mark_verified(p);
-    }
+    rc = spot.inverse_compare(out);
+    if (rc != LAGO_OK) return rc;
     return finish_launch(s, "fluid_metric");
 }
 
@@ -466,6 +513,14 @@ void lago_fluid_cache_clear(void) {
 int lago_fluid_cache_entries(void) {
     std::lock_guard<std::mutex> lk(lago::g_plan_mu);
     return (int)lago::g_tabs.size();
+}
+int lago_fft_plan_state(int *plans, int *verified) {
+    std::lock_guard<std::mutex> lk(lago::g_plan_mu);
+    int nv = 0;
+    for (const lago::FftPlan &p : lago::g_plans) nv += p.verified ? 1 : 0;
+    if (plans) *plans = (int)lago::g_plans.size();
+    if (verified) *verified = nv;
+    return 0;
 }
 #define LAGO_DEFINE(REAL, SUF)                                                                                     \
     int lago_fluid_metric##SUF(REAL *out, const REAL *m, REAL *work, int64_t lut_generation, int inverse,         \

@@ -173,7 +173,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         constexpr bool STRAY = decltype(stray)::value;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (c > 0) __syncthreads();  // channel c's window has landed
+            if (c > 0) {
+                // channel c's window must have landed before anyone reads it: the wait for this wave's own LDS-direct
+                // loads is spelled out (no language rule makes hipcc put it in front of the barrier; it does today)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             const BufRsrc ro = make_rsrc(on + (size_t)c * nv, plane);
 #pragma unroll
             for (int e = 0; e < U; ++e) {
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
     };
-    // channel 0's window has landed behind this barrier (the compiler waits for the LDS-direct loads first)
+    // channel 0's window has landed behind this barrier (each wave waits for its own LDS-direct loads first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (__syncthreads_or(outm != 0))
         channels(std::true_type{});
     else

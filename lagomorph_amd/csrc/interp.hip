@@ -191,7 +191,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
     };
-    // channel 0's window has landed behind this barrier (the compiler waits for the LDS-direct loads first)
+    // channel 0's window has landed behind this barrier (each wave waits for its own LDS-direct loads first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (__syncthreads_or(outm != 0))
         channels(std::true_type{});
     else

@@ -216,7 +216,8 @@ def set_gather_window(on):
 
 
 if os.environ.get("LAGO_GATHER_WINDOW") is not None:  # profiling convenience: A/B under rocprofv3 without code changes
-    set_gather_window(int(os.environ["LAGO_GATHER_WINDOW"]))
+    # (parsed defensively: an empty or odd value of a profiling variable must not break `import lagomorph_amd`)
+    set_gather_window(os.environ["LAGO_GATHER_WINDOW"].strip().lower() not in ("", "0", "off", "false", "no"))
 
 
 def set_vector_kernels(on):
@@ -406,6 +407,13 @@ def fluid_cache_clear():
 
 def fluid_cache_entries():
     return int(_lib.lago_fluid_cache_entries())
+
+
+def fft_plan_state():
+    """(cached rocFFT fallback plans, how many of them are currently verified by the spot check)."""
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.lago_fft_plan_state(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma, lut_generation=0):

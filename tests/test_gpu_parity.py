@@ -646,6 +646,82 @@ def test_rocfft_fallback_is_right_or_loud(ext):
         ext.set_fluid_mode(2)
 
 
+def test_rocfft_guard_judges_against_a_global_scale(ext):
+    """the spot check used to scale its tolerance by the sampled values only, so a centred object on
+    a zero background (corner voxels nine orders below the peak) or a single sinusoid (empty bins) raised a false
+    'WRONG transform'.  The deviation is now judged against the root-mean-square bin / voxel of the whole transform
+    (csrc/fft.hip): these inputs pass, and the results are the oracle's."""
+    import lagomorph_amd as lm
+
+    ext.set_fluid_mode(0)
+    try:
+        met = lm.FluidMetric([0.1, 0.0, 0.01])
+        for sp in ((256, 256), (120, 120, 120)):
+            ax = [np.arange(n, dtype=np.float64) - n / 2 for n in sp]
+            r2 = sum(np.square(a).reshape([-1 if i == d else 1 for i in range(len(sp))]) for d, a in enumerate(ax))
+            blob = np.exp(-r2 / (2 * 3.0 ** 2))
+            blob[blob < 1e-6] = 0.0     # compact support: exact zeros towards the corners
+            m = np.zeros((2, len(sp)) + sp, np.float32)
+            m[0, 0] = blob
+            m[1, -1] = -2 * blob
+            for inverse, f in ((True, met.sharp), (False, met.flat)):
+                got = f(dev(m))     # must not raise
+                assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.0, 0.01], inverse), torch.float32, f"blob {sp}")
+        # a single sinusoid per component: one occupied bin pair, every other bin empty
+        sp = (96, 40)
+        i, j = np.meshgrid(np.arange(sp[0]), np.arange(sp[1]), indexing="ij")
+        m = np.stack([np.sin(2 * np.pi * (3 * i / sp[0] + 5 * j / sp[1])), np.cos(2 * np.pi * 7 * i / sp[0])])[None].astype(np.float32)
+        m = np.repeat(m, 3, 0)
+        for inverse, f in ((True, met.sharp), (False, met.flat)):
+            assert_close(f(dev(m)), orc.fluid_metric_apply(m, [0.1, 0.0, 0.01], inverse), torch.float32, "sinusoid")
+    finally:
+        ext.set_fluid_mode(2)
+
+
+def test_rocfft_guard_bookkeeping(ext):
+    """A check on an all-zero field proves nothing (the first atlas iteration: m == 0) and must leave the plan
+    unverified; a later non-zero call verifies it; creating ANY new plan marks every cached plan unverified again (the
+    failure the guard exists for depends on which other plans exist); while a stream is being captured the check --
+    which synchronises -- is skipped and the capture stays valid."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(11)
+    ext.set_fluid_mode(0)
+    try:
+        met = lm.FluidMetric([0.1, 0.05, 0.01])
+        sp = (44, 52)   # not a fused-2D shape: rocFFT
+        z = torch.zeros((7, 2) + sp, device="cuda")
+        n0, _ = ext.fft_plan_state()
+        assert float(met.sharp(z).abs().max()) == 0.0
+        n1, v1 = ext.fft_plan_state()
+        assert n1 == n0 + 1 and v1 == 0, "a new plan, and nothing verified by a zero field (the new plan reset the others)"
+        # capture with the still unverified plan: no synchronisation, no failure, right answer on replay
+        m = rnd(rng, (7, 2) + sp, torch.float32)
+        md = dev(m)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="relaxed"):
+                out = met.sharp(md)
+        torch.cuda.current_stream().wait_stream(side)
+        assert ext.fft_plan_state() == (n1, 0), "capturing must not verify (or check) anything"
+        graph.replay()
+        torch.cuda.synchronize()
+        assert_close(out, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "captured rocFFT fallback")
+        # eager, non-zero: verified now
+        assert_close(met.sharp(md), orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "eager rocFFT fallback")
+        assert ext.fft_plan_state() == (n1, 1)
+        # a plan for another batch size: everything is to be checked again
+        m2 = rnd(rng, (3, 2) + sp, torch.float32)
+        assert_close(met.flat(dev(m2)), orc.fluid_metric_apply(m2, [0.1, 0.05, 0.01], False), torch.float32, "second plan")
+        assert ext.fft_plan_state() == (n1 + 1, 1), "the new plan verified, the older one waiting for its next use"
+        met.sharp(md)
+        assert ext.fft_plan_state() == (n1 + 1, 2)
+    finally:
+        ext.set_fluid_mode(2)
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5])
 def test_persistent_zy_passes_any_plane_count(ext, batch):
     """Planes above 80 KB of LDS run on a grid of at most 256 persistent workgroups that prefetch their next plane:
