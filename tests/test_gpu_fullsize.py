@@ -264,3 +264,112 @@ def test_ad_star_compile_time_geometry_same_bits(lm, S):
             assert torch.equal(out, want) and torch.equal(kept, ext.interp_forward(m, phi, 1.0)), mode
     finally:
         ext.set_stencil_tile(1)
+
+
+# ---- configs[4] volume (160^3): the production geometries against the ORACLE, not only against each other ----------
+# (the 8 x 6 x 80 splat tile, ad_star3_tile_kernel<..., 160>, the 160-row compose window and the
+# persistent 160^2 zy passes were tied to the oracle only through self-equivalence chains and a float32-vs-float64
+# comparison at 1.5e-3.)
+
+def _oracle_threads():
+    import os
+
+    return min(os.cpu_count() or 1, 64)
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+@pytest.mark.parametrize("dt", [1.0, -0.2])
+def test_config4_splat_production_geometry_160_vs_oracle(lm, nc, dt):
+    """The shipped splat kernels in their 160^3 production geometry (z rows split into two 80-voxel parts, 112-cell
+    windows; one channel: splat_shear_kernel, three: the geometry-once / window forms) against the CPU oracle on one
+    item of a two-item batch: d_u bit for bit, d_I within 1e-5 x max, unit and non-unit step, with and without d_u."""
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device="cuda").manual_seed(160 + nc)
+    N, S = 2, 160
+    I = smooth((N, nc, S, S, S), 2.0, g)
+    I = I / I.std()
+    u = smooth((N, 3, S, S, S), 8.0, g)
+    u = u * (4.0 / u.abs().max())
+    go = torch.randn((N, nc, S, S, S), device="cuda", generator=g)
+    before = ext.path_launches()
+    dI, du = ext.interp_backward(go, I, u, dt, True, True)
+    after = ext.path_launches()
+    assert sum(after[k] - before[k] for k in ("splat_shear", "splat_shear_mc")) == 1, "not a sheared-window kernel"
+    pick = [1]
+    orc.set_threads(_oracle_threads())
+    try:
+        oI, ou = orc.interp_backward(go[pick].cpu().numpy(), I[pick].cpu().numpy(), u[pick].cpu().numpy(), dt, True, True)
+    finally:
+        orc.set_threads(1)
+    assert np.array_equal(du[pick].cpu().numpy(), ou), "d_u of the production splat kernel at 160^3 != oracle"
+    err = np.abs(dI[pick].cpu().numpy().astype(np.float64) - oI).max()
+    assert err <= 1e-5 * np.abs(oI).max(), (err, np.abs(oI).max())
+    dI2, _ = ext.interp_backward(go, I, u, dt, True, False)
+    err = np.abs(dI2[pick].cpu().numpy().astype(np.float64) - oI).max()
+    assert err <= 1e-5 * np.abs(oI).max(), (err, np.abs(oI).max())
+
+
+def test_config4_ad_star_compose_interp_160_vs_oracle(lm):
+    """ad_star3_tile_kernel<..., 160> (compile-time geometry), the LDS-window compose and the window interp_forward of
+    three channels at 160^3, one item each against the oracle, bit for bit."""
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device="cuda").manual_seed(1604)
+    sh = (2, 3, 160, 160, 160)
+    phi = smooth(sh, 6.0, g)
+    phi = phi * (4.0 / phi.abs().max())
+    m = torch.randn(sh, device="cuda", generator=g)
+    before = ext.path_launches()
+    ad = ext.Ad_star(phi, m)
+    comp = ext.compose(phi, m, -0.1, 1.0)
+    itp = ext.interp_forward(m, phi, 0.7)
+    after = ext.path_launches()
+    assert after["stencil_tile"] == before["stencil_tile"] + 1 and after["gather_window"] == before["gather_window"] + 2
+    p0, m0 = phi[1:].cpu().numpy(), m[1:].cpu().numpy()
+    orc.set_threads(_oracle_threads())
+    try:
+        want_ad = orc.jacobian_times_vectorfield_forward(p0, orc.interp_forward(m0, p0, 1.0), True, False)
+        want_comp = np.float32(-0.1) * p0 + np.float32(1.0) * orc.interp_forward(m0, p0, -0.1)
+        want_itp = orc.interp_forward(m0, p0, 0.7)
+    finally:
+        orc.set_threads(1)
+    assert np.array_equal(ad[1:].cpu().numpy(), want_ad), "Ad_star at 160^3 != oracle"
+    assert np.array_equal(comp[1:].cpu().numpy(), want_comp), "compose at 160^3 != oracle"
+    assert np.array_equal(itp[1:].cpu().numpy(), want_itp), "interp_forward (3 channels) at 160^3 != oracle"
+
+
+def test_config4_lddmm_step_160_hip_vs_oracle_backend(lm):
+    """One lddmm_step item at 160^3 (configs[4]) through the HIP kernels against the same step on the oracle backend
+    (the reference's unfused call sequence on the CPU), float32, at north_star's 1e-5 x max: loss, regulariser, updated
+    momenta and atlas gradient -- every production geometry of the step (persistent 160^2 zy passes, radix-10 x pass,
+    8 x 6 x 80 splat tiles, 160-row Ad_star / compose / jtv kernels, the fused backward forms) in one comparison."""
+    from test_gpu_lddmm_step import oracle_backend
+
+    S = 160
+    g = torch.Generator(device="cuda").manual_seed(1605)
+    base = smooth((1, 1, S, S, S), 3.0, g)
+    base = base / base.std()
+    imgs = (base + 0.2 * smooth((1, 1, S, S, S), 2.0, g)).contiguous()
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    m = smooth((1, 3, S, S, S), 4.0, g)
+    m = (m * (2.0 / met.sharp(m).abs().max())).contiguous()
+    kw = dict(integration_steps=3, reg_weight=1e-2, learning_rate_pose=1e-3)
+    Ig = base.clone().requires_grad_(True)
+    mg, lg, rg = lm.lddmm_step(Ig, m.clone(), imgs, met, 1, **kw)
+    nthr = torch.get_num_threads()
+    orc.set_threads(_oracle_threads())
+    torch.set_num_threads(_oracle_threads())
+    try:
+        with oracle_backend() as lmo:
+            Ic = base.cpu().clone().requires_grad_(True)
+            mc, lc, rc = lmo.lddmm_step(Ic, m.cpu().clone(), imgs.cpu(), lmo.FluidMetric([0.1, 0.0, 0.01]), 1, **kw)
+    finally:
+        orc.set_threads(1)
+        torch.set_num_threads(nthr)
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach().double()).abs().max() / b.detach().double().abs().max())
+
+    errs = {"loss": rel(lg, lc), "reg": rel(rg, rc), "m": rel(mg, mc), "I.grad": rel(Ig.grad, Ic.grad)}
+    print(f"lddmm_step at 160^3, HIP vs oracle backend: {errs}")
+    assert all(e <= 1e-5 for e in errs.values()), errs
+    assert float((mg - m).abs().max()) > 0
