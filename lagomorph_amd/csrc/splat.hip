@@ -400,6 +400,9 @@ struct ShearGeom {
     uint32_t ntx, nty, ntz, tiles_per_item, total, tile_vox, win_cells;
     int rev;               // launch direction (common.hpp)
     FastDiv d_tiles, d_tyz, d_tz, d_TyTz, d_Tz, d_wy;
+    // image window of splat_shear_iw_kernel: the same cells as float32, in 16-byte chunks of four z cells
+    uint32_t iw_chunks, iw_bytes;   // chunks; bytes reserved (whole 1 KB wave-instructions)
+    FastDiv d_wzc;                  // chunks per window row (WZ / 4)
 };
 
 template <bool UNIT>
@@ -909,6 +912,326 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sheared-window splat whose d_u gathers go through an LDS window of I (round 4).
+//
+// The kernels above take the eight corners of the d_u term (include/interp.h:207-327) with four pair gathers per
+// voxel-channel through the vector L1 -- 70 of the 190 us of the C = 1 kernel at 8 x 128^3, and DEPENDENT round trips
+// inside a barrier-phased workgroup: u, grad_out -> position -> gathers -> d_u, pass after pass.  Here the footprint
+// cells of the tile exist twice in LDS: the float64 accumulation window (as above) and, behind it, the SAME cells of
+// I as float32 (12 instead of 8 bytes per cell), filled with LDS-direct `buffer_load_dwordx4 ... lds` in coalesced
+// 16-byte chunks -- each 16-cell z segment from its own sheared (x, y) origin, rows clamped to the grid exactly as
+// the reference clamps its corner indices.  One LDS address pair per voxel serves both windows: the corners for the
+// gradient are eight ds_read_b32 at (A0, A1)/2 + the row strides, the contributions eight ds_add_f64 at A0, A1 + ....
+// Everything a tile needs from global memory is requested up front -- u, grad_out and the d_u start values of all its
+// voxels (registers), then the image window -- so a tile costs ONE exposed memory round trip instead of two per pass;
+// the accumulation window is zeroed underneath it.  Per channel: [wait, barrier] corners + adds [barrier] next
+// channel's image window requested, flush.  Tiles are at most VPL x 1024 voxels (geometry, fractions and d_u sums in
+// registers over the channel loop, as splat_shear_mc_kernel).  Samples whose footprint leaves the window (well
+// under 1 % of a smooth field) recompute their position and take the reference's clamped global atomics and
+// Lerp3's pair gathers.  Arithmetic per voxel and channel is that of splat_shear_kernel: d_u bit-identical.
+template <int NT, bool UNIT, bool BC, int VPL, int WPE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(WPE, WPE))) void splat_shear_iw_kernel(
+    float *__restrict__ d_I, float *__restrict__ d_u, const float *__restrict__ go, const float *__restrict__ I,
+    const float *__restrict__ u, double dt, int nc, ShearGeom sg, int umode, float addgo) {
+    extern __shared__ __align__(16) unsigned char lago_smem[];
+    double *win = reinterpret_cast<double *>(lago_smem);
+    const uint32_t iwB = sg.win_cells * 8u;                                   // byte offset of the image window
+    const int nx = sg.nx, ny = sg.ny, nz = sg.nz;
+    const uint32_t nv = (uint32_t)nx * ny * nz;
+    const uint32_t planeB = nv * 4u;
+    constexpr uint32_t NOWIN = 0xffffffffu, DEAD = 0xffffffffu;
+    constexpr int RCH = 2;   // image-window chunks per thread (host: iw_chunks <= RCH * NT)
+
+    // workgroup -> (batch item, tile)
+    const uint32_t L = block_order(blockIdx.x, sg.total, sg.rev);
+    const uint32_t n = sg.d_tiles.div(L);
+    uint32_t r = L - n * sg.tiles_per_item;
+    const uint32_t bx = sg.d_tyz.div(r);
+    r -= bx * (sg.nty * sg.ntz);
+    const uint32_t by = sg.d_tz.div(r);
+    const uint32_t bz = r - by * sg.ntz;
+    const int x0 = bx * sg.TX, y0 = by * sg.TY, z0 = bz * sg.TZ;
+    const int ex = min(sg.TX, nx - x0), ey = min(sg.TY, ny - y0), ez = min(sg.TZ, nz - z0);
+
+    const float *un = u + (size_t)n * 3 * nv;
+    const float *In = BC ? I : I + (size_t)n * nc * nv;
+    float *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
+    const float *gon = go + (size_t)n * nc * nv;
+    float *dun = d_u + (size_t)n * 3 * nv;
+
+    // ---- window placement first: the two probe loads of a z segment's origin are the OLDEST loads of the wave, so the
+    // wait in front of barrier 1 does not cover the voxel operands requested next (loads return in order)
+    const int WX = sg.WX, WY = sg.WY, WZ = sg.WZ;
+    const int wez = min(WZ, nz);
+    const int cxs = x0 + ex / 2, cys = y0 + ey / 2;
+    int wz0 = 0;
+    if (wez < nz) {   // (a window as long as the z rows starts at 0 whatever the displacement)
+        const float fdt = (float)dt;
+        const size_t sc = ((size_t)cxs * ny + cys) * nz + (z0 + ez / 2);
+        const int bzo = z0 + (int)floorf(fdt * un[sc + 2 * (size_t)nv]);   // (wave-uniform address: a scalar load)
+        wz0 = max(0, min((bzo - sg.MZ) & ~15, nz - wez));
+    }
+    // (x, y) origin per 16-cell z segment: lane s < nseg of EVERY wave probes the displacement of the tile's centre column
+    // at segment s and keeps the origin in a register; a look-up is one ds_bpermute (the LDS crossbar, not LDS memory:
+    // a table in LDS would be read behind the LDS-direct loads below, and hipcc makes any LDS read wait for them)
+    float pox, poy;
+    {
+        const int lane = (int)(threadIdx.x & 63u);
+        const int zc = min(wz0 + lane * 16 + 8, nz - 1);
+        const uint32_t off = lane < sg.nseg ? (((uint32_t)cxs * ny + cys) * nz + zc) * 4u : DEAD;
+        pox = buf_load1<float>(make_rsrc(un, planeB), off);
+        poy = buf_load1<float>(make_rsrc(un + nv, planeB), off);
+    }
+    // ---- every voxel operand of the tile, requested at once (out-of-range offsets -- DEAD -- read 0)
+    uint32_t SV[VPL];
+    float ux[VPL], uy[VPL], uz[VPL], pgv[VPL], rux[VPL], ruy[VPL], ruz[VPL];
+    {
+        const BufRsrc rux_ = make_rsrc(un, planeB), ruy_ = make_rsrc(un + nv, planeB), ruz_ = make_rsrc(un + 2 * (size_t)nv, planeB);
+        const BufRsrc rg = make_rsrc(gon, planeB);
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            const uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+            const uint32_t a = sg.d_TyTz.div(tt);
+            const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
+            const uint32_t b = sg.d_Tz.div(rr);
+            const uint32_t kk = rr - b * (uint32_t)sg.TZ;
+            const bool live = tt < sg.tile_vox && (int)a < ex && (int)b < ey && (int)kk < ez;
+            SV[it] = live ? (((uint32_t)(x0 + a) * ny + (y0 + b)) * nz + (z0 + kk)) * 4u : DEAD;   // byte offset in a plane
+            ux[it] = buf_load1<float>(rux_, SV[it]);
+            uy[it] = buf_load1<float>(ruy_, SV[it]);
+            uz[it] = buf_load1<float>(ruz_, SV[it]);
+            pgv[it] = buf_load1<float>(rg, SV[it]);
+        }
+    }
+    {   // zero the accumulation window under the latency of the loads above (16-byte stores; win_cells is even)
+        double2 *w2 = reinterpret_cast<double2 *>(win);
+        for (uint32_t f = threadIdx.x; f < sg.win_cells / 2; f += NT) w2[f] = make_double2(0.0, 0.0);
+    }
+    int orgp;   // this lane's segment origin, packed (x + 1) << 16 | (y + 1) (host: nx, ny < 32768)
+    {
+        const float fdt = (float)dt;
+        const int ox = max(-1, min(x0 + (int)floorf(fdt * pox) - sg.MX, nx + 1 - WX));
+        const int oy = max(-1, min(y0 + (int)floorf(fdt * poy) - sg.MY, ny + 1 - WY));
+        orgp = ((ox + 1) << 16) | (oy + 1);
+    }
+    auto org_of = [&](uint32_t seg) {   // seg < nseg <= 64
+        const int p = __builtin_amdgcn_ds_bpermute((int)(seg << 2), orgp);
+        int2 o;
+        o.x = (p >> 16) - 1;
+        o.y = (p & 0xffff) - 1;
+        return o;
+    };
+    const uint32_t sxB = (uint32_t)(WY * WZ) * 8u, syB = (uint32_t)WZ * 8u;            // window strides in bytes
+    const uint32_t gxB = (uint32_t)ny * nz * 4u, gyB = (uint32_t)nz * 4u;              // grid strides in bytes
+    const uint32_t wxu1 = (uint32_t)(WX - 1), wyu1 = (uint32_t)(WY - 1), wezu = (uint32_t)wez;
+
+    // ---- image window: chunk c of the window (four z cells; row-major [lx][ly][z/4]) comes from the clamped grid row of
+    // its segment's origin; recomputed per channel (two registers kept over the channel loop cost a spill)
+    auto request_image = [&](int c) {
+        const BufRsrc rI = make_rsrc(In + (size_t)c * nv, planeB);
+#pragma unroll
+        for (int q = 0; q < RCH; ++q) {
+            if ((uint32_t)(q * NT) + (threadIdx.x & ~63u) >= sg.iw_chunks) break;   // wave-uniform
+            uint32_t ch = (uint32_t)(q * NT) + threadIdx.x;
+            asm volatile("" : "+v"(ch));   // (per channel: nothing of this is to be kept in registers over the loop)
+            const uint32_t row = sg.d_wzc.div(ch), cz = ch - row * (uint32_t)(WZ >> 2);
+            const uint32_t lx = sg.d_wy.div(row), ly = row - lx * (uint32_t)WY;
+            // (the look-up outside any divergent branch: ds_bpermute reads 0 from a lane that is switched off)
+            const int2 o = org_of(min(cz >> 2, (uint32_t)sg.nseg - 1u));
+            uint32_t src = DEAD;
+            if (ch < sg.iw_chunks && cz * 4u < wezu)
+                src = __umul24((uint32_t)clamp1(o.x + (int)lx, nx), gxB) + __umul24((uint32_t)clamp1(o.y + (int)ly, ny), gyB) +
+                      ((uint32_t)wz0 + cz * 4u) * 4u;
+            // the wave's LDS destination (M0) from a scalar made here: hoisted out of the channel loop it sits in a VGPR
+            // for the whole loop (a spill at this kernel's 64)
+            uint32_t wv = threadIdx.x >> 6;
+            asm volatile("" : "+v"(wv));
+            const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv) * 64u;
+            unsigned char *dst = lago_smem + iwB + ((size_t)(q * NT) + wbase) * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rI, (__attribute__((address_space(3))) void *)dst, 16, src, 0, 0, 0);
+        }
+    };
+    request_image(0);
+    // how d_u starts: zero (the reference), the caller's d_u, or addgo * grad_out[component] -- ONE unconditional set of
+    // loads (a branch around them would be joined with a wait for everything in flight): the planes are chosen by
+    // wave-uniform selects, umode 0 reads nothing (offset beyond the plane: 0), 1 * x and 1 * 0 are exact
+    {
+        const float *sb = umode == 1 ? dun : gon;
+        const float sm = umode == 2 ? addgo : 1.f;
+        const BufRsrc r0 = make_rsrc(sb, planeB), r1 = make_rsrc(sb + nv, planeB), r2 = make_rsrc(sb + 2 * (size_t)nv, planeB);
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            const uint32_t off = umode ? SV[it] : DEAD;
+            rux[it] = sm * buf_load1<float>(r0, off);
+            ruy[it] = sm * buf_load1<float>(r1, off);
+            ruz[it] = sm * buf_load1<float>(r2, off);
+        }
+    }
+
+    // ---- per-voxel geometry, once (branch-free: dead voxels -- their u reads 0 -- compute along and end as NOWIN; the
+    // origin look-ups need every lane of the wave switched on)
+    uint32_t A0[VPL], A1[VPL];
+    float FT[VPL], FU[VPL], FV[VPL];
+#pragma unroll
+    for (int it = 0; it < VPL; ++it) {
+        const uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+        const uint32_t a = sg.d_TyTz.div(tt);
+        const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
+        const uint32_t b = sg.d_Tz.div(rr);
+        const uint32_t kk = rr - b * (uint32_t)sg.TZ;
+        const float hx = shear_pos<UNIT>(x0 + (int)a, dt, ux[it]);
+        const float hy = shear_pos<UNIT>(y0 + (int)b, dt, uy[it]);
+        const float hz = shear_pos<UNIT>(z0 + (int)kk, dt, uz[it]);
+        const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+        FT[it] = hx - (float)fx;
+        FU[it] = hy - (float)fy;
+        FV[it] = hz - (float)fz;
+        // the two z cells, clamped as the reference clamps them, and the window segment each falls in
+        const int cz0 = clamp1(fz, nz), cz1 = clamp1(fz + 1, nz);
+        const uint32_t lz0 = (uint32_t)(cz0 - wz0), lz1 = (uint32_t)(cz1 - wz0);
+        const uint32_t smax = (uint32_t)sg.nseg - 1u;
+        const int2 o0 = org_of(min(lz0 >> 4, smax)), o1 = org_of(min(lz1 >> 4, smax));
+        const uint32_t lx0 = (uint32_t)(fx - o0.x), ly0 = (uint32_t)(fy - o0.y);
+        const uint32_t lx1 = (uint32_t)(fx - o1.x), ly1 = (uint32_t)(fy - o1.y);
+        const bool inwin = SV[it] != DEAD && lz0 < wezu && lz1 < wezu && lx0 < wxu1 && ly0 < wyu1 && lx1 < wxu1 && ly1 < wyu1;
+        A0[it] = inwin ? __umul24(lx0, sxB) + __umul24(ly0, syB) + lz0 * 8u : NOWIN;
+        A1[it] = inwin ? __umul24(lx1, sxB) + __umul24(ly1, syB) + lz1 * 8u : NOWIN;
+    }
+
+    for (int c = 0; c < nc; ++c) {
+        const float *Ic = In + (size_t)c * nv;
+        const BufRsrc rdI = make_rsrc(dIn + (size_t)c * nv, planeB);
+        float gvs[VPL];
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) gvs[it] = pgv[it];
+        // channel c's image window has landed (every wave waits for its own LDS-direct loads, then the barrier); the
+        // accumulation window is zero (prologue / the previous flush)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 1 < nc) {   // the next channel's grad_out values travel under this channel's work
+            const BufRsrc rg = make_rsrc(gon + (size_t)(c + 1) * nv, planeB);
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) pgv[it] = buf_load1<float>(rg, SV[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < VPL; ++it) {
+            if (VPL > 1 && it) __builtin_amdgcn_sched_barrier(0);  // one pass after the other (register pressure)
+            // the kept geometry is made opaque once per channel: otherwise everything derived from it is hoisted out
+            // of the channel loop into registers (splat_shear_mc_kernel)
+            asm volatile("" : "+v"(A0[it]), "+v"(A1[it]), "+v"(FT[it]), "+v"(FU[it]), "+v"(FV[it]), "+v"(SV[it]));
+            const uint32_t sv = SV[it];
+            const float gv = gvs[it];
+            if (sv == DEAD) continue;
+            const float t = FT[it], uu = FU[it], v = FV[it];
+            const float omt = 1.f - t, omu = 1.f - uu, omv = 1.f - v;
+            // sequentially flipped weights (include/interp.h:431-453): x outer, y, z inner
+            float wq[8];
+            {
+                float ddx = omt, ddy = omu, ddz = omv;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    wq[q] = (ddx * ddy * ddz) * gv;
+                    ddz = 1.f - ddz;
+                    if (q & 1) ddy = 1.f - ddy;
+                    if ((q & 3) == 3) ddx = 1.f - ddx;
+                }
+            }
+            const uint32_t a0 = A0[it], a1 = A1[it];
+            float gx, gy, gz;
+            if (a0 != NOWIN) {
+                // corners in Lerp3's order: rows (fx,fy) (fx+1,fy) (fx+1,fy+1) (fx,fy+1) at the floor cell, then at the ceil cell
+                const unsigned char *i0 = lago_smem + iwB + (a0 >> 1), *i1 = lago_smem + iwB + (a1 >> 1);
+                const uint32_t sx4 = sxB >> 1, sy4 = syB >> 1;
+                const float c0 = *reinterpret_cast<const float *>(i0), c4 = *reinterpret_cast<const float *>(i1);
+                const float c1 = *reinterpret_cast<const float *>(i0 + sx4), c5 = *reinterpret_cast<const float *>(i1 + sx4);
+                const float c2 = *reinterpret_cast<const float *>(i0 + sx4 + sy4), c6 = *reinterpret_cast<const float *>(i1 + sx4 + sy4);
+                const float c3 = *reinterpret_cast<const float *>(i0 + sy4), c7 = *reinterpret_cast<const float *>(i1 + sy4);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0), (double)wq[0]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1), (double)wq[1]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + syB), (double)wq[2]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + syB), (double)wq[3]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + sxB), (double)wq[4]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + sxB), (double)wq[5]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a0 + sxB + syB), (double)wq[6]);
+                lds_add(reinterpret_cast<double *>(lago_smem + a1 + sxB + syB), (double)wq[7]);
+                // include/interp.h:315-326
+                gx = lg_fma(omv, lg_fma(omu, c1 - c0, uu * (c2 - c3)), v * lg_fma(omu, c5 - c4, uu * (c6 - c7)));
+                gy = lg_fma(omv, lg_fma(omt, c3 - c0, t * (c2 - c1)), v * lg_fma(omt, c7 - c4, t * (c6 - c5)));
+                gz = lg_fma(omu, lg_fma(omt, c4 - c0, t * (c5 - c1)), uu * lg_fma(omt, c7 - c3, t * (c6 - c2)));
+            } else {
+                // beyond the window: position again (same expressions, same bits), the reference's clamped global
+                // atomics (include/interp.h:330-401, :431-453) and Lerp3's pair gathers
+                uint32_t tt = threadIdx.x + (uint32_t)it * NT;
+                asm volatile("" : "+v"(tt));  // nothing of this rare path may be hoisted out of the channel loop
+                const uint32_t a = sg.d_TyTz.div(tt);
+                const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
+                const uint32_t b = sg.d_Tz.div(rr);
+                const uint32_t kk = rr - b * (uint32_t)sg.TZ;
+                const float hx = shear_pos<UNIT>(x0 + (int)a, dt, un[sv >> 2]);
+                const float hy = shear_pos<UNIT>(y0 + (int)b, dt, un[(sv >> 2) + nv]);
+                const float hz = shear_pos<UNIT>(z0 + (int)kk, dt, un[(sv >> 2) + 2 * (size_t)nv]);
+                const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+                const uint32_t X0 = __umul24((uint32_t)clamp1(fx, nx), gxB), X1 = __umul24((uint32_t)clamp1(fx + 1, nx), gxB);
+                const uint32_t Y0 = __umul24((uint32_t)clamp1(fy, ny), gyB), Y1 = __umul24((uint32_t)clamp1(fy + 1, ny), gyB);
+                const uint32_t Z0 = (uint32_t)clamp1(fz, nz) * 4u, Z1 = (uint32_t)clamp1(fz + 1, nz) * 4u;
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[0], rdI, X0 + Y0 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[1], rdI, X0 + Y0 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[2], rdI, X0 + Y1 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[3], rdI, X0 + Y1 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[4], rdI, X1 + Y0 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[5], rdI, X1 + Y0 + Z1, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[6], rdI, X1 + Y1 + Z0, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[7], rdI, X1 + Y1 + Z1, 0, 0);
+                Lerp3<float, false> Lq;
+                Lq.setup(hx, hy, hz, nx, ny, nz);
+                Lq.grad(Ic, gx, gy, gz);
+            }
+            // cuda/interp.cu:230: (Real)((double)diff * dt); for dt = +-1 that is +-diff exactly
+            const float diff = UNIT ? (float)dt * gv : (float)((double)gv * dt);
+            rux[it] = lg_fma(gx, diff, rux[it]);   // ascending channel order, as the reference's thread-owned sum
+            ruy[it] = lg_fma(gy, diff, ruy[it]);
+            ruz[it] = lg_fma(gz, diff, ruz[it]);
+        }
+        if (c + 1 == nc) {   // d_u is complete: its stores travel under the flush
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) {
+                const uint32_t off = SV[it];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rux[it]), make_rsrc(dun, planeB), off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ruy[it]), make_rsrc(dun + nv, planeB), off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ruz[it]), make_rsrc(dun + 2 * (size_t)nv, planeB), off, 0, 0);
+            }
+        } else {
+            // the next channel's grad_out values are settled in front of the flush (loads and atomics share one in-order
+            // counter: behind the flush the wait would also cover every flush atomic's acknowledgement)
+#pragma unroll
+            for (int it = 0; it < VPL; ++it) asm volatile("" : "+v"(pgv[it]));
+        }
+        __syncthreads();   // every add has landed, every corner has been read
+        if (c + 1 < nc) request_image(c + 1);
+        // flush touched cells (one wave per window row, lanes along z) and re-zero them for the next channel
+        {
+            const int lane = threadIdx.x & 63;
+            const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const uint32_t nrows = (uint32_t)(WX * WY);
+            for (uint32_t row = wave; row < nrows; row += NT / 64) {
+                const uint32_t lx = sg.d_wy.div(row), ly = row - lx * (uint32_t)WY;
+                double *wrow = win + row * (uint32_t)WZ;
+                for (int lz = lane; lz < wez; lz += 64) {
+                    const double acc = wrow[lz];
+                    const int2 o = org_of((uint32_t)lz >> 4);   // (source lanes < nseg are on whenever any lane is)
+                    if (acc != 0.0) {
+                        if (c + 1 < nc) wrow[lz] = 0.0;
+                        const uint32_t off = __umul24((uint32_t)clamp1(o.x + (int)lx, nx), gxB) +
+                                             __umul24((uint32_t)clamp1(o.y + (int)ly, ny), gyB) + (uint32_t)(wz0 + lz) * 4u;
+                        (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((float)acc, rdI, off, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // TX TY TZ(0 = auto) margins MX MY MZ.  TX is an upper bound: make_shear shrinks it until the float64 window fits
 // 80 KB (8 x 6 -> 5 x 6 x 128 at nz = 128, 8 x 6 x 80 at nz = 160: 3840-voxel tiles).  Measured against 4 x 8
 // (tools/ab_tiles.py, steady state): 1-3 % faster at 128^3 and 160^3, one and three channels.
@@ -916,10 +1239,15 @@ static KnobArray<6> g_shear_cfg({8, 6, 0, 1, 1, 4});
 // g_shear_mc, several channels with d_u wanted: 0 d_u read-modify-written per channel, 1 d_u in registers over the
 // channels (splat_shear_kernel<..., VPL>), 2 (default) the geometry-once kernel (splat_shear_mc_kernel)
 static std::atomic<int> g_shear_nt{1024}, g_shear_on{1}, g_shear_mc{2};
+// 1 (default): d_u wanted -> splat_shear_iw_kernel (corners of the d_u term from an LDS window of I)
+static std::atomic<int> g_shear_iw{1};
 
 // max_vox > 0 (the geometry-once multi-channel kernel): the tile is shrunk further, larger of TX / TY first, until it
 // has at most that many voxels.
-static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem, int max_vox = 0) {
+// image_window (splat_shear_iw_kernel): 12 bytes per cell -- the float64 window plus the same cells of I as float32 --
+// within `budget` bytes of LDS per workgroup (80 KB: two workgroups per CU).
+static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem, int max_vox = 0, bool image_window = false,
+                       size_t budget = 80 * 1024) {
     const std::array<int, 6> cfg = g_shear_cfg.get();
     int TX = cfg[0], TY = cfg[1], TZ = cfg[2];
     const int EX = cfg[3], EY = cfg[4], EZ = cfg[5];
@@ -939,7 +1267,9 @@ static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem, i
         sg.WZ = TZ >= g.nz ? g.nz : ((TZ + 1 + 2 * EZ + 15 + 15) / 16) * 16;
         if (sg.WZ > g.nz) sg.WZ = g.nz;
         sg.nseg = (sg.WZ + 15) / 16;
-        const bool fits = (uint64_t)sg.WX * sg.WY * sg.WZ * 8 + (uint64_t)sg.nseg * 8 <= 80 * 1024;  // two workgroups per CU
+        const uint64_t cells = (uint64_t)sg.WX * sg.WY * sg.WZ;
+        const uint64_t iwb = image_window ? ((cells / 4 + 63) / 64) * 1024 : 0;   // whole 1 KB wave-instructions
+        const bool fits = cells * 8 + iwb + (uint64_t)sg.nseg * 8 <= budget;
         if (fits && (max_vox <= 0 || (int64_t)TX * TY * TZ <= max_vox)) break;
         if (max_vox > 0) {
             if (TX >= TY && TX > 1) --TX;
@@ -957,7 +1287,14 @@ static bool make_shear(ShearGeom &sg, const Geom &g, int64_t nn, size_t &smem, i
     sg.TX = TX; sg.TY = TY; sg.TZ = TZ;
     sg.MX = EX; sg.MY = EY; sg.MZ = EZ;
     sg.win_cells = (uint32_t)sg.WX * sg.WY * sg.WZ;
-    smem = (size_t)sg.win_cells * sizeof(double) + (size_t)sg.nseg * 8;
+    sg.iw_chunks = sg.iw_bytes = 0;
+    if (image_window) {
+        if ((sg.WZ & 15) || (g.nz & 3)) return false;   // 16-byte chunks of whole segments, rows 16-byte aligned
+        sg.iw_chunks = sg.win_cells / 4;
+        sg.iw_bytes = ((sg.iw_chunks + 63) / 64) * 1024;
+        sg.d_wzc = FastDiv((uint32_t)(sg.WZ / 4));
+    }
+    smem = (size_t)sg.win_cells * sizeof(double) + sg.iw_bytes + (size_t)sg.nseg * 8;
     sg.ntx = (g.nx + TX - 1) / TX;
     sg.nty = (g.ny + TY - 1) / TY;
     sg.ntz = (g.nz + TZ - 1) / TZ;
@@ -1020,6 +1357,26 @@ static int interp_backward_shear(float *d_I, float *d_u, const float *go, const 
     // (smaller tiles flush more cells); inside lddmm_step -- running d_u / d_I sums, 3-voxel displacements -- it wins
     // for both: 21.63 -> 20.40 ms per step at 8 x 160^3, 10.27 -> 9.85 at 8 x 128^3 (tools/ab_step_mc.py)
     const bool unit_step = unit_dt<float>(dt);
+    // d_u wanted (any channel count): corners through an LDS window of I, every operand of a tile requested up front
+    if (need_u && g_shear_iw && shear_nt >= 1024 && !((uintptr_t)I & 15u) && g.nx < 32768 && g.ny < 32768 &&
+        make_shear(sg, g, nn, smem, 2048, true) && sg.iw_chunks <= 2048u && sg.nseg <= 64) {
+        const bool one = sg.tile_vox <= 1024u;
+#define LAGO_SHEAR_IW(UN, B)                                                                                      \
+    do {                                                                                                          \
+        auto k = one ? splat_shear_iw_kernel<1024, UN, B, 1, 8> : splat_shear_iw_kernel<1024, UN, B, 2, 8>;       \
+        if (smem > 64 * 1024) {                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)smem);                                                                   \
+            if (e != hipSuccess) return fail_hip(e, "interp_backward (image-window splat)");                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL(k, dim3(sg.total), dim3(1024), smem, s, d_I, d_u, go, I, u, dt, nc, sg, umode, addgo);  \
+    } while (0)
+        if (unit_step) { if (bc) LAGO_SHEAR_IW(true, true); else LAGO_SHEAR_IW(true, false); }
+        else { if (bc) LAGO_SHEAR_IW(false, true); else LAGO_SHEAR_IW(false, false); }
+#undef LAGO_SHEAR_IW
+        note_path(LP_SPLAT_SHEAR_IW);
+        return finish_launch(s, "interp_backward (image-window splat)");
+    }
     if (need_u && nc > 1 && g_shear_mc >= 2 && shear_nt >= 1024 && make_shear(sg, g, nn, smem, 2048)) {
         const bool unit = unit_step;
         const bool one = sg.tile_vox <= 1024u;
@@ -1277,7 +1634,10 @@ extern "C" {
 // Affects speed only, never results.
 void lago_set_splat_mc(int on) { lago::g_splat_mc = on; }
 // sheared-window float32 splat: on/off, tile TX TY TZ (0 = auto), margins, threads per workgroup.  Speed only.
-void lago_set_splat_shear_mc(int mode) { lago::g_shear_mc = mode; }
+void lago_set_splat_shear_mc(int mode) {
+    lago::g_shear_iw = mode >= 3 ? 1 : 0;          // 3 (default): the image-window kernel where it applies
+    lago::g_shear_mc = mode >= 3 ? 2 : mode;
+}
 void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
     lago::g_shear_on = on;
     lago::g_shear_cfg.set({tx, ty, tz, mx, my, mz});

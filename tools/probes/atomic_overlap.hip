@@ -1,0 +1,84 @@
+// Probe (round 4): do the splat's flush atomics and its streamed operands OVERLAP in the memory system, or add?
+// The C = 1 splat at 8 x 128^3 moves 20 B/voxel in (u, grad_out, I), 12 B/voxel out (d_u) and flushes ~1.41 window cells
+// per voxel with global float atomics (512-byte rows).  Global float atomics execute at the memory side at ~1.3 TB/s
+// of added bytes; if that time ADDS to the streaming time the kernel is at its floor, if it overlaps there is headroom.
+//   stream   : coalesced reads of 5 planes + writes of 3 planes per voxel (the splat's 32 B/voxel), no atomics
+//   atomic   : the flush only -- per 5 x 6 x 128 tile a 6 x 7 window of 512-byte rows, one atomic per cell
+//   store    : the same rows with plain stores (what a non-atomic flush would cost)
+//   phased   : each workgroup streams its tile's operands, then flushes (the splat's structure), 2 workgroups per CU
+//   split    : half of the co-resident workgroups stream, the other half flush (memory-side overlap without the
+//              workgroup's own phase order)
+//   hipcc --offload-arch=gfx950 -O3 atomic_overlap.hip -o atomic_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+constexpr int S = 128, B = 8, TX = 5, TY = 6, NT = 1024;
+constexpr int NTX = (S + TX - 1) / TX, NTY = (S + TY - 1) / TY;
+
+__device__ __forceinline__ void stream_tile(float* __restrict__ out, const float* __restrict__ in, int n, int bx, int by, float& keep) {
+    const size_t nv = (size_t)S * S * S;
+    for (int t = threadIdx.x; t < TX * TY * S; t += NT) {
+        const int a = t / (TY * S), rr = t % (TY * S), c = rr / S, kz = rr % S;
+        const int gx = bx * TX + a, gy = by * TY + c;
+        if (gx >= S || gy >= S) continue;
+        const size_t sv = ((size_t)gx * S + gy) * S + kz;
+        const float* p = in + (size_t)n * 5 * nv + sv;
+        const float v0 = p[0], v1 = p[nv], v2 = p[2 * nv], v3 = p[3 * nv], v4 = p[4 * nv];
+        float* q = out + (size_t)n * 3 * nv + sv;
+        q[0] = v0 + v3; q[nv] = v1 + v4; q[2 * nv] = v2 * v3;
+        keep += v4;
+    }
+}
+template <bool ATOMIC>
+__device__ __forceinline__ void flush_tile(float* __restrict__ dI, int n, int bx, int by, float val) {
+    const size_t nv = (size_t)S * S * S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = wave; row < (TX + 1) * (TY + 1); row += NT / 64) {
+        const int lx = row / (TY + 1), ly = row % (TY + 1);
+        const int gx = min(bx * TX + lx, S - 1), gy = min(by * TY + ly, S - 1);
+        float* grow = dI + (size_t)n * nv + ((size_t)gx * S + gy) * S;
+        for (int z = lane; z < S; z += 64) {
+            if (ATOMIC) unsafeAtomicAdd(grow + z, val);
+            else grow[z] = val;
+        }
+    }
+}
+template <int MODE>  // 0 stream, 1 atomic, 2 store, 3 phased, 4 split
+__global__ __launch_bounds__(NT) void k(float* dI, float* out, const float* in) {
+    extern __shared__ double win[];
+    int b = blockIdx.x;
+    bool do_stream = MODE == 0 || MODE == 3, do_flush = MODE == 1 || MODE == 2 || MODE == 3;
+    if (MODE == 4) { do_stream = (b & 1) == 0; do_flush = !do_stream; b >>= 1; }
+    const int n = b / (NTX * NTY), r = b % (NTX * NTY), bx = r / NTY, by = r % NTY;
+    float keep = 0.f;
+    if (do_stream) stream_tile(out, in, n, bx, by, keep);
+    if (MODE == 3) __syncthreads();
+    if (do_flush) { if (MODE == 2) flush_tile<false>(dI, n, bx, by, 1.f + keep * 1e-30f); else flush_tile<true>(dI, n, bx, by, 1.f + keep * 1e-30f); }
+    if (keep == 1.2345e30f) win[0] = 1.0;
+}
+template <int MODE> float run(float* dI, float* out, const float* in, size_t smem) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    const int blocks = B * NTX * NTY * (MODE == 4 ? 2 : 1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    for (int i = 0; i < 3; ++i) k<MODE><<<blocks, NT, smem>>>(dI, out, in);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    for (int i = 0; i < 10; ++i) k<MODE><<<blocks, NT, smem>>>(dI, out, in);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / 10 * 1e3f;
+}
+int main() {
+    const size_t nv = (size_t)S * S * S;
+    float *dI, *out, *in;
+    (void)hipMalloc((void**)&dI, B * nv * 4); (void)hipMalloc((void**)&out, B * 3 * nv * 4); (void)hipMalloc((void**)&in, B * 5 * nv * 4);
+    (void)hipMemset(dI, 0, B * nv * 4); (void)hipMemset(in, 0, B * 5 * nv * 4);
+    const double streamMB = B * nv * 32 / 1e6, flushMB = (double)B * NTX * NTY * (TX + 1) * (TY + 1) * S * 4 / 1e6;
+    printf("8 x 128^3: streamed %.0f MB, flushed %.0f MB (%.2f cells per voxel)\n", streamMB, flushMB, flushMB / (B * nv * 4 / 1e6));
+    for (size_t smem : {(size_t)80 * 1024, (size_t)40 * 1024}) {
+        const float ts = run<0>(dI, out, in, smem), ta = run<1>(dI, out, in, smem), tp = run<2>(dI, out, in, smem);
+        const float t3 = run<3>(dI, out, in, smem), t4 = run<4>(dI, out, in, smem);
+        printf("LDS %3zu KB per workgroup (%d per CU): stream %.1f us (%.2f TB/s)  atomic flush %.1f us (%.2f TB/s)  store flush %.1f us\n"
+               "    phased %.1f us   split %.1f us   [sum %.1f, max %.1f]\n",
+               smem / 1024, (int)(160 * 1024 / smem), ts, streamMB / ts, ta, flushMB / ta, tp, t3, t4, ts + ta, ts > ta ? ts : ta);
+    }
+    return 0;
+}
