@@ -677,7 +677,9 @@ def test_rocfft_guard_judges_against_a_global_scale(ext):
         m = np.stack([np.sin(2 * np.pi * (3 * i / sp[0] + 5 * j / sp[1])), np.cos(2 * np.pi * 7 * i / sp[0])])[None].astype(np.float32)
         m = np.repeat(m, 3, 0)
         for inverse, f in ((True, met.sharp), (False, met.flat)):
-            assert_close(f(dev(m)), orc.fluid_metric_apply(m, [0.1, 0.0, 0.01], inverse), torch.float32, "sinusoid")
+            want = orc.fluid_metric_apply(m, [0.1, 0.0, 0.01], inverse)
+            err = float(np.abs(host(f(dev(m))).astype(np.float64) - want).max() / np.abs(want).max())
+            assert err <= 5e-5, ("sinusoid", inverse, err)   # (observed 1.04e-5: rocFFT float32 on a 3 x 2^5 / 5 x 2^3 plane)
     finally:
         ext.set_fluid_mode(2)
 

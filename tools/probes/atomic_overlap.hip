@@ -55,6 +55,53 @@ __global__ __launch_bounds__(NT) void k(float* dI, float* out, const float* in) 
     if (do_flush) { if (MODE == 2) flush_tile<false>(dI, n, bx, by, 1.f + keep * 1e-30f); else flush_tile<true>(dI, n, bx, by, 1.f + keep * 1e-30f); }
     if (keep == 1.2345e30f) win[0] = 1.0;
 }
+// persistent forms: G workgroups walk the tiles (tile = blockIdx.x, += G).  PM 0: every wave streams its tile, then flushes it,
+// no barrier anywhere (waves drift apart: loads, stores and atomics of different tiles in flight together); PM 1: waves
+// 0-7 only stream, waves 8-15 only flush (both all the time); PM 2: flush only; PM 3: stream only
+template <int PM>
+__global__ __launch_bounds__(NT) void kp(float* dI, float* out, const float* in, int ntiles) {
+    float keep = 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t nv = (size_t)S * S * S;
+    for (int b = blockIdx.x; b < ntiles; b += gridDim.x) {
+        const int n = b / (NTX * NTY), r = b % (NTX * NTY), bx = r / NTY, by = r % NTY;
+        const bool st = PM == 0 || PM == 3 || (PM == 1 && wave < 8), fl = PM == 0 || PM == 2 || (PM == 1 && wave >= 8);
+        if (st) {
+            const int nt = PM == 1 ? NT / 2 : NT, t0 = PM == 1 ? threadIdx.x : threadIdx.x;
+            for (int t = t0; t < TX * TY * S; t += nt) {
+                const int a = t / (TY * S), rr = t % (TY * S), c = rr / S, kz = rr % S;
+                const int gx = bx * TX + a, gy = by * TY + c;
+                if (gx >= S || gy >= S) continue;
+                const size_t sv = ((size_t)gx * S + gy) * S + kz;
+                const float* p = in + (size_t)n * 5 * nv + sv;
+                const float v0 = p[0], v1 = p[nv], v2 = p[2 * nv], v3 = p[3 * nv], v4 = p[4 * nv];
+                float* q = out + (size_t)n * 3 * nv + sv;
+                q[0] = v0 + v3; q[nv] = v1 + v4; q[2 * nv] = v2 * v3;
+                keep += v4;
+            }
+        }
+        if (fl) {
+            const int w0 = PM == 1 ? wave - 8 : wave, nw = PM == 1 ? 8 : 16;
+            for (int row = w0; row < (TX + 1) * (TY + 1); row += nw) {
+                const int lx = row / (TY + 1), ly = row % (TY + 1);
+                const int gx = min(bx * TX + lx, S - 1), gy = min(by * TY + ly, S - 1);
+                float* grow = dI + (size_t)n * nv + ((size_t)gx * S + gy) * S;
+                for (int z = lane; z < S; z += 64) unsafeAtomicAdd(grow + z, 1.f + keep * 1e-30f);
+            }
+        }
+    }
+    if (keep == 1.2345e30f) out[0] = 1.f;
+}
+template <int PM> float runp(float* dI, float* out, const float* in, int grid) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    const int ntiles = B * NTX * NTY;
+    for (int i = 0; i < 3; ++i) kp<PM><<<grid, NT>>>(dI, out, in, ntiles);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    for (int i = 0; i < 10; ++i) kp<PM><<<grid, NT>>>(dI, out, in, ntiles);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / 10 * 1e3f;
+}
 template <int MODE> float run(float* dI, float* out, const float* in, size_t smem) {
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     const int blocks = B * NTX * NTY * (MODE == 4 ? 2 : 1);
@@ -79,6 +126,10 @@ int main() {
         printf("LDS %3zu KB per workgroup (%d per CU): stream %.1f us (%.2f TB/s)  atomic flush %.1f us (%.2f TB/s)  store flush %.1f us\n"
                "    phased %.1f us   split %.1f us   [sum %.1f, max %.1f]\n",
                smem / 1024, (int)(160 * 1024 / smem), ts, streamMB / ts, ta, flushMB / ta, tp, t3, t4, ts + ta, ts > ta ? ts : ta);
+    }
+    for (int grid : {256, 512, 128}) {
+        printf("persistent, %d workgroups of 1024: stream only %.1f us  flush only %.1f us  every wave stream+flush %.1f us  waves split 8/8 %.1f us\n",
+               grid, runp<3>(dI, out, in, grid), runp<2>(dI, out, in, grid), runp<0>(dI, out, in, grid), runp<1>(dI, out, in, grid));
     }
     return 0;
 }
