@@ -98,6 +98,8 @@ void lago_set_gather_window(int on);
 #define LAGO_PATH_FLUID_XPASS 9    /* lago_fluid_metric: rocFFT (y, z) plan + fused x pass */
 #define LAGO_PATH_FLUID_ROCFFT 10  /* lago_fluid_metric: rocFFT plan + operator kernel */
 #define LAGO_PATH_SPLAT_SHEAR_IW 11 /* sheared-window splat with the d_u corners from an LDS window of I */
+#define LAGO_PATH_SPLAT_SHEAR_PP 12 /* its persistent, software-pipelined form (one workgroup per CU) */
+#define LAGO_PATH_SPLAT_SHEAR_ROW 13 /* sheared-window splat, row-mapped (index arithmetic out of the voxel loop) */
 long long lago_path_launches(int path);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
  * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes

@@ -16,7 +16,17 @@ ext = lm.lagomorph_ext
 dev = torch.device("cuda")
 cases = [tuple(float(x) for x in c.split(":")) for c in
          os.environ.get("CASES", "128:8:1:1,128:8:3:1,128:8:3:-0.2,160:8:1:1,160:8:3:-0.2").split(",")]
-MODES = [int(x) for x in os.environ.get("MODES", "3,2").split(",")]
+# a mode may carry a tile setting: "5:8x8" = mode 5 with set_splat_shear(1, 8, 8, 0, 1, 1, 4, 1024)
+MODES = [m for m in os.environ.get("MODES", "5,4,3,2").split(",")]
+
+
+def apply(m):
+    mode, _, tile = m.partition(":")
+    tx, ty = (int(x) for x in tile.split("x")) if tile else (8, 6)
+    ext.set_splat_shear(1, tx, ty, 0, 1, 1, 4, 1024)
+    ext.set_splat_shear_mc(int(mode))
+
+
 for S, B, C, dt in cases:
     S, B, C = int(S), int(B), int(C)
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -28,7 +38,7 @@ for S, B, C, dt in cases:
     res, rows = {}, {m: [] for m in MODES}
     for r in range(3):
         for m in MODES:
-            ext.set_splat_shear_mc(m)
+            apply(m)
             if r == 0:
                 before = ext.path_launches()
                 res[m] = ext.interp_backward(go, I, u, dt, True, True)
@@ -36,7 +46,8 @@ for S, B, C, dt in cases:
                 res[(m, "path")] = [k for k in after if after[k] != before[k]]
             med, _ = time_op(lambda: ext.interp_backward(go, I, u, dt, True, True), reps=30, warm=30)
             rows[m].append(med * 1e3)
-    ext.set_splat_shear_mc(3)
+    ext.set_splat_shear(1, 8, 6, 0, 1, 1, 4, 1024)
+    ext.set_splat_shear_mc(ext.DEFAULT_SPLAT_SHEAR_MC)
     a, b = res[MODES[0]], res[MODES[-1]]
     same_du = torch.equal(a[1], b[1])
     dI_err = float((a[0] - b[0]).abs().max() / b[0].abs().max())
@@ -44,6 +55,6 @@ for S, B, C, dt in cases:
     print(f"S={S} B={B} C={C} dt={dt}: d_u same bits {same_du}, d_I rel diff {dI_err:.2e}")
     for m in MODES:
         best = min(rows[m])
-        print(f"   mode {m} {res[(m, 'path')]}: " + "  ".join(f"{x:7.1f}" for x in rows[m]) +
+        print(f"   mode {m:6s} {res[(m, 'path')]}: " + "  ".join(f"{x:7.1f}" for x in rows[m]) +
               f" us   best -> {alg / best / 1e6:.2f} TB/s = {alg / best / 8e6:.3f} of peak")
     del I, u, go, res
