@@ -97,9 +97,6 @@ void lago_set_gather_window(int on);
 #define LAGO_PATH_FLUID_2D 8       /* lago_fluid_metric: one fused 2D kernel */
 #define LAGO_PATH_FLUID_XPASS 9    /* lago_fluid_metric: rocFFT (y, z) plan + fused x pass */
 #define LAGO_PATH_FLUID_ROCFFT 10  /* lago_fluid_metric: rocFFT plan + operator kernel */
-#define LAGO_PATH_SPLAT_SHEAR_IW 11 /* sheared-window splat with the d_u corners from an LDS window of I */
-#define LAGO_PATH_SPLAT_SHEAR_PP 12 /* its persistent, software-pipelined form (one workgroup per CU) */
-#define LAGO_PATH_SPLAT_SHEAR_ROW 13 /* sheared-window splat, row-mapped (index arithmetic out of the voxel loop) */
 long long lago_path_launches(int path);
 /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
  * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
@@ -113,10 +110,7 @@ void lago_set_fluid_xpass(int mode);
  * above 128 voxels), window margins MX MY MZ around the probed origin, threads per workgroup (256 / 512 / 1024).
  * Default 1, 8 6 0, 1 1 4, 1024.  d_u is bit-identical under every setting; d_I differs by the order of its sums. */
 void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
-/* d_u wanted.  3 (default): any channel count goes through splat_shear_iw_kernel where the shape allows (nz a multiple
- * of 4, I 16-byte aligned): the tile's footprint cells of I are staged in LDS next to the float64 accumulation window
- * and the eight corners of the d_u term are LDS reads; every operand of a tile is requested up front.  Below 3, several
- * channels with d_u wanted.  Sheared-window kernel: 2 each voxel's geometry -- window addresses,
+/* Several channels with d_u wanted.  Sheared-window kernel: 2 (default) each voxel's geometry -- window addresses,
  * gather offset, fractions -- and its d_u sums stay in registers over the channel loop (tiles of at most 2048
  * voxels), 1 only the d_u sums do (geometry recomputed per channel), 0 d_u is read-modify-written per channel.  General tiled
  * kernel: 1 (default) / 0 likewise.  Same d_u bits under every setting. */

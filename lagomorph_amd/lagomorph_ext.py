@@ -168,14 +168,9 @@ def set_splat_mc(on):
     _lib.lago_set_splat_mc(1 if on else 0)
 
 
-DEFAULT_SPLAT_SHEAR_MC = 5
-
-
 def set_splat_shear_mc(mode):
-    """Sheared-window splat with d_u wanted: 4 the persistent, software-pipelined image-window kernel (whole z rows of at
-    most 160 voxels), 3 the one-shot image-window kernel (corners of the d_u term from an LDS window of I, any channel
-    count); several channels below that: 2 geometry and d_u sums in registers over the channels, 1 the d_u sums only,
-    0 neither.  Speed only (same d_u bits)."""
+    """Sheared-window splat, several channels with d_u: 2 (default) geometry and d_u sums in registers over the
+    channels, 1 the d_u sums only, 0 neither.  Speed only (same d_u bits)."""
     _lib.lago_set_splat_shear_mc(int(mode))
 
 
@@ -204,7 +199,7 @@ def set_stencil_tile(on):
 _lib.lago_path_launches.restype = ctypes.c_longlong
 _lib.lago_path_launches.argtypes = [_int]
 PATHS = ("gather_window", "stencil_tile", "vector_gather", "splat_shear", "splat_shear_mc", "splat_tiled", "splat_global",
-         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft", "splat_shear_iw", "splat_shear_pp", "splat_shear_row")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
+         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
 
 
 def path_launches(name=None):

@@ -39,18 +39,9 @@ def test_headline_operators_take_their_fast_paths(lm, sp):
     assert _delta(shim, lambda: shim.interp_forward(I, u, 1.0)) == {"vector_gather": 1}     # one channel: pair gathers
     assert _delta(shim, lambda: shim.interp_forward(v, u, 1.0)) == {"gather_window": 1}     # several: through the LDS window
     go = _fields(1, 1, sp)
-    # d_u wanted: the image-window kernels (corners of the d_u term from an LDS window of I), any channel count
+    assert _delta(shim, lambda: shim.interp_backward(go, I, u, 1.0, True, True)) == {"splat_shear": 1}
     go3 = _fields(1, 3, sp)
-    want = shim.DEFAULT_SPLAT_SHEAR_MC
-    try:
-        for mode, one, three in ((4, "splat_shear_pp", "splat_shear_pp"), (3, "splat_shear_iw", "splat_shear_iw"),
-                                 (2, "splat_shear", "splat_shear_mc")):
-            shim.set_splat_shear_mc(mode)
-            assert _delta(shim, lambda: shim.interp_backward(go, I, u, 1.0, True, True)) == {one: 1}, mode
-            assert _delta(shim, lambda: shim.interp_backward(go3, v, u, -0.1, True, True)) == {three: 1}, mode
-            assert _delta(shim, lambda: shim.interp_backward(go, I, u, 1.0, True, False)) == {"splat_shear": 1}
-    finally:
-        shim.set_splat_shear_mc(want)
+    assert _delta(shim, lambda: shim.interp_backward(go3, v, u, -0.1, True, True)) == {"splat_shear_mc": 1}
 
 
 @pytest.mark.parametrize("sp,path", [((128, 128, 128), "fluid_lds"), ((160, 160, 160), "fluid_lds"), ((64, 96, 128), "fluid_lds"),

@@ -281,7 +281,7 @@ def _oracle_threads():
 @pytest.mark.parametrize("dt", [1.0, -0.2])
 def test_config4_splat_production_geometry_160_vs_oracle(lm, nc, dt):
     """The shipped splat kernels in their 160^3 production geometry (z rows split into two 80-voxel parts, 112-cell
-    windows; one channel: splat_shear_kernel, three: the geometry-once / window forms) against the CPU oracle on one
+    windows; one channel: splat_shear_kernel, three: splat_shear_mc_kernel) against the CPU oracle on one
     item of a two-item batch: d_u bit for bit, d_I within 1e-5 x max, unit and non-unit step, with and without d_u."""
     ext = lm.lagomorph_ext
     g = torch.Generator(device="cuda").manual_seed(160 + nc)
@@ -294,7 +294,7 @@ def test_config4_splat_production_geometry_160_vs_oracle(lm, nc, dt):
     before = ext.path_launches()
     dI, du = ext.interp_backward(go, I, u, dt, True, True)
     after = ext.path_launches()
-    assert sum(after[k] - before[k] for k in ("splat_shear", "splat_shear_mc", "splat_shear_iw")) == 1, "not a sheared-window kernel"
+    assert sum(after[k] - before[k] for k in ("splat_shear", "splat_shear_mc")) == 1, "not a sheared-window kernel"
     pick = [1]
     orc.set_threads(_oracle_threads())
     try:

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B in one process: the image-window splat (lago_set_splat_shear_mc 3) against its predecessors (2), alternating
+"""A/B in one process of lago_set_splat_shear_mc modes / tile settings (round 4 used it for the image-window, pipelined and
+row-mapped splat kernels -- commits a5e8ce0 .. d7f13fb, removed again: profiles/r04_splat_pipeline.md), alternating
 rounds, 30 warm-up + 30 timed launches each; configs[1] (8 x 1 x 128^3) and the three-channel reverse-sweep form at
 128^3 / 160^3, unit and non-unit step, plus d_u bits and d_I agreement between the two.
 env: CASES "S:B:C:dt,..." """
@@ -17,7 +18,7 @@ dev = torch.device("cuda")
 cases = [tuple(float(x) for x in c.split(":")) for c in
          os.environ.get("CASES", "128:8:1:1,128:8:3:1,128:8:3:-0.2,160:8:1:1,160:8:3:-0.2").split(",")]
 # a mode may carry a tile setting: "5:8x8" = mode 5 with set_splat_shear(1, 8, 8, 0, 1, 1, 4, 1024)
-MODES = [m for m in os.environ.get("MODES", "5,4,3,2").split(",")]
+MODES = [m for m in os.environ.get("MODES", "2,1").split(",")]
 
 
 def apply(m):
@@ -47,7 +48,7 @@ for S, B, C, dt in cases:
             med, _ = time_op(lambda: ext.interp_backward(go, I, u, dt, True, True), reps=30, warm=30)
             rows[m].append(med * 1e3)
     ext.set_splat_shear(1, 8, 6, 0, 1, 1, 4, 1024)
-    ext.set_splat_shear_mc(ext.DEFAULT_SPLAT_SHEAR_MC)
+    ext.set_splat_shear_mc(2)
     a, b = res[MODES[0]], res[MODES[-1]]
     same_du = torch.equal(a[1], b[1])
     dI_err = float((a[0] - b[0]).abs().max() / b[0].abs().max())

@@ -20,7 +20,7 @@ I = I / I.std()
 u = gaussian_blur(torch.randn((B, 3, S, S, S), device=dev, generator=g), 8.0)
 u = u * (4.0 / u.abs().max())
 go = torch.randn((B, C, S, S, S), device=dev, generator=g)
-for mode in [int(x) for x in os.environ.get("MODES", "4,3,2").split(",")]:
+for mode in [int(x) for x in os.environ.get("MODES", "2").split(",")]:
     ext.set_splat_shear_mc(mode)
     for _ in range(5):
         ext.interp_backward(go, I, u, dt, True, True)
