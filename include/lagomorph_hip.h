@@ -37,7 +37,7 @@ extern "C" {
 #define LAGO_ERR_INVALID (-1)
 #define LAGO_ERR_HIP (-2)
 
-#define LAGO_ABI_VERSION 3
+#define LAGO_ABI_VERSION 4
 
 /* ---- housekeeping --------------------------------------------------------- */
 
@@ -50,40 +50,77 @@ int lago_abi_version(void);
 const char *lago_version(void);
 const char *lago_last_error(void);
 
-/* Tuning settings.  All of them are PROCESS-WIDE, stored atomically (they may be changed while other host threads,
- * e.g. autograd's backward threads, are inside entry points: a call sees the old or the new setting as a whole) and
- * affect speed only, never which results are produced beyond the rounding differences documented per setting.
- * The defaults are what the product runs with; the parity tests sweep them. */
-/* interp_backward: 0 = global float atomics only,
- * 1 = LDS-privatised splat with atomic flush (default for 3D f32). */
-void lago_set_splat_mode(int mode);
-int lago_get_splat_mode(void);
-/* Tuning hook for the LDS-privatised splat: source tile TX x TY x TZ (TZ = 0:
- * whole z rows, split evenly above 128 voxels; TX = 0: about 4096 voxels per
- * tile), window margins MX MY MZ, threads per workgroup (256 / 512 / 1024).
- * Default 0 8 0 1 1 4 512.  Affects speed only, never results. */
-void lago_set_splat_tile(int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
-/* 1 (default): use the slab-unrolled 3D gather kernels (two voxels per lane) when the shape allows; 0: one-voxel-per-lane kernels only. */
-void lago_set_vector_kernels(int on);
-/* 1 (default): every launch of the large kernels walks its workgroups in the opposite direction of the launch before
- * it, so that a consumer starts on what its producer wrote last -- still in the 256 MB Infinity Cache; 0: always
- * ascending.  Same results (scatter-add outputs differ in their last bits, as between any two runs).  The direction
- * is taken from ONE process-wide launch counter (every entry point that builds a launch geometry advances it, small
- * launches and calls that fail a later argument check included), so "opposite to its producer" holds for the chains
- * of large kernels the library itself issues back to back, and the last bits of scatter-add outputs (d_I) depend on
- * how many launches came before -- as they depend on the hardware's atomic ordering anyway; every other output is
- * bit-identical in both directions. */
-void lago_set_launch_order(int alternate);
-/* 1 (default): the 3D Jacobian / stencil terms of Ad_star and jacobian_times_vectorfield_backward are taken from an
- * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows -- 128^3 and 160^3
- * volumes through instantiations with their geometry compiled in; 3: row tiles without those instantiations; 0: every
- * neighbour is loaded from global memory.  Same bits. */
-void lago_set_stencil_tile(int on);
-/* 1 (default): float32 3D trilinear gathers of smooth fields (compose) stage the source block of a
- * tile of voxels in LDS with LDS-direct loads and take the corners from there (csrc/gather_window.hpp) where the
- * shape allows; a workgroup whose samples leave its window, and every other shape, uses the pair gathers through the
- * vector L1; 0: pair gathers only.  Same bits. */
-void lago_set_gather_window(int on);
+/* Tuning settings: ONE struct, read and written as a whole (the ABI does not grow per experiment).  The settings are
+ * PROCESS-WIDE (two users of the library in one process share them), stored atomically field by field (they may be
+ * changed while other host threads, e.g. autograd's backward threads, are inside entry points) and affect speed only,
+ * never which results are produced beyond the rounding differences noted per field.  The defaults are what the product
+ * runs with; the parity tests sweep them.  `struct_size` is sizeof(lago_tuning) as the CALLER was compiled: the
+ * library reads / writes only that many bytes, so a caller built against an older header keeps working when fields
+ * are appended. */
+typedef struct lago_tuning {
+    uint32_t struct_size;
+    /* interp_backward: 0 global float atomics only (the reference's form), 1 LDS-privatised splat with atomic flush
+     * (default for 3D float32) */
+    int32_t splat_mode;
+    /* general tiled LDS splat: source tile TX TY TZ (TZ = 0: whole z rows, split evenly above 128 voxels; TX = 0: about
+     * 4096 voxels per tile), window margins MX MY MZ, threads per workgroup (256 / 512 / 1024).  Default 0 8 0 1 1 4 512 */
+    int32_t splat_tile[7];
+    /* sheared-window float32 3D displacement splat (csrc/splat.hip: splat_shear_kernel, the form interp_backward takes
+     * for float32 3D fields): on (0 leaves every call to the general tiled kernel), source tile TX TY TZ (TX an upper
+     * bound shrunk until the window fits 80 KB; TZ = 0: whole z rows, split evenly above 128 voxels), window margins
+     * MX MY MZ around the probed origin, threads per workgroup.  Default 1, 8 6 0, 1 1 4, 1024.  d_u is bit-identical
+     * under every setting; d_I differs by the order of its sums */
+    int32_t splat_shear[8];
+    /* several channels with d_u wanted, sheared-window kernel: 2 (default) each voxel's geometry -- window addresses,
+     * gather offset, fractions -- and its d_u sums stay in registers over the channel loop (tiles of at most 2048
+     * voxels), 1 only the d_u sums do (geometry recomputed per channel), 0 d_u is read-modify-written per channel.
+     * Same d_u bits under every setting */
+    int32_t splat_shear_mc;
+    /* the same for the general tiled kernel: 1 (default) / 0 */
+    int32_t splat_mc;
+    /* 1 (default): the slab-unrolled 3D gather kernels (two voxels per lane) when the shape allows; 0: one-voxel-per-lane
+     * kernels only */
+    int32_t vector_kernels;
+    /* 1 (default): every launch of the large kernels walks its workgroups in the opposite direction of the launch before
+     * it, so that a consumer starts on what its producer wrote last -- still in the 256 MB Infinity Cache; 0: always
+     * ascending.  Same results (scatter-add outputs differ in their last bits, as between any two runs).  The direction
+     * is taken from ONE process-wide launch counter (every entry point that builds a launch geometry advances it, small
+     * launches and calls that fail a later argument check included), so "opposite to its producer" holds for the chains
+     * of large kernels the library itself issues back to back, and the last bits of scatter-add outputs (d_I) depend on
+     * how many launches came before -- as they depend on the hardware's atomic ordering anyway; every other output is
+     * bit-identical in both directions */
+    int32_t launch_order;
+    /* 1 (default): the 3D Jacobian / stencil terms of Ad_star and jacobian_times_vectorfield_backward are taken from an
+     * LDS-staged tile of z-rows with a one-voxel halo (csrc/stencil_tile.hpp) where the shape allows -- 128^3 and 160^3
+     * volumes through instantiations with their geometry compiled in; 3: row tiles without those instantiations; 0:
+     * every neighbour is loaded from global memory.  Same bits */
+    int32_t stencil_tile;
+    /* 1 (default): float32 3D trilinear gathers of smooth fields (compose, interp_forward of several channels) stage the
+     * source block of a tile of voxels in LDS with LDS-direct loads and take the corners from there
+     * (csrc/gather_window.hpp) where the shape allows; 0: pair gathers through the vector L1 only.  Same bits */
+    int32_t gather_window;
+    /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT (nx in
+     * {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes 32x{64,128,256},
+     * 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z) plan + fused x-axis pass (nx in
+     * {64,128,256}); 0: rocFFT 3D plan + operator kernel.  A mode falls back to the next lower one for shapes it does
+     * not support.  Results agree to rounding */
+    int32_t fluid_mode;
+    /* FFT-pass fluid metric: batch items per x-pass workgroup (0, the default: chosen by the size of the launch) */
+    int32_t fluid_xpass_ipw;
+    /* persistent prefetching zy kernels for planes above 80 KB of LDS (default 1) */
+    int32_t fluid_zy_persist;
+    /* 512-thread x-pass workgroups for the 256-point tile (default 1) */
+    int32_t fluid_xpass_wide;
+    /* x pass as a persistent grid of two workgroups per CU that prefetch their next tile (default 1: taken when the
+     * launch has at least four (bin tile, batch item) pairs per workgroup; 2: always; 0: never).  Same bits */
+    int32_t fluid_xpass_persist;
+} lago_tuning;
+/* the settings in force / the library's defaults: fills t->struct_size bytes (struct_size set by the caller) */
+void lago_get_tuning(lago_tuning *t);
+void lago_default_tuning(lago_tuning *t);
+/* applies the first t->struct_size bytes (fields beyond them keep their values); LAGO_ERR_INVALID for a null pointer or
+ * a struct_size that is not a whole number of fields */
+int lago_set_tuning(const lago_tuning *t);
 /* Which implementation calls were dispatched to: number of launches so far in this process per path (telemetry; the
  * tests use it to make sure a case meant to exercise a fast path really runs it).  -1 for an unknown id. */
 #define LAGO_PATH_GATHER_WINDOW 0  /* compose through the LDS window */
@@ -98,34 +135,7 @@ void lago_set_gather_window(int on);
 #define LAGO_PATH_FLUID_XPASS 9    /* lago_fluid_metric: rocFFT (y, z) plan + fused x pass */
 #define LAGO_PATH_FLUID_ROCFFT 10  /* lago_fluid_metric: rocFFT plan + operator kernel */
 long long lago_path_launches(int path);
-/* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT
- * (nx in {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
- * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z)
- * plan + fused x-axis pass (nx in {64,128,256}); 0: rocFFT 3D plan + operator kernel.  A mode falls back
- * to the next lower one for shapes it does not support.  Results agree to rounding. */
-void lago_set_fluid_xpass(int mode);
-/* Sheared-window float32 3D displacement splat (csrc/splat.hip: splat_shear_kernel, the form interp_backward takes
- * for float32 3D fields): on (default 1; 0 leaves every call to the general tiled kernel of lago_set_splat_tile),
- * source tile TX x TY x TZ (TX an upper bound shrunk until the window fits 80 KB; TZ = 0: whole z rows, split evenly
- * above 128 voxels), window margins MX MY MZ around the probed origin, threads per workgroup (256 / 512 / 1024).
- * Default 1, 8 6 0, 1 1 4, 1024.  d_u is bit-identical under every setting; d_I differs by the order of its sums. */
-void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads);
-/* Several channels with d_u wanted.  Sheared-window kernel: 2 (default) each voxel's geometry -- window addresses,
- * gather offset, fractions -- and its d_u sums stay in registers over the channel loop (tiles of at most 2048
- * voxels), 1 only the d_u sums do (geometry recomputed per channel), 0 d_u is read-modify-written per channel.  General tiled
- * kernel: 1 (default) / 0 likewise.  Same d_u bits under every setting. */
-void lago_set_splat_shear_mc(int mode);
-void lago_set_splat_mc(int on);
-/* FFT-pass fluid metric: batch items per x-pass workgroup (0, the default: chosen by the size of the launch),
- * persistent prefetching zy kernels for planes above 80 KB of LDS (default 1), 512-thread x-pass workgroups for
- * the 256-point tile (default 1).  Same bits under every setting. */
-void lago_set_fluid_xpass_ipw(int items);
-void lago_set_fluid_zy_persist(int on);
-void lago_set_fluid_xpass_wide(int on);
-/* x pass as a persistent grid of two workgroups per CU that prefetch their next tile (default 1; taken when the
- * launch has at least eight (bin tile, batch item) pairs per workgroup; 2: whatever its size; 0: one-shot workgroups).
- * Same bits under every setting. */
-void lago_set_fluid_xpass_persist(int on);
+
 
 #define LAGO_DECLARE(REAL, SUF)                                                                                      \
     /* interp_forward (extension.cpp:135-143 -> cuda/interp.cu:80-130):                                           \

@@ -39,19 +39,70 @@ int finish_launch(hipStream_t s, const char *what) {
     return LAGO_OK;
 }
 
+// ---- tuning: one struct (include/lagomorph_hip.h).  The struct in force is kept here; a set applies it to the modules.
+static std::mutex g_tuning_mu;
+static lago_tuning default_tuning() {
+    lago_tuning t;
+    memset(&t, 0, sizeof(t));
+    t.struct_size = (uint32_t)sizeof(lago_tuning);
+    t.splat_mode = 1;
+    const int32_t tile[7] = {0, 8, 0, 1, 1, 4, 512}, shear[8] = {1, 8, 6, 0, 1, 1, 4, 1024};
+    memcpy(t.splat_tile, tile, sizeof(tile));
+    memcpy(t.splat_shear, shear, sizeof(shear));
+    t.splat_shear_mc = 2;
+    t.splat_mc = 1;
+    t.vector_kernels = 1;
+    t.launch_order = 1;
+    t.stencil_tile = 1;
+    t.gather_window = 1;
+    t.fluid_mode = 2;
+    t.fluid_xpass_ipw = 0;
+    t.fluid_zy_persist = 1;
+    t.fluid_xpass_wide = 1;
+    t.fluid_xpass_persist = 1;
+    return t;
+}
+static lago_tuning g_tuning = default_tuning();
+
 }  // namespace lago
 
 extern "C" {
+void lago_default_tuning(lago_tuning *t) {
+    if (!t) return;
+    const lago_tuning d = lago::default_tuning();
+    const uint32_t n = t->struct_size < sizeof(d) ? t->struct_size : (uint32_t)sizeof(d);
+    if (n > sizeof(uint32_t)) memcpy((char *)t + sizeof(uint32_t), (const char *)&d + sizeof(uint32_t), n - sizeof(uint32_t));
+}
+void lago_get_tuning(lago_tuning *t) {
+    if (!t) return;
+    std::lock_guard<std::mutex> lk(lago::g_tuning_mu);
+    const uint32_t n = t->struct_size < sizeof(lago::g_tuning) ? t->struct_size : (uint32_t)sizeof(lago::g_tuning);
+    if (n > sizeof(uint32_t))
+        memcpy((char *)t + sizeof(uint32_t), (const char *)&lago::g_tuning + sizeof(uint32_t), n - sizeof(uint32_t));
+}
+int lago_set_tuning(const lago_tuning *t) {
+    if (!t) return lago::fail_invalid("lago_set_tuning: null pointer");
+    if (t->struct_size < sizeof(uint32_t) || t->struct_size % sizeof(int32_t) != 0)
+        return lago::fail_invalid("lago_set_tuning: struct_size %u is not a whole number of fields", t->struct_size);
+    std::lock_guard<std::mutex> lk(lago::g_tuning_mu);
+    lago_tuning &g = lago::g_tuning;
+    const uint32_t n = t->struct_size < sizeof(g) ? t->struct_size : (uint32_t)sizeof(g);
+    memcpy((char *)&g + sizeof(uint32_t), (const char *)t + sizeof(uint32_t), n - sizeof(uint32_t));
+    lago::g_splat_mode = g.splat_mode;
+    lago::g_interp_vec = g.vector_kernels ? 1 : 0;
+    lago::g_launch_alt = g.launch_order ? 1 : 0;
+    lago::tune_splat(g.splat_tile, g.splat_shear, g.splat_shear_mc, g.splat_mc);
+    lago::tune_fused(g.stencil_tile, g.gather_window);
+    lago::tune_fluid(g.fluid_mode);
+    lago::tune_fluid_passes(g.fluid_xpass_ipw, g.fluid_zy_persist, g.fluid_xpass_wide, g.fluid_xpass_persist);
+    return LAGO_OK;
+}
 void lago_set_debug(int on) { lago::g_debug = on ? 1 : 0; }
 int lago_get_debug(void) { return lago::g_debug; }
 int lago_abi_version(void) { return LAGO_ABI_VERSION; }
 const char *lago_version(void) { return "lagomorph_hip 0.1 (gfx950, HIP)"; }
 const char *lago_last_error(void) { return lago::g_err; }
-void lago_set_splat_mode(int mode) { lago::g_splat_mode = mode; }
-int lago_get_splat_mode(void) { return lago::g_splat_mode; }
-void lago_set_vector_kernels(int on) { lago::g_interp_vec = on ? 1 : 0; }
 long long lago_path_launches(int path) {
     return path >= 0 && path < lago::LP_COUNT ? lago::g_path_launches[path].load() : -1;
 }
-void lago_set_launch_order(int alternate) { lago::g_launch_alt = alternate ? 1 : 0; }
 }

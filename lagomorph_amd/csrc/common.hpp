@@ -63,6 +63,12 @@ enum { LP_GATHER_WINDOW = 0, LP_STENCIL_TILE, LP_VECTOR_GATHER, LP_SPLAT_SHEAR, 
 extern std::atomic<long long> g_path_launches[LP_COUNT];
 inline void note_path(int p) { g_path_launches[p].fetch_add(1, std::memory_order_relaxed); }
 
+// tuning (include/lagomorph_hip.h: lago_tuning): every module applies its own fields (api.hip: lago_set_tuning)
+void tune_splat(const int32_t *tile7, const int32_t *shear8, int shear_mc, int mc);    // splat.hip
+void tune_fused(int stencil_tile, int gather_window);                                   // fused.hip
+void tune_fluid(int mode);                                                              // fft.hip
+void tune_fluid_passes(int ipw, int zy_persist, int xpass_wide, int xpass_persist);     // fft3.hip
+
 #define LAGO_HIP_TRY(expr)                                      \
     do {                                                        \
         hipError_t e__ = (expr);                                \

@@ -503,8 +503,11 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
 
 }  // namespace lago
 
+namespace lago {
+void tune_fluid(int mode) { g_fluid_xpass = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+}  // namespace lago
+
 extern "C" {
-void lago_set_fluid_xpass(int mode) { lago::g_fluid_xpass = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 void lago_fluid_cache_clear(void) {
     std::vector<lago::CoefRef> dropped;  // released after the lock
     std::lock_guard<std::mutex> lk(lago::g_plan_mu);

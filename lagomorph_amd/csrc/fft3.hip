@@ -560,8 +560,12 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
 #ifdef LAGO_PROFILING
 extern "C" void lago_debug_fluid_stage_mask(int m) { lago::g_native_stage_mask = m; }
 #endif
-// tuning settings (speed only; include/lagomorph_hip.h)
-extern "C" void lago_set_fluid_xpass_ipw(int n) { lago::g_xpass_ipw = n; }
-extern "C" void lago_set_fluid_zy_persist(int on) { lago::g_zy_persist = on; }
-extern "C" void lago_set_fluid_xpass_wide(int on) { lago::g_xpass_wide = on; }
-extern "C" void lago_set_fluid_xpass_persist(int on) { lago::g_xpass_persist = on; }
+// tuning settings (speed only; include/lagomorph_hip.h: lago_tuning)
+namespace lago {
+void tune_fluid_passes(int ipw, int zy_persist, int xpass_wide, int xpass_persist) {
+    g_xpass_ipw = ipw;
+    g_zy_persist = zy_persist;
+    g_xpass_wide = xpass_wide;
+    g_xpass_persist = xpass_persist;
+}
+}  // namespace lago

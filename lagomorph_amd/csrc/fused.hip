@@ -680,12 +680,16 @@ int lincomb_impl(R *out, int k, const R *x0, const R *x1, const R *x2, const R *
 
 }  // namespace lago
 
-extern "C" {
-void lago_set_stencil_tile(int on) {   // 0: direct kernels; 1: row tiles (default); 3: row tiles without the compile-time-geometry instantiations
-    lago::g_stencil_tile = on ? 1 : 0;
-    lago::g_tile_cube = on == 3 ? 0 : 1;
+namespace lago {
+void tune_fused(int stencil_tile, int gather_window) {
+    // stencil_tile 0: direct kernels; 1: row tiles (default); 3: row tiles without the compile-time-geometry instantiations
+    g_stencil_tile = stencil_tile ? 1 : 0;
+    g_tile_cube = stencil_tile == 3 ? 0 : 1;
+    g_gather_window = gather_window ? 1 : 0;
 }
-void lago_set_gather_window(int on) { lago::g_gather_window = on ? 1 : 0; }
+}  // namespace lago
+
+extern "C" {
 int lago_lincomb_f32(float *out, int k, const float *x0, const float *x1, const float *x2, const float *x3, double c0,
                      double c1, double c2, double c3, int64_t n, void *stream) {
     return lago::lincomb_impl<float>(out, k, x0, x1, x2, x3, c0, c1, c2, c3, n, stream);

@@ -1272,18 +1272,13 @@ template int regrid_splat_lds<double>(double *, const double *, int64_t, const G
 
 }  // namespace lago
 
-extern "C" {
-// Tuning hook (bench / tests): tile TX, TY, TZ (0 = auto), window margins, threads per workgroup.
-// Affects speed only, never results.
-void lago_set_splat_mc(int on) { lago::g_splat_mc = on; }
-// sheared-window float32 splat: on/off, tile TX TY TZ (0 = auto), margins, threads per workgroup.  Speed only.
-void lago_set_splat_shear_mc(int mode) { lago::g_shear_mc = mode; }
-void lago_set_splat_shear(int on, int tx, int ty, int tz, int mx, int my, int mz, int nthreads) {
-    lago::g_shear_on = on;
-    lago::g_shear_cfg.set({tx, ty, tz, mx, my, mz});
-    lago::g_shear_nt = nthreads;
+namespace lago {
+void tune_splat(const int32_t *tile7, const int32_t *shear8, int shear_mc, int mc) {
+    g_tile_cfg.set({tile7[0], tile7[1], tile7[2], tile7[3], tile7[4], tile7[5], tile7[6]});
+    g_shear_on = shear8[0];
+    g_shear_cfg.set({shear8[1], shear8[2], shear8[3], shear8[4], shear8[5], shear8[6]});
+    g_shear_nt = shear8[7];
+    g_shear_mc = shear_mc;
+    g_splat_mc = mc;
 }
-void lago_set_splat_tile(int tx, int ty, int tz, int ex, int ey, int ez, int nthreads) {
-    lago::g_tile_cfg.set({tx, ty, tz, ex, ey, ez, nthreads});
-}
-}
+}  // namespace lago

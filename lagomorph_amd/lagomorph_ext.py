@@ -14,6 +14,7 @@ this module raises if the HIP library has not been built
 (``python -m lagomorph_amd.build`` / ``__graft_entry__.build()``).
 """
 import ctypes
+import threading
 import os
 
 import torch  # must be imported first: it loads the process's libamdhip64.so.7
@@ -21,7 +22,7 @@ import torch  # must be imported first: it loads the process's libamdhip64.so.7
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LAGO_HIP_LIBRARY selects another build of the same C ABI (tools/ use the -DLAGO_PROFILING build this way)
 LIB_PATH = os.environ.get("LAGO_HIP_LIBRARY") or os.path.join(_HERE, "_lib", "liblagomorph_hip.so")
-ABI_VERSION = 3  # LAGO_ABI_VERSION of include/lagomorph_hip.h this binding was written against
+ABI_VERSION = 4  # LAGO_ABI_VERSION of include/lagomorph_hip.h this binding was written against
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -79,14 +80,67 @@ for _name, _args in _SIGS.items():
         _f.restype = _int
         _fn[_name + _suf] = _f
 _lib.lago_set_debug.argtypes = [_int]
-_lib.lago_set_splat_mode.argtypes = [_int]
-_lib.lago_set_splat_tile.argtypes = [_int] * 7
-_lib.lago_set_vector_kernels.argtypes = [_int]
-_lib.lago_set_splat_shear.argtypes = [_int] * 8
-_lib.lago_set_fluid_xpass.argtypes = [_int]
-for _name in ("lago_set_launch_order", "lago_set_stencil_tile", "lago_set_gather_window", "lago_set_splat_mc", "lago_set_splat_shear_mc", "lago_set_fluid_xpass_ipw", "lago_set_fluid_zy_persist",
-              "lago_set_fluid_xpass_wide", "lago_set_fluid_xpass_persist"):
-    getattr(_lib, _name).argtypes = [_int]
+
+
+class LagoTuning(ctypes.Structure):
+    """include/lagomorph_hip.h: lago_tuning (field order and types as declared there)."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("splat_mode", ctypes.c_int32), ("splat_tile", ctypes.c_int32 * 7),
+                ("splat_shear", ctypes.c_int32 * 8), ("splat_shear_mc", ctypes.c_int32), ("splat_mc", ctypes.c_int32),
+                ("vector_kernels", ctypes.c_int32), ("launch_order", ctypes.c_int32), ("stencil_tile", ctypes.c_int32),
+                ("gather_window", ctypes.c_int32), ("fluid_mode", ctypes.c_int32), ("fluid_xpass_ipw", ctypes.c_int32),
+                ("fluid_zy_persist", ctypes.c_int32), ("fluid_xpass_wide", ctypes.c_int32),
+                ("fluid_xpass_persist", ctypes.c_int32)]
+
+
+_lib.lago_get_tuning.argtypes = [ctypes.POINTER(LagoTuning)]
+_lib.lago_get_tuning.restype = None
+_lib.lago_default_tuning.argtypes = [ctypes.POINTER(LagoTuning)]
+_lib.lago_default_tuning.restype = None
+_lib.lago_set_tuning.argtypes = [ctypes.POINTER(LagoTuning)]
+_lib.lago_set_tuning.restype = _int
+_tune_lock = threading.Lock()
+
+
+def _tuning_struct(getter):
+    t = LagoTuning()
+    t.struct_size = ctypes.sizeof(LagoTuning)
+    getter(ctypes.byref(t))
+    return t
+
+
+def _as_dict(t):
+    return {n: (list(getattr(t, n)) if hasattr(getattr(t, n), "__len__") else int(getattr(t, n)))
+            for n, _ in LagoTuning._fields_ if n != "struct_size"}
+
+
+def get_tuning():
+    """The tuning settings in force (include/lagomorph_hip.h: lago_tuning) as a dict."""
+    return _as_dict(_tuning_struct(_lib.lago_get_tuning))
+
+
+def default_tuning():
+    return _as_dict(_tuning_struct(_lib.lago_default_tuning))
+
+
+def tune(**fields):
+    """Change some tuning settings (process-wide, speed only): read the struct, replace the named fields, write it back.
+    tune(splat_shear_mc=1), tune(splat_shear=[1, 8, 6, 0, 1, 1, 4, 1024]), ...; tune(**default_tuning()) restores all."""
+    with _tune_lock:
+        t = _tuning_struct(_lib.lago_get_tuning)
+        for k, v in fields.items():
+            if k == "struct_size" or k not in dict(LagoTuning._fields_):
+                raise KeyError(f"lago_tuning has no field {k!r}")
+            cur = getattr(t, k)
+            if hasattr(cur, "__len__"):
+                v = [int(x) for x in v]
+                if len(v) != len(cur):
+                    raise ValueError(f"lago_tuning.{k} takes {len(cur)} values")
+                for i, x in enumerate(v):
+                    cur[i] = x
+            else:
+                setattr(t, k, int(v))
+        if _lib.lago_set_tuning(ctypes.byref(t)) != 0:
+            raise RuntimeError(_lib.lago_last_error().decode())
 
 
 def _suffix(t):
@@ -151,49 +205,47 @@ def set_debug_mode(mode):
 
 def set_splat_mode(mode):
     """0 = global atomics only, 1 = LDS-privatised splat (default)."""
-    _lib.lago_set_splat_mode(int(mode))
+    tune(splat_mode=mode)
 
 
 def set_splat_tile(tx, ty, tz, mx, my, mz, nthreads):
-    _lib.lago_set_splat_tile(int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
+    tune(splat_tile=[tx, ty, tz, mx, my, mz, nthreads])
 
 
 def set_splat_shear(on=1, tx=8, ty=6, tz=0, mx=1, my=1, mz=4, nthreads=1024):
     """Sheared-window float32 splat (csrc/splat.hip: splat_shear_kernel): on/off and its tile.  Speed only."""
-    _lib.lago_set_splat_shear(int(on), int(tx), int(ty), int(tz), int(mx), int(my), int(mz), int(nthreads))
+    tune(splat_shear=[on, tx, ty, tz, mx, my, mz, nthreads])
 
 
 def set_splat_mc(on):
     """General tiled splat: 1 (default) the multi-channel single-pass form where it applies.  Speed only."""
-    _lib.lago_set_splat_mc(1 if on else 0)
+    tune(splat_mc=1 if on else 0)
 
 
 def set_splat_shear_mc(mode):
     """Sheared-window splat, several channels with d_u: 2 (default) geometry and d_u sums in registers over the
     channels, 1 the d_u sums only, 0 neither.  Speed only (same d_u bits)."""
-    _lib.lago_set_splat_shear_mc(int(mode))
+    tune(splat_shear_mc=mode)
 
 
 def set_fluid_tuning(xpass_ipw=0, zy_persist=1, xpass_wide=1, xpass_persist=1):
     """FFT-pass fluid metric: batch items per x-pass workgroup (0 = by launch size), persistent zy kernels for
     planes above 80 KB, 512-thread x pass for the 256-point tile, persistent prefetching x-pass grid.  Speed only."""
-    _lib.lago_set_fluid_xpass_persist(int(xpass_persist))
-    _lib.lago_set_fluid_xpass_ipw(int(xpass_ipw))
-    _lib.lago_set_fluid_zy_persist(1 if zy_persist else 0)
-    _lib.lago_set_fluid_xpass_wide(1 if xpass_wide else 0)
+    tune(fluid_xpass_persist=xpass_persist, fluid_xpass_ipw=xpass_ipw, fluid_zy_persist=1 if zy_persist else 0,
+         fluid_xpass_wide=1 if xpass_wide else 0)
 
 
 def set_launch_order(alternate):
     """1 (default): successive launches walk their workgroups in alternating directions (a consumer starts on what
     its producer wrote last: Infinity-Cache reuse); 0: always ascending.  Speed only."""
-    _lib.lago_set_launch_order(1 if alternate else 0)
+    tune(launch_order=1 if alternate else 0)
 
 
 def set_stencil_tile(on):
     """1 (default): LDS row-tile stencil kernels (Ad_star, jacobian_times_vectorfield_backward) where shapes allow;
     0: the direct one-lane-per-voxel kernels; 3: row tiles without the compile-time-geometry instantiations for 128^3 /
     160^3 volumes.  Same bits."""
-    _lib.lago_set_stencil_tile(int(on))
+    tune(stencil_tile=on)
 
 
 _lib.lago_path_launches.restype = ctypes.c_longlong
@@ -212,7 +264,7 @@ def path_launches(name=None):
 def set_gather_window(on):
     """1 (default): float32 3D gathers through an LDS window (compose) where shapes allow; 0: pair gathers
     through the vector L1 only.  Same bits."""
-    _lib.lago_set_gather_window(1 if on else 0)
+    tune(gather_window=1 if on else 0)
 
 
 if os.environ.get("LAGO_GATHER_WINDOW") is not None:  # profiling convenience: A/B under rocprofv3 without code changes
@@ -222,13 +274,13 @@ if os.environ.get("LAGO_GATHER_WINDOW") is not None:  # profiling convenience: A
 
 def set_vector_kernels(on):
     """1 (default): slab-unrolled 3D gather kernels (two voxels per lane) where shapes allow; 0: one-voxel-per-lane kernels only."""
-    _lib.lago_set_vector_kernels(1 if on else 0)
+    tune(vector_kernels=1 if on else 0)
 
 
 def set_fluid_mode(mode):
     """fluid_metric implementation: 2 (default) three LDS-tiled FFT passes where the shape allows,
     1 rocFFT 2D plan + fused x pass, 0 rocFFT 3D plan + operator kernel."""
-    _lib.lago_set_fluid_xpass(int(mode))
+    tune(fluid_mode=mode)
 
 
 def version():

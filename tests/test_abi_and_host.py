@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35, names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/lagomorph_hip.h but not exported: {missing}"
-    assert lib.lago_abi_version() == lagomorph_amd.lagomorph_ext.ABI_VERSION == 3
+    assert lib.lago_abi_version() == lagomorph_amd.lagomorph_ext.ABI_VERSION == 4
     lib.lago_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.lago_version()
 
@@ -190,6 +190,12 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
         "    if (lago_abi_version() != LAGO_ABI_VERSION) return 1;\n"
         "    if (!lago_version() || !strlen(lago_version())) return 2;\n"
         "    lago_set_debug(1); if (lago_get_debug() != 1) return 3; lago_set_debug(0);\n"
+        "    { lago_tuning t, d; t.struct_size = sizeof t; d.struct_size = sizeof d; lago_get_tuning(&t); lago_default_tuning(&d);\n"
+        "      if (memcmp(&t, &d, sizeof t) || t.splat_shear[7] != 1024 || t.fluid_mode != 2) return 5;\n"
+        "      t.gather_window = 0; if (lago_set_tuning(&t) != LAGO_OK) return 6; lago_get_tuning(&d); if (d.gather_window != 0) return 7;\n"
+        "      t.struct_size = 6; if (lago_set_tuning(&t) != LAGO_ERR_INVALID) return 8;\n"
+        "      t.struct_size = 8; t.splat_mode = 0; t.gather_window = 1; if (lago_set_tuning(&t) != LAGO_OK) return 9;   /* an older, shorter struct */\n"
+        "      d.struct_size = sizeof d; lago_get_tuning(&d); if (d.splat_mode != 0 || d.gather_window != 0) return 10; }\n"
         "    /* argument validation happens before any HIP call */\n"
         "    if (lago_interp_forward_f32(0, 0, 0, 1.0, 5, 1, 1, 4, 4, 4, 0, 0) != LAGO_ERR_INVALID) return 4;\n"
         '    printf("%s\\n", lago_last_error());\n'
@@ -222,3 +228,30 @@ def test_builder_does_not_need_the_package():
             "print(lagomorph_amd._BUILDING, hasattr(lagomorph_amd, 'expmap'))")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
     assert r.returncode == 0 and r.stdout.split() == ["True", "False"], (r.stdout, r.stderr)
+
+
+def test_tuning_is_one_struct():
+    """include/lagomorph_hip.h: the sixteen per-experiment setters of rounds 1-3 are ONE struct now.
+    The Python shim reads, changes and writes it as a whole; unknown fields and wrong lengths are refused; the defaults
+    are what the library starts with."""
+    import lagomorph_amd.lagomorph_ext as ext
+
+    d = ext.default_tuning()
+    assert ext.get_tuning() == d
+    assert d["splat_shear"] == [1, 8, 6, 0, 1, 1, 4, 1024] and d["splat_tile"] == [0, 8, 0, 1, 1, 4, 512]
+    assert d["fluid_mode"] == 2 and d["splat_shear_mc"] == 2 and d["launch_order"] == 1
+    try:
+        ext.tune(gather_window=0, splat_shear=[1, 4, 8, 0, 2, 2, 8, 512])
+        t = ext.get_tuning()
+        assert t["gather_window"] == 0 and t["splat_shear"] == [1, 4, 8, 0, 2, 2, 8, 512]
+        assert {k: v for k, v in t.items() if k not in ("gather_window", "splat_shear")} == \
+               {k: v for k, v in d.items() if k not in ("gather_window", "splat_shear")}
+        ext.set_fluid_mode(0)   # the convenience wrappers go through the same struct
+        assert ext.get_tuning()["fluid_mode"] == 0
+        with pytest.raises(KeyError):
+            ext.tune(no_such_field=1)
+        with pytest.raises(ValueError):
+            ext.tune(splat_tile=[1, 2, 3])
+    finally:
+        ext.tune(**d)
+    assert ext.get_tuning() == d

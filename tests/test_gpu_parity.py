@@ -587,7 +587,7 @@ def test_fused_2d_fluid_metric(ext, sp, inverse):
 
 
 def test_launch_order_does_not_change_results(ext):
-    """`lago_set_launch_order`: walking the workgroups in alternating directions (Infinity-Cache reuse) is a pure
+    """`lago_tuning.launch_order`: walking the workgroups in alternating directions (Infinity-Cache reuse) is a pure
     re-ordering -- every non-atomic output is bit-identical under both settings, scatter-adds stay within the bound."""
     import lagomorph_amd as lm
 
@@ -740,11 +740,11 @@ def test_persistent_zy_passes_any_plane_count(ext, batch):
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     got = met.sharp(dev(m))
     assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "persistent zy passes vs oracle")
-    ext._lib.lago_set_fluid_zy_persist(0)
+    ext.tune(fluid_zy_persist=0)
     try:
         plain = met.sharp(dev(m))
     finally:
-        ext._lib.lago_set_fluid_zy_persist(1)
+        ext.tune(fluid_zy_persist=1)
     assert torch.equal(got, plain)
 
 
@@ -762,13 +762,13 @@ def test_persistent_x_pass_any_pair_count(ext, shape, batch, inverse):
     m = rnd(rng, (batch, 3) + shape, torch.float32)
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     op = met.sharp if inverse else met.flat
-    ext._lib.lago_set_fluid_xpass_persist(0)
+    ext.tune(fluid_xpass_persist=0)
     try:
         plain = op(dev(m))
-        ext._lib.lago_set_fluid_xpass_persist(2)
+        ext.tune(fluid_xpass_persist=2)
         got = [op(dev(m)) for _ in range(2)]   # two calls: both launch directions (common.hpp: next_direction)
     finally:
-        ext._lib.lago_set_fluid_xpass_persist(1)
+        ext.tune(fluid_xpass_persist=1)
     assert_close(got[0], orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse), torch.float32, "persistent x pass vs oracle")
     assert torch.equal(got[0], plain) and torch.equal(got[1], plain)
 

@@ -39,9 +39,9 @@ with torch.no_grad():
         print(f"native stage mask {mask}: sharp {timeit(lambda: met.sharp(m)):.3f} ms", flush=True)
     lib.lago_debug_fluid_stage_mask(7)
     for ipw in (1, 2, 4, 8):
-        lib.lago_set_fluid_xpass_ipw(ipw)
+        ext.tune(fluid_xpass_ipw=ipw)
         lib.lago_debug_fluid_stage_mask(2)
         a = timeit(lambda: met.sharp(m))
         lib.lago_debug_fluid_stage_mask(7)
         print(f"x pass, {ipw} batch items per workgroup: x pass alone {a:.3f} ms, sharp {timeit(lambda: met.sharp(m)):.3f} ms", flush=True)
-    lib.lago_set_fluid_xpass_ipw(2)
+    ext.tune(fluid_xpass_ipw=2)

@@ -16,10 +16,10 @@ for C in (2, 3):
     go = torch.randn((B, C, S, S, S), device=dev, generator=g)
     res = {}
     for mc in (0, 1):
-        ext._lib.lago_set_splat_mc(mc)
+        ext.tune(splat_mc=mc)
         t, _ = time_op(lambda: ext.interp_backward(go, I, u, 1.0, True, True), reps=10, warm=3)
         res[mc] = (t, ext.interp_backward(go, I, u, 1.0, True, True))
         print(f"C={C} multi-channel={mc}: {t*1e3:.1f} us", flush=True)
     print("   d_u identical:", torch.equal(res[0][1][1], res[1][1][1]),
           " d_I max diff / max:", float((res[0][1][0] - res[1][1][0]).abs().max() / res[0][1][0].abs().max()))
-ext._lib.lago_set_splat_mc(1)
+ext.tune(splat_mc=1)

@@ -54,18 +54,18 @@ for label, uu, dtt in (("rough", rough, 1.0), ("smooth dt=-0.2", u, -0.2), ("smo
     Ic = I if C == 1 else torch.randn((1 if "bc" in label else B, 3, S, S, S), device=dev, generator=g)
     gc = go if C == 1 else torch.randn((B, 3, S, S, S), device=dev, generator=g)
     ext.set_splat_shear(0)
-    ext._lib.lago_set_splat_mc(0)
+    ext.tune(splat_mc=0)
     a = ext.interp_backward(gc, Ic, uu, dtt, True, True)
     ta, _ = time_op(lambda: ext.interp_backward(gc, Ic, uu, dtt, True, True), reps=5, warm=1)
-    ext._lib.lago_set_splat_mc(1)
+    ext.tune(splat_mc=1)
     tm, _ = time_op(lambda: ext.interp_backward(gc, Ic, uu, dtt, True, True), reps=5, warm=1)
-    ext._lib.lago_set_splat_mc(0)
+    ext.tune(splat_mc=0)
     ext.set_splat_shear(1, **best)
-    ext._lib.lago_set_splat_shear_mc(0)
+    ext.tune(splat_shear_mc=0)
     tb0, _ = time_op(lambda: ext.interp_backward(gc, Ic, uu, dtt, True, True), reps=5, warm=1)
-    ext._lib.lago_set_splat_shear_mc(1)
+    ext.tune(splat_shear_mc=1)
     b = ext.interp_backward(gc, Ic, uu, dtt, True, True)
     tb, _ = time_op(lambda: ext.interp_backward(gc, Ic, uu, dtt, True, True), reps=5, warm=1)
-    ext._lib.lago_set_splat_mc(1)
+    ext.tune(splat_mc=1)
     print(f"{label}: general {ta*1e3:.1f} us (multi-channel form {tm*1e3:.1f}), sheared {tb*1e3:.1f} us (d_u per channel {tb0*1e3:.1f}), d_u bits {'ok' if torch.equal(a[1], b[1]) else 'DIFF'}, "
           f"d_I relerr {float((a[0]-b[0]).abs().max()/a[0].abs().max()):.1e}")
