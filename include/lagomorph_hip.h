@@ -134,6 +134,7 @@ int lago_set_tuning(const lago_tuning *t);
 #define LAGO_PATH_FLUID_2D 8       /* lago_fluid_metric: one fused 2D kernel */
 #define LAGO_PATH_FLUID_XPASS 9    /* lago_fluid_metric: rocFFT (y, z) plan + fused x pass */
 #define LAGO_PATH_FLUID_ROCFFT 10  /* lago_fluid_metric: rocFFT plan + operator kernel */
+#define LAGO_PATH_SPLAT_2D 11      /* LDS-privatised 2D splat (interp_backward of 2D fields) */
 long long lago_path_launches(int path);
 
 

@@ -310,6 +310,170 @@ __global__ __launch_bounds__(kBlock) void interp_bwd_kernel(R *__restrict__ d_I,
     }
 }
 
+// ------------------------------------------------------------------ backward, 2D, LDS-privatised
+//
+// interp_kernel_backward_2d (cuda/interp.cu:132-183 + atomicSplat include/interp.h:404-424): the reference's whole
+// test-suite and the 2D lagomorph.affine path splat with four global float atomics per pixel-channel, which the memory
+// side retires at 1.3 TB/s of added bytes.  Same scheme as the 3D kernels of splat.hip: a workgroup owns a TH x TW tile
+// of source pixels (lanes along the row), accumulates their four corner contributions in a float64 LDS window placed
+// at tile origin + the displacement probed at the tile centre - margin (its first column a multiple of 16: 64-byte
+// aligned flush rows), and flushes the window with one global atomic per touched cell.  Corners that miss the window
+// take the reference's clamped global atomics, so any displacement is handled.  d_u (biLerp_grad, include/interp.h:
+// 128-203) is produced by the same pass, accumulated per pixel in registers over the channels in ascending order:
+// bit-identical to interp_bwd_kernel.
+struct Splat2Geom {
+    int H, W;                 // image (= Geom::ny, nz)
+    int TH, TW, WH, WW, MH, MW;
+    uint32_t nth, ntw, tiles_per_item, total;
+    int rev;
+    FastDiv d_tiles, d_tw;
+};
+constexpr int kS2T = 256, kS2V = 4;   // threads per workgroup, pixels per thread (TH * TW = kS2T * kS2V, TW = 64)
+
+template <typename R, bool BC, bool NEED_U>
+__global__ __launch_bounds__(kS2T) void splat2d_lds_kernel(R *__restrict__ d_I, R *__restrict__ d_u, const R *__restrict__ go,
+                                                           const R *__restrict__ I, const R *__restrict__ u, double dt, int nc,
+                                                           Splat2Geom sg, int umode, R addgo) {
+    extern __shared__ __align__(16) unsigned char lago_s2[];
+    double *win = reinterpret_cast<double *>(lago_s2);
+    const int H = sg.H, W = sg.W;
+    const size_t nv = (size_t)H * W;
+    const uint32_t L = block_order(blockIdx.x, sg.total, sg.rev);
+    const uint32_t n = sg.d_tiles.div(L);
+    const uint32_t r = L - n * sg.tiles_per_item;
+    const uint32_t by = sg.d_tw.div(r), bx = r - by * sg.ntw;
+    const int y0 = (int)by * sg.TH, x0 = (int)bx * sg.TW;
+    const R *un = u + (size_t)n * 2 * nv;
+    const R *In = BC ? I : I + (size_t)n * nc * nv;
+    R *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
+    const R *gon = go + (size_t)n * nc * nv;
+    R *dun = NEED_U ? d_u + (size_t)n * 2 * nv : nullptr;
+    // window placement (speed only): the displacement of the tile's centre pixel
+    const int weh = min(sg.WH, H), wew = min(sg.WW, W);
+    int wy0, wx0;
+    {
+        const int cy = min(y0 + sg.TH / 2, H - 1), cx = min(x0 + sg.TW / 2, W - 1);
+        const float fdt = (float)dt;
+        const int oy = y0 + (int)floorf(fdt * (float)un[(size_t)cy * W + cx]) - sg.MH;
+        const int ox = x0 + (int)floorf(fdt * (float)un[nv + (size_t)cy * W + cx]) - sg.MW;
+        wy0 = max(0, min(oy, H - weh));
+        wx0 = max(0, min(ox & ~15, W - wew));
+    }
+    const int WWp = sg.WW;   // window row pitch (cells)
+    constexpr uint32_t NOWIN = 0xffffffffu;
+    // this thread's pixels: q = t + e * kS2T -> (row q / 64, column q % 64): a wave is one row piece (TW = 64)
+    bool live[kS2V];
+    size_t sv[kS2V];
+    Splat2<R> S[kS2V];
+    uint32_t wl[kS2V][4];   // window cell of every (clamped) corner, or NOWIN: the same for every channel
+    Lerp2<R> Lq[kS2V];
+    R ax[kS2V], ay[kS2V];
+#pragma unroll
+    for (int e = 0; e < kS2V; ++e) {
+        const int q = (int)threadIdx.x + e * kS2T;
+        const int pj = y0 + (q >> 6), pk = x0 + (q & 63);
+        live[e] = pj < H && pk < W;
+        sv[e] = live[e] ? (size_t)pj * W + pk : 0;
+        const R hx = sample_pos<R>(pj, dt, un[sv[e]]);
+        const R hy = sample_pos<R>(pk, dt, un[nv + sv[e]]);
+        S[e].setup(hx, hy, H, W);
+        {   // the corners' rows / columns again (Splat2 keeps the linear index only): same clamps, corner order a outer, b inner
+            const int fx = lg_floor(hx), fy = lg_floor(hy);
+            const uint32_t ly[2] = {(uint32_t)(clamp1(fx, H) - wy0), (uint32_t)(clamp1(fx + 1, H) - wy0)};
+            const uint32_t lx[2] = {(uint32_t)(clamp1(fy, W) - wx0), (uint32_t)(clamp1(fy + 1, W) - wx0)};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const uint32_t yy = ly[q4 >> 1], xx = lx[q4 & 1];
+                wl[e][q4] = (yy < (uint32_t)weh && xx < (uint32_t)wew) ? yy * (uint32_t)WWp + xx : NOWIN;
+            }
+        }
+        if (NEED_U) Lq[e].setup(hx, hy, H, W);
+        ax[e] = ay[e] = (R)0;
+        if (NEED_U && umode) {   // start of the thread-owned d_u sum: the caller's d_u, or addgo * grad_out[component]
+            ax[e] = umode == 1 ? dun[sv[e]] : addgo * gon[sv[e]];
+            ay[e] = umode == 1 ? dun[nv + sv[e]] : addgo * gon[nv + sv[e]];
+        }
+    }
+    for (int c = 0; c < nc; ++c) {
+        for (int f = threadIdx.x; f < sg.WH * WWp; f += kS2T) win[f] = 0.0;
+        __syncthreads();
+        R *dIc = dIn + (size_t)c * nv;
+        const R *gc = gon + (size_t)c * nv;
+#pragma unroll
+        for (int e = 0; e < kS2V; ++e) {
+            if (!live[e]) continue;
+            R diff = gc[sv[e]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const R w = S[e].w[q] * diff;                      // include/interp.h:404-424
+                if (wl[e][q] != NOWIN)
+                    __hip_atomic_fetch_add(win + wl[e][q], (double)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    atomic_add(dIc + S[e].o[q], w);
+            }
+            if (NEED_U) {
+                R gx, gy;
+                Lq[e].grad(In + (size_t)c * nv, gx, gy);
+                diff = (R)((double)diff * dt);  // cuda/interp.cu:171
+                ax[e] = lg_fma(gx, diff, ax[e]);
+                ay[e] = lg_fma(gy, diff, ay[e]);
+            }
+        }
+        __syncthreads();
+        // flush: one wave per window row, lanes along the row
+        {
+            const int lane = threadIdx.x & 63;
+            const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            for (int row = wave; row < weh; row += kS2T / 64) {
+                R *grow = dIc + (size_t)(wy0 + row) * W + wx0;
+                for (int col = lane; col < wew; col += 64) {
+                    const double acc = win[row * WWp + col];
+                    if (acc != 0.0) atomic_add(grow + col, (R)acc);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (NEED_U) {
+#pragma unroll
+        for (int e = 0; e < kS2V; ++e)
+            if (live[e]) {
+                dun[sv[e]] = ax[e];
+                dun[nv + sv[e]] = ay[e];
+            }
+    }
+}
+
+// returns false when the shape is left to the global-atomics kernel
+template <typename R>
+static bool interp_backward_2d_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, double dt, int nc, int64_t nn,
+                                   const Geom &g, bool bc, bool need_u, int umode, double addgo, hipStream_t s) {
+    if (g.ny < 16 || g.nz < 64 || (int64_t)g.ny * g.nz < 8192) return false;   // not worth a window
+    Splat2Geom sg;
+    sg.H = g.ny; sg.W = g.nz;
+    sg.TW = 64; sg.TH = kS2T * kS2V / 64;   // (the kernel's pixel mapping assumes 64-pixel tile rows)
+    sg.MH = 2; sg.MW = 4;
+    sg.WH = sg.TH + 1 + 2 * sg.MH;
+    sg.WW = ((sg.TW + 1 + 2 * sg.MW + 15 + 15) / 16) * 16;   // + 15: the first column is aligned down
+    sg.nth = (uint32_t)((g.ny + sg.TH - 1) / sg.TH);
+    sg.ntw = (uint32_t)((g.nz + sg.TW - 1) / sg.TW);
+    sg.tiles_per_item = sg.nth * sg.ntw;
+    const int64_t total = (int64_t)sg.tiles_per_item * nn;
+    if (total <= 0 || total >= (1ll << 31)) return false;
+    sg.total = (uint32_t)total;
+    sg.rev = g.rev;
+    sg.d_tiles = FastDiv(sg.tiles_per_item);
+    sg.d_tw = FastDiv(sg.ntw);
+    const size_t smem = (size_t)sg.WH * sg.WW * sizeof(double);
+#define LAGO_S2(B, NU) \
+    hipLaunchKernelGGL((splat2d_lds_kernel<R, B, NU>), dim3(sg.total), dim3(kS2T), smem, s, d_I, d_u, go, I, u, dt, nc, sg, umode, (R)addgo)
+    if (bc) { if (need_u) LAGO_S2(true, true); else LAGO_S2(true, false); }
+    else { if (need_u) LAGO_S2(false, true); else LAGO_S2(false, false); }
+#undef LAGO_S2
+    note_path(LP_SPLAT_2D);
+    return true;
+}
+
 // ------------------------------------------------------------------ Hessian diagonal (2D)
 
 template <typename R>
@@ -425,6 +589,9 @@ static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R
         int rc = interp_backward_lds<R>(d_I, d_u, go, I, u, dt, (int)nc, nn, g, bc != 0, need_u != 0, umode, addgo, s);
         if (rc != 1) return rc;  // 1 = shape not supported by the tiled kernel, fall through
     }
+    if (dim == 2 && need_I && g_splat_mode >= 1 &&
+        interp_backward_2d_lds<R>(d_I, d_u, go, I, u, dt, (int)nc, nn, g, bc != 0, need_u != 0, umode, addgo, s))
+        return finish_launch(s, "interp_backward");
     note_path(LP_SPLAT_GLOBAL);
     if (dim == 3) {
         if (bc) launch_bwd<R, 3, true>(d_I, d_u, go, I, u, dt, (int)nc, g, need_I, need_u, umode, addgo, s);

@@ -251,7 +251,7 @@ def set_stencil_tile(on):
 _lib.lago_path_launches.restype = ctypes.c_longlong
 _lib.lago_path_launches.argtypes = [_int]
 PATHS = ("gather_window", "stencil_tile", "vector_gather", "splat_shear", "splat_shear_mc", "splat_tiled", "splat_global",
-         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
+         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft", "splat_2d")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
 
 
 def path_launches(name=None):

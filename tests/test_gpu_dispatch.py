@@ -82,4 +82,7 @@ def test_float64_and_2d_take_the_general_kernels(lm):
     assert _delta(shim, lambda: shim.interp_backward(v, v, u, -0.1, True, True)) == {"splat_tiled": 1}
     u2, v2 = 0.5 * _fields(1, 2, (64, 64)), _fields(1, 2, (64, 64))
     assert _delta(shim, lambda: shim.compose(u2, v2, 1.0, -0.1)) == {}
-    assert _delta(shim, lambda: shim.interp_backward(v2, v2, u2, -0.1, True, True)) == {"splat_global": 1}
+    assert _delta(shim, lambda: shim.interp_backward(v2, v2, u2, -0.1, True, True)) == {"splat_global": 1}   # 4096 pixels: too few
+    u3, v3 = 0.5 * _fields(1, 2, (128, 128)), _fields(1, 2, (128, 128))
+    assert _delta(shim, lambda: shim.interp_backward(v3, v3, u3, -0.1, True, True)) == {"splat_2d": 1}
+    assert _delta(shim, lambda: shim.interp_backward(v3, v3, u3, -0.1, False, True)) == {"splat_global": 1}   # nothing to splat
