@@ -608,7 +608,27 @@ def main():
         torch.cuda.synchronize()
         t_general = (time.perf_counter() - tg0) / min(args.steps, 3)
         same_bits = bool(torch.equal(hg, h))
-        del h, hg, z
+        del hg, z
+        # untimed region as well: the headline shoot cut into two sub-batches on HIP streams of their own (an option of
+        # the product, off by default: lagomorph_amd.lddmm.EXPMAP_STREAMS, profiles/r04_stream_split.md)
+        from lagomorph_amd import lddmm as _lddmm
+        t_split, split_bits = None, None
+        if B >= 4:
+            _lddmm.EXPMAP_STREAMS = 2
+            try:
+                for _ in range(2):
+                    hs = step()
+                torch.cuda.synchronize()
+                ts0 = time.perf_counter()
+                for _ in range(min(args.steps, 5)):
+                    hs = step()
+                torch.cuda.synchronize()
+                t_split = (time.perf_counter() - ts0) / min(args.steps, 5)
+                split_bits = bool(torch.equal(hs, h))
+                del hs
+            finally:
+                _lddmm.EXPMAP_STREAMS = 1
+        del h
     elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -635,6 +655,8 @@ def main():
                         "first Euler step is evaluated in closed form (-dt sharp(m0): the bits EPDiff_step returns)",
             "all_steps_through_the_general_kernels": {"ms_per_step": 1e3 * t_general, "local_voxel_steps_per_s":
                                                       B * S ** 3 * E / t_general, "same_bits": same_bits},
+            "stream_split": None if t_split is None else {"parts": 2, "ms_per_step": 1e3 * t_split, "same_bits": split_bits,
+                                                           "note": "option lddmm.EXPMAP_STREAMS = 2; not the headline"},
             "global_batch": GBATCH, "per_gpu_batch": B, "volume": [S, S, S], "euler_steps": E,
             "parallelism": f"batch-sharded x{world}, no data-path collective in expmap; the atlas step "
                            "(atlas_step below) all-reduces the atlas gradient over RCCL",

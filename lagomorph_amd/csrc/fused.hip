@@ -8,6 +8,8 @@
 // reference formula with this library's interp.
 #include <algorithm>
 #include <type_traits>
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "stencil_tile.hpp"
 #include "gather_window.hpp"
@@ -225,6 +227,26 @@ template __global__ void compose3_window_kernel<GW::NT, 8, false>(float *, const
 std::atomic<int> g_gather_window{1};  // 1: LDS-window gathers where the shape allows (default); 0: pair gathers only
 std::atomic<int> g_tile_cube{1};      // 1: 128^3 / 160^3 volumes take the instantiations with compile-time geometry
 
+// EXPERIMENT (round 4; tools/ab_streams.py): LAGO_EXP_GATHER_PAD=<bytes> makes the gather kernels of
+// the Euler step ask for at least that much LDS, so that only one of their workgroups fits a CU and the FFT passes of
+// ANOTHER stream can co-reside.  Read once; not part of the ABI.  Speed only.
+static size_t exp_gather_pad() {
+    static const size_t pad = [] {
+        const char *e = getenv("LAGO_EXP_GATHER_PAD");
+        return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)0;
+    }();
+    return pad;
+}
+template <typename K>
+static size_t padded_smem(K k, size_t smem) {
+    const size_t pad = exp_gather_pad();
+    if (pad > smem) {
+        smem = pad;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    }
+    return smem;
+}
+
 template <typename R>
 static bool compose_window_launch(R *out, const R *u, const R *v, double ds, double dt, const Geom &g, int64_t nn,
                                   hipStream_t s) {
@@ -236,9 +258,9 @@ static bool compose_window_launch(R *out, const R *u, const R *v, double ds, dou
         // (compiling the geometry of 128^3 / 160^3 volumes in, as ad_star3_tile_kernel does, costs this kernel 2-15
         // spilled registers at its 128: not done)
         if (unit_dt<R>(ds))
-            hipLaunchKernelGGL((compose3_window_kernel<NT, U, true>), dim3(w.total), dim3(NT), smem, s, out, u, v, ds, dt, g, w);
+            hipLaunchKernelGGL((compose3_window_kernel<NT, U, true>), dim3(w.total), dim3(NT), padded_smem(compose3_window_kernel<NT, U, true>, smem), s, out, u, v, ds, dt, g, w);
         else
-            hipLaunchKernelGGL((compose3_window_kernel<NT, U, false>), dim3(w.total), dim3(NT), smem, s, out, u, v, ds, dt, g, w);
+            hipLaunchKernelGGL((compose3_window_kernel<NT, U, false>), dim3(w.total), dim3(NT), padded_smem(compose3_window_kernel<NT, U, false>, smem), s, out, u, v, ds, dt, g, w);
         note_path(LP_GATHER_WINDOW);
         return true;
     }
@@ -573,7 +595,7 @@ static bool ad_star_tile_launch(R *out, R *mphi, const R *phi, const R *m, const
         // the two benchmark volumes with their geometry compiled in
         const bool cube = g.nx == g.ny && g.ny == g.nz && t.TX == 2 && g_tile_cube;
         if (cube && g.nz == 128 && t.TY == 4) {
-            hipLaunchKernelGGL((ad_star3_tile_kernel<R, NT, U, RI, 2, 128>), dim3(t.total), dim3(NT), smem, s, out, mphi, phi, m, g, t);
+            hipLaunchKernelGGL((ad_star3_tile_kernel<R, NT, U, RI, 2, 128>), dim3(t.total), dim3(NT), padded_smem(ad_star3_tile_kernel<R, NT, U, RI, 2, 128>, smem), s, out, mphi, phi, m, g, t);
             note_path(LP_STENCIL_TILE);
             return true;
         }

@@ -549,9 +549,10 @@ def affine_interp_backward(grad_out, I, A, T, need_I, need_A, need_T):
     return [d_I, d_A, d_T]
 
 
-def compose(u, v, ds=1.0, dt=1.0):
+def compose(u, v, ds=1.0, dt=1.0, out=None):
     """Fused deform.compose (deform.py:53-55): ds*u + dt*interp(v, u, dt=ds) in one kernel.
-    Not part of the reference's extension surface; u and v are (N, d, *spatial) vector fields."""
+    Not part of the reference's extension surface; u and v are (N, d, *spatial) vector fields.  `out`: a contiguous
+    tensor of their shape to write into (it must not alias u or v)."""
     _check_input(u, "u")
     _check_input(v, "v")
     _same(u, v)
@@ -560,7 +561,13 @@ def compose(u, v, ds=1.0, dt=1.0):
         raise RuntimeError("Only two- and three-dimensional interpolation is supported")
     if u.shape != v.shape or u.size(1) != dim:
         raise RuntimeError("compose: u and v must be vector fields of the same shape")
-    out = torch.empty_like(u)
+    if out is None:
+        out = torch.empty_like(u)
+    else:
+        _check_input(out, "out")
+        _same(u, out)
+        if out.shape != u.shape or out.data_ptr() in (u.data_ptr(), v.data_ptr()):
+            raise RuntimeError("compose: out must have the shape of u and must not alias an input")
     _call("lago_compose", u, _ptr(out), _ptr(u), _ptr(v), float(ds), float(dt), dim, u.size(0), nx, ny, nz)
     return out
 

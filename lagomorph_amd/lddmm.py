@@ -93,24 +93,73 @@ class ExpmapFunction(torch.autograd.Function):
                 d_v0 if (need_v0 and ctx.has_v0) else None)
 
 
-def _shoot(metric, m0, phiinv, dt, num_steps, v0, keep):
+def _shoot(metric, m0, phiinv, dt, num_steps, v0, keep, out=None):
     """The Euler loop of `expmap` through the fused kernels.  Returns (phi, steps, first): steps = per general step
-    (phi_k, v_k, m0 o (id + phi_k)) when `keep`, first = the first step was taken in closed form (`_first_step`)."""
+    (phi_k, v_k, m0 o (id + phi_k)) when `keep`, first = the first step was taken in closed form (`_first_step`).
+    `out`: where the final displacement is to be written (a contiguous tensor of m0's shape)."""
     steps = []
     first = phiinv is None   # shooting from the identity
     phi = _first_step(metric, m0, dt, v0) if first else phiinv.contiguous()
-    for _ in range(num_steps - 1 if first else num_steps):
+    general = num_steps - 1 if first else num_steps
+    for k in range(general):
         if keep:
             m, mphi = lagomorph_ext.Ad_star(phi, m0, save_resampled=True)
         else:
             m, mphi = lagomorph_ext.Ad_star(phi, m0), None
         v = metric.sharp(m)
         del m
-        nxt = lagomorph_ext.compose(v, phi, -dt, 1.0)
+        nxt = lagomorph_ext.compose(v, phi, -dt, 1.0, out=out if k + 1 == general else None)
         if keep:
             steps.append((phi, v, mphi))
         phi = nxt
+    if out is not None and general == 0:
+        out.copy_(phi)
+        phi = out
     return phi, steps, first
+
+
+# A forward-only shoot (no gradient wanted) of at least 2 * EXPMAP_STREAMS batch items can be cut into EXPMAP_STREAMS
+# contiguous sub-batches that run on HIP streams of their own: batch items are independent, and the tail of one part's
+# kernel (the last workgroups of a launch leave most CUs idle) then overlaps with the head of another part's next
+# kernel.  Measured (tools/ab_streams.py, round 4, profiles/r04_stream_split.md): 22.28 -> 21.66 ms at 32 x 128^3,
+# 5.84 -> 5.55 at 8 x 128^3, same bits; capping the gather kernels to one workgroup per CU so that the other part's
+# FFT passes co-reside (VERDICT r3 item 2) costs 30 %.  OFF by default (1): with two parts in flight a kernel's launch
+# duration is no longer the time it needs by itself, and the benchmark's per-kernel roofline is measured on the
+# default path; `lagomorph_amd.lddmm.EXPMAP_STREAMS = 2` switches it on (bench.py reports it beside the headline).
+EXPMAP_STREAMS = 1
+_side_streams = {}
+
+
+def _streams_for(device, n):
+    pool = _side_streams.setdefault(device, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def _shoot_forward_split(metric, m0, phiinv, dt, num_steps, v0):
+    """`_shoot(..., keep=False)` over sub-batches on side streams; None when the split does not apply."""
+    parts = EXPMAP_STREAMS
+    B = m0.size(0)
+    if parts < 2 or B < 2 * parts or not m0.is_cuda or num_steps < 2:
+        return None
+    m0 = m0.contiguous()
+    phiinv = None if phiinv is None else phiinv.contiguous()
+    v0 = None if v0 is None else v0.contiguous()
+    out = torch.empty_like(m0)
+    main = torch.cuda.current_stream(m0.device)
+    streams = _streams_for(m0.device, parts)
+    bounds = [B * i // parts for i in range(parts + 1)]
+    metric.initialize_luts(shape=m0.shape, dtype=m0.dtype, device=m0.device)   # (made once, on the main stream)
+    for i, s in enumerate(streams):
+        s.wait_stream(main)   # the inputs (and `out`'s memory) are the main stream's
+        sl = slice(bounds[i], bounds[i + 1])
+        with torch.cuda.stream(s):
+            _shoot(metric, m0[sl], None if phiinv is None else phiinv[sl], dt, num_steps, None if v0 is None else v0[sl],
+                   False, out=out[sl])
+    for s in streams:
+        main.wait_stream(s)
+    return out
 
 
 def _shoot_reverse(metric, m0, dt, steps, G):
@@ -149,6 +198,15 @@ def _fused_expmap_ok(metric, m0, phiinv, mommask, v0):
             and torch.is_grad_enabled() and grads)
 
 
+def _forward_split_ok(metric, m0, phiinv, mommask, v0):
+    grads = torch.is_grad_enabled() and (m0.requires_grad or (phiinv is not None and phiinv.requires_grad)
+                                          or (v0 is not None and v0.requires_grad))
+    return (USE_FUSED_EXPMAP and not grads and mommask is None and isinstance(metric, FluidMetric) and m0.is_cuda
+            and m0.size(1) == m0.dim() - 2 and m0.dtype in (torch.float32, torch.float64)
+            and (phiinv is None or (phiinv.shape == m0.shape and phiinv.dtype == m0.dtype))
+            and all(hasattr(lagomorph_ext, n) for n in ("Ad_star", "compose")))
+
+
 def expmap(metric, m0, T=1.0, num_steps=10, phiinv=None, mommask=None, checkpoints=False, v0=None):
     """Exponential map: returns the displacement of phi^-1 (lddmm.py:73-105).
 
@@ -170,6 +228,11 @@ def expmap(metric, m0, T=1.0, num_steps=10, phiinv=None, mommask=None, checkpoin
         v0 = None
     if _fused_expmap_ok(metric, m0, phiinv, mommask, v0):
         return ExpmapFunction.apply(metric, m0, phiinv, dt, num_steps, v0)
+    if _forward_split_ok(metric, m0, phiinv, mommask, v0):
+        with torch.no_grad():
+            h = _shoot_forward_split(metric, m0, phiinv, dt, num_steps, v0)
+        if h is not None:
+            return h
     first = phiinv is None
     if first:
         phiinv = _first_step(metric, m0, dt, v0, mommask)
