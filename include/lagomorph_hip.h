@@ -194,7 +194,16 @@ long long lago_path_launches(int path);
     /* regrid_backward (cuda/affine.cu:802-855): splat grad_out (nn, nc, Nx, Ny, Nz) back onto (nx, ny, nz). */     \
     int lago_regrid_backward##SUF(REAL *d_I, const REAL *grad_out, int dim, int64_t nn, int64_t nc, int64_t nx,     \
                                   int64_t ny, int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz,                       \
-                                  const double *origin, const double *spacing, void *stream);
+                                  const double *origin, const double *spacing, void *stream);                       \
+    /* the same operator applied axis by axis in gather form (positive spacings): no atomics, d_I need not be       \
+     * initialised, results independent of the launch; only the association of the weight products differs from     \
+     * the reference's (wz (wy (wx m)) against wx wy wz m).  ws: two temporaries of ws_elems / 2 elements each,     \
+     * ws_elems >= 2 nn nc max(nx Ny Nz, nx ny Nz) (3D; 2D: >= 2 nn nc nx Ny with (nx, ny) the 2D extents; may be   \
+     * null when ws_elems == 0 suffices).  Not in the reference's extension surface. */                             \
+    int lago_regrid_backward_sep##SUF(REAL *d_I, const REAL *grad_out, REAL *ws, int64_t ws_elems, int dim,         \
+                                      int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int64_t Nx,       \
+                                      int64_t Ny, int64_t Nz, const double *origin, const double *spacing,          \
+                                      void *stream);
 
 LAGO_DECLARE(float, _f32)
 LAGO_DECLARE(double, _f64)

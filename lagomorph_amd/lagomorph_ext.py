@@ -14,6 +14,7 @@ this module raises if the HIP library has not been built
 (``python -m lagomorph_amd.build`` / ``__graft_entry__.build()``).
 """
 import ctypes
+import math
 import threading
 import os
 
@@ -59,6 +60,7 @@ _SIGS = {
     "lago_affine_interp_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _int, _int,
                                     _int, _int, _vp],
     "lago_regrid_forward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
+    "lago_regrid_backward_sep": [_vp, _vp, _vp, _i64, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_regrid_backward": [_vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "lago_compose": [_vp, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_lincomb": [_vp, _int, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i64, _vp],
@@ -701,6 +703,11 @@ def regrid_forward(I, shape, origin, spacing):
     return out
 
 
+# 1 (default): regrid_backward runs axis by axis in gather form (lago_regrid_backward_sep: no atomics, no memset, results
+# independent of the launch); 0: the reference's splat (LDS-privatised / global atomics by lago_tuning.splat_mode)
+REGRID_BACKWARD_SEPARABLE = 1
+
+
 def regrid_backward(grad_out, inshape, shape, origin, spacing):
     """cuda/affine.cu:802-855"""
     _check_input(grad_out, "grad_out")
@@ -717,6 +724,18 @@ def regrid_backward(grad_out, inshape, shape, origin, spacing):
     n3 = inshape + [1] * (3 - dim)
     N = shape + [1] * (3 - dim)
     d_I = torch.empty(tuple(grad_out.shape[:2]) + tuple(inshape), dtype=grad_out.dtype, device=grad_out.device)
+    if REGRID_BACKWARD_SEPARABLE and all(S[d] > 0 for d in range(dim)) and d_I.numel() and grad_out.numel():
+        # axis by axis in gather form (no atomics, deterministic): two temporaries, each as large as the biggest
+        # intermediate (the axes go from grad_out's extents to d_I's one at a time, slowest axis first)
+        planes = grad_out.size(0) * grad_out.size(1)
+        cur, half = list(shape), 0
+        for a in range(dim - 1):
+            cur[a] = inshape[a]
+            half = max(half, planes * math.prod(cur))
+        ws = torch.empty((2 * half,), dtype=grad_out.dtype, device=grad_out.device) if half else None
+        _call("lago_regrid_backward_sep", grad_out, _ptr(d_I), _ptr(grad_out), _ptr(ws), 2 * half, dim, grad_out.size(0),
+              grad_out.size(1), n3[0], n3[1], n3[2], N[0], N[1], N[2], O, S)
+        return d_I
     _call("lago_regrid_backward", grad_out, _ptr(d_I), _ptr(grad_out), dim, grad_out.size(0), grad_out.size(1), n3[0],
           n3[1], n3[2], N[0], N[1], N[2], O, S)
     return d_I

@@ -861,19 +861,30 @@ def test_affine_backward_tiled_splat(ext, dtype, kind, bc):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp,out,scale", [((20, 12, 40), (40, 24, 80), 1.0), ((40, 24, 80), (20, 12, 40), 1.0),
                                           ((33, 17, 65), (33, 17, 65), 1.0), ((16, 16, 16), (24, 20, 90), -0.8),
-                                          ((12, 10, 14), (30, 22, 66), 7.0)])
-def test_regrid_backward_tiled_splat(ext, dtype, sp, out, scale):
+                                          ((12, 10, 14), (30, 22, 66), 7.0), ((12, 10, 14), (30, 22, 66), 0.05),
+                                          ((1, 2, 3), (5, 4, 7), 1.0), ((48, 40), (96, 100), 1.0), ((64, 50), (20, 30), 2.5),
+                                          ((64, 64, 64), (128, 128, 128), 1.0)])
+def test_regrid_backward_every_form(ext, dtype, sp, out, scale):
     rng = np.random.default_rng(78)
     origin = [(s - 1) * 0.5 - 0.2 for s in sp]
     spacing = [scale * (a - 1) / (b - 1) for a, b in zip(sp, out)]
     go = rnd(rng, (2, 3) + out, dtype)
     want = orc.regrid_backward(go, sp, out, origin, spacing)
-    assert_close(ext.regrid_backward(dev(go), sp, out, origin, spacing), want, dtype, "regrid backward (tiled)")
-    ext.set_splat_mode(0)
+    # default: axis by axis in gather form (positive spacings; round 4) -- no atomics: two runs give the same bits
+    sep = ext.regrid_backward(dev(go), sp, out, origin, spacing)
+    assert_close(sep, want, dtype, "regrid backward (separable)")
+    if all(x > 0 for x in spacing):   # (non-positive spacings stay on the splat: atomics)
+        assert torch.equal(sep, ext.regrid_backward(dev(go), sp, out, origin, spacing))
+    ext.REGRID_BACKWARD_SEPARABLE = 0
     try:
-        got0 = ext.regrid_backward(dev(go), sp, out, origin, spacing)
+        assert_close(ext.regrid_backward(dev(go), sp, out, origin, spacing), want, dtype, "regrid backward (tiled)")
+        ext.set_splat_mode(0)
+        try:
+            got0 = ext.regrid_backward(dev(go), sp, out, origin, spacing)
+        finally:
+            ext.set_splat_mode(1)
     finally:
-        ext.set_splat_mode(1)
+        ext.REGRID_BACKWARD_SEPARABLE = 1
     assert_close(got0, want, dtype, "regrid backward (global atomics)")
 
 
