@@ -114,6 +114,10 @@ typedef struct lago_tuning {
     /* x pass as a persistent grid of two workgroups per CU that prefetch their next tile (default 1: taken when the
      * launch has at least four (bin tile, batch item) pairs per workgroup; 2: always; 0: never).  Same bits */
     int32_t fluid_xpass_persist;
+    /* affine_interp_backward (3D), the image splat: 1 (default) by target boxes for batch items whose matrix is
+     * invertible with a moderate inverse (decided per item on the device), the general tiled LDS splat for the others;
+     * 0: the general tiled splat for every item.  d_I differs by the order of its sums */
+    int32_t affine_box;
 } lago_tuning;
 /* the settings in force / the library's defaults: fills t->struct_size bytes (struct_size set by the caller) */
 void lago_get_tuning(lago_tuning *t);
@@ -135,6 +139,7 @@ int lago_set_tuning(const lago_tuning *t);
 #define LAGO_PATH_FLUID_XPASS 9    /* lago_fluid_metric: rocFFT (y, z) plan + fused x pass */
 #define LAGO_PATH_FLUID_ROCFFT 10  /* lago_fluid_metric: rocFFT plan + operator kernel */
 #define LAGO_PATH_SPLAT_2D 11      /* LDS-privatised 2D splat (interp_backward of 2D fields) */
+#define LAGO_PATH_SPLAT_AFFINE_BOX 12 /* affine_interp_backward's image splat by target boxes */
 long long lago_path_launches(int path);
 
 

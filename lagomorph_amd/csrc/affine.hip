@@ -20,7 +20,7 @@ namespace lago {
 // splat.hip
 template <typename R>
 int affine_splat_lds(R *d_I, const R *go, const R *A, const R *T, int nc, int64_t nn, const Geom &g, bool bc,
-                     hipStream_t s);
+                     hipStream_t s, int gate);
 template <typename R>
 int regrid_splat_lds(R *d_I, const R *go, int64_t nplanes, const Geom &g, const Geom &gs, const double *O,
                      const double *S, hipStream_t s);
@@ -178,6 +178,195 @@ __global__ __launch_bounds__(kBlock) void affine_bwd_kernel(R *__restrict__ d_I,
             }
         }
     }
+}
+
+std::atomic<int> g_affine_box{1};   // 1: affine_interp_backward's image splat by target boxes where the matrix allows
+void tune_affine(int box) { g_affine_box = box ? 1 : 0; }
+
+// ------------------------------------------------------------------ affine backward: image splat by TARGET boxes
+//
+// The sheared windows of the displacement splat do not carry over to an affine map (a 15 degree rotation moves a tile's
+// footprint by four cells across a 16-cell z segment), and the general tiled kernel (splat.hip) covers a rotated tile
+// with its bounding box: 270 of the 350 us of affine_interp_backward at 8 x 128^3.  For an affine map the roles can be
+// turned round exactly: a workgroup OWNS a box of target cells and processes precisely the source voxels whose
+// clamped floor cell lies in it -- a partition of the sources, decided with the reference's own position expression
+// (cuda/affine.cu:42-61), so every contribution is made once.  Their eight cells are the box plus one layer on its
+// upper faces: the LDS window is (BX + 1)(BY + 1)(BZ + 1) cells, nothing ever misses it, and the flush touches 1.3
+// cells per voxel instead of the bounding box of a sheared tile.  Candidates: the source voxels in the bounding box of
+// the box's PREIMAGE (the inverse matrix in double, one voxel of slack for the rounding of h; border boxes own
+// everything clamped onto them and reach out to the image of the source grid's corners).  Matrices whose inverse would
+// make that candidate set large (or that have none) are left, per batch item and decided on the device, to the general
+// kernel (common.hpp: affine_item_regular).  d_I as always: float64 sums per window, one float atomic per touched cell.
+struct BoxGeom {
+    int nx, ny, nz, BX, BY, BZ;
+    uint32_t nbx, nby, nbz, per_item, total;
+    int rev;
+    FastDiv d_item, d_yz, d_z, d_wyz, d_wz;
+};
+
+template <typename R, bool BC>
+__global__ __launch_bounds__(kBlock) void affine_splat_box_kernel(R *__restrict__ d_I, const R *__restrict__ go,
+                                                                  const R *__restrict__ A, const R *__restrict__ T, int nc,
+                                                                  BoxGeom bg) {
+    extern __shared__ __align__(16) unsigned char lago_bx[];
+    double *win = reinterpret_cast<double *>(lago_bx);
+    const int nx = bg.nx, ny = bg.ny, nz = bg.nz;
+    const size_t nv = (size_t)nx * ny * nz;
+    const uint32_t L = block_order(blockIdx.x, bg.total, bg.rev);
+    const uint32_t n = bg.d_item.div(L);
+    uint32_t r = L - n * bg.per_item;
+    const uint32_t bx = bg.d_yz.div(r);
+    r -= bx * (bg.nby * bg.nbz);
+    const uint32_t by = bg.d_z.div(r), bz = r - by * bg.nbz;
+    const int X0 = (int)bx * bg.BX, Y0 = (int)by * bg.BY, Z0 = (int)bz * bg.BZ;
+    const int ex = min(bg.BX, nx - X0), ey = min(bg.BY, ny - Y0), ez = min(bg.BZ, nz - Z0);
+    const R *An = A + (size_t)n * 9, *Tn = T + (size_t)n * 3;
+    double Ai[9];
+    if (!affine_item_regular<R>(An, Ai)) return;   // this item is the general kernel's
+    const R ox = half_extent<R>(nx), oy = half_extent<R>(ny), oz = half_extent<R>(nz);
+    const double od[3] = {(double)ox, (double)oy, (double)oz};
+    const double Td[3] = {(double)Tn[0], (double)Tn[1], (double)Tn[2]};
+    // the box in position space: [lo, hi) per axis; a border box owns everything clamped onto it, i.e. it reaches to
+    // the image of the source grid (its eight corners) on that side
+    double lo[3] = {(double)X0, (double)Y0, (double)Z0}, hi[3] = {(double)(X0 + ex), (double)(Y0 + ey), (double)(Z0 + ez)};
+    {
+        double hmin[3] = {1e300, 1e300, 1e300}, hmax[3] = {-1e300, -1e300, -1e300};
+        const int ext[3] = {nx, ny, nz};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double f[3] = {((q & 4) ? ext[0] - 1 : 0) - od[0], ((q & 2) ? ext[1] - 1 : 0) - od[1], ((q & 1) ? ext[2] - 1 : 0) - od[2]};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double h = (double)An[3 * d] * f[0] + (double)An[3 * d + 1] * f[1] + (double)An[3 * d + 2] * f[2] + Td[d] + od[d];
+                hmin[d] = h < hmin[d] ? h : hmin[d];
+                hmax[d] = h > hmax[d] ? h : hmax[d];
+            }
+        }
+        const int org[3] = {X0, Y0, Z0}, len[3] = {ex, ey, ez};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (org[d] == 0) lo[d] = fmin(lo[d], hmin[d] - 2.0);
+            if (org[d] + len[d] == ext[d]) hi[d] = fmax(hi[d], hmax[d] + 2.0);
+        }
+    }
+    // candidate sources: bounding box of the preimage of [lo, hi), one voxel of slack, inside the grid
+    int s0[3], s1[3];
+    {
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double h[3] = {((q & 4) ? hi[0] : lo[0]) - Td[0] - od[0], ((q & 2) ? hi[1] : lo[1]) - Td[1] - od[1],
+                                 ((q & 1) ? hi[2] : lo[2]) - Td[2] - od[2]};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double x = Ai[3 * d] * h[0] + Ai[3 * d + 1] * h[1] + Ai[3 * d + 2] * h[2] + od[d];
+                mn[d] = x < mn[d] ? x : mn[d];
+                mx[d] = x > mx[d] ? x : mx[d];
+            }
+        }
+        const int ext[3] = {nx, ny, nz};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            s0[d] = max(0, (int)floor(fmax(mn[d], -1e9)) - 1);
+            s1[d] = min(ext[d] - 1, (int)ceil(fmin(mx[d], 1e9)) + 1);
+        }
+    }
+    const int WY = bg.BY + 1, WZ = bg.BZ + 1;
+    const int wcells = (bg.BX + 1) * WY * WZ;
+    for (int f = threadIdx.x; f < wcells; f += kBlock) win[f] = 0.0;
+    __syncthreads();
+    const int cy = s1[1] - s0[1] + 1, cz = s1[2] - s0[2] + 1;
+    const int rows = s1[0] >= s0[0] && cy > 0 && cz > 0 ? (s1[0] - s0[0] + 1) * cy : 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const R *gon = go + (size_t)n * nc * nv;
+    R *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
+    for (int c = 0; c < nc; ++c) {
+        const R *gc = gon + (size_t)c * nv;
+        // one wave per candidate row (i, j), lanes along z.  (Requesting the next row's grad_out values ahead of the
+        // ownership test -- software pipelining over the ~25 rows a wave walks -- measured 15 % SLOWER: it loads the
+        // candidates that are not owned as well.)
+        for (int row = wave; row < rows; row += kBlock / 64) {
+            const int i = s0[0] + row / cy, j = s0[1] + row % cy;   // (scalar)
+            const R fi = (R)i - ox, fj = (R)j - oy;
+            for (int k = s0[2] + lane; k <= s1[2]; k += 64) {
+                const R fk = (R)k - oz;
+                // cuda/affine.cu:42-61 (as affine_bwd_kernel above)
+                const R hx = lg_fma(An[2], fk, lg_fma(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+                const R hy = lg_fma(An[5], fk, lg_fma(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+                const R hz = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
+                const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
+                const int gx0 = clamp1(fx, nx), gy0 = clamp1(fy, ny), gz0 = clamp1(fz, nz);
+                const uint32_t lx = (uint32_t)(gx0 - X0), ly = (uint32_t)(gy0 - Y0), lz = (uint32_t)(gz0 - Z0);
+                if (lx >= (uint32_t)ex || ly >= (uint32_t)ey || lz >= (uint32_t)ez) continue;   // another box owns it
+                const R diff = gc[((size_t)i * ny + j) * nz + k];
+                const uint32_t lx1 = (uint32_t)(clamp1(fx + 1, nx) - X0), ly1 = (uint32_t)(clamp1(fy + 1, ny) - Y0),
+                               lz1 = (uint32_t)(clamp1(fz + 1, nz) - Z0);
+                const uint32_t cxs[2] = {lx, lx1}, cys[2] = {ly, ly1}, czs[2] = {lz, lz1};
+                // sequentially flipped weights (include/interp.h:431-453): x outer, y, z inner
+                R ddx = (R)1.f - (hx - (R)fx), ddy = (R)1.f - (hy - (R)fy), ddz = (R)1.f - (hz - (R)fz);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const R w = (ddx * ddy * ddz) * diff;
+                    __hip_atomic_fetch_add(win + ((cxs[q >> 2] * (uint32_t)WY + cys[(q >> 1) & 1]) * (uint32_t)WZ + czs[q & 1]),
+                                           (double)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ddz = (R)1.f - ddz;
+                    if (q & 1) ddy = (R)1.f - ddy;
+                    if ((q & 3) == 3) ddx = (R)1.f - ddx;
+                }
+            }
+        }
+        __syncthreads();
+        // flush: one wave per window row (lx, ly), lanes along z; re-zero for the next channel
+        R *dIc = dIn + (size_t)c * nv;
+        const int fx_n = min(ex + 1, nx - X0), fy_n = min(ey + 1, ny - Y0), fz_n = min(ez + 1, nz - Z0);
+        for (int row = wave; row < fx_n * fy_n; row += kBlock / 64) {
+            const int lx = row / fy_n, ly = row % fy_n;
+            double *wrow = win + (lx * WY + ly) * WZ;
+            R *grow = dIc + ((size_t)(X0 + lx) * ny + (Y0 + ly)) * nz + Z0;
+            for (int lz = lane; lz < fz_n; lz += 64) {
+                const double acc = wrow[lz];
+                if (acc != 0.0) {
+                    wrow[lz] = 0.0;
+                    atomic_add(grow + lz, (R)acc);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Launches the box kernel for the regular batch items and the general kernel, gated, for the others.  Returns 0 when the
+// image splat is done, 1 when the shape is left to the plain kernel, < 0 on failure.
+template <typename R>
+static int affine_splat_boxes(R *d_I, const R *go, const R *A, const R *T, int nc, int64_t nn, const Geom &g, bool bc,
+                              hipStream_t s) {
+    if (g.nz < 16 || g.nx < 2 || g.ny < 2) return 1;
+    BoxGeom bg;
+    bg.nx = g.nx; bg.ny = g.ny; bg.nz = g.nz;
+    bg.BX = g.nx < 8 ? g.nx : 8;
+    bg.BY = g.ny < 8 ? g.ny : 8;
+    bg.BZ = g.nz < 48 ? g.nz : 48;
+    bg.nbx = (uint32_t)((g.nx + bg.BX - 1) / bg.BX);
+    bg.nby = (uint32_t)((g.ny + bg.BY - 1) / bg.BY);
+    bg.nbz = (uint32_t)((g.nz + bg.BZ - 1) / bg.BZ);
+    bg.per_item = bg.nbx * bg.nby * bg.nbz;
+    const int64_t total = (int64_t)bg.per_item * nn;
+    if (total <= 0 || total >= (1ll << 31)) return 1;
+    bg.total = (uint32_t)total;
+    bg.rev = g.rev;
+    bg.d_item = FastDiv(bg.per_item);
+    bg.d_yz = FastDiv(bg.nby * bg.nbz);
+    bg.d_z = FastDiv(bg.nbz);
+    const size_t smem = (size_t)(bg.BX + 1) * (bg.BY + 1) * (bg.BZ + 1) * sizeof(double);
+    // the items the box kernel leaves: the general tiled kernel (or, where it does not apply, nothing: handled below)
+    const int rc = affine_splat_lds<R>(d_I, go, A, T, nc, nn, g, bc, s, 1);
+    if (rc != 0) return rc;   // shape not supported by the general kernel either: the caller's plain kernel does all items
+    if (bc)
+        hipLaunchKernelGGL((affine_splat_box_kernel<R, true>), dim3(bg.total), dim3(kBlock), smem, s, d_I, go, A, T, nc, bg);
+    else
+        hipLaunchKernelGGL((affine_splat_box_kernel<R, false>), dim3(bg.total), dim3(kBlock), smem, s, d_I, go, A, T, nc, bg);
+    note_path(LP_SPLAT_AFFINE_BOX);
+    return 0;
 }
 
 // ------------------------------------------------------------------ regrid
@@ -475,7 +664,9 @@ static int affine_backward_impl(R *d_I, R *d_A, R *d_T, const R *go, const R *I,
     if (nn > 65535) return fail_invalid("affine_interp_backward: batch size above 65535 is not supported");
     if (g.nblocks && nc && need_I && dim == 3 && g_splat_mode >= 1) {
         // the image splat goes through the LDS-privatised kernel; d_A / d_T keep the reduction kernel
-        const int rc = affine_splat_lds<R>(d_I, go, A, T, (int)nc, nn, g, bc != 0, s);
+        // regular matrices: by target boxes; the others (decided per item on the device): the general tiled kernel
+        int rc = g_affine_box ? affine_splat_boxes<R>(d_I, go, A, T, (int)nc, nn, g, bc != 0, s) : 1;
+        if (rc == 1) rc = affine_splat_lds<R>(d_I, go, A, T, (int)nc, nn, g, bc != 0, s, 0);
         if (rc < 0) return rc;
         if (rc == 0) need_I = 0;
     }

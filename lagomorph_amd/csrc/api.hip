@@ -60,6 +60,7 @@ static lago_tuning default_tuning() {
     t.fluid_zy_persist = 1;
     t.fluid_xpass_wide = 1;
     t.fluid_xpass_persist = 1;
+    t.affine_box = 1;
     return t;
 }
 static lago_tuning g_tuning = default_tuning();
@@ -95,6 +96,7 @@ int lago_set_tuning(const lago_tuning *t) {
     lago::tune_fused(g.stencil_tile, g.gather_window);
     lago::tune_fluid(g.fluid_mode);
     lago::tune_fluid_passes(g.fluid_xpass_ipw, g.fluid_zy_persist, g.fluid_xpass_wide, g.fluid_xpass_persist);
+    lago::tune_affine(g.affine_box);
     return LAGO_OK;
 }
 void lago_set_debug(int on) { lago::g_debug = on ? 1 : 0; }

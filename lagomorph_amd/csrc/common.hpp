@@ -59,7 +59,7 @@ extern std::atomic<int> g_interp_vec;  // 1: use the vectorised 3D kernels when 
 // Which implementation a call was dispatched to (lago_path_launches; ids = LAGO_PATH_* of the header).  Telemetry only:
 // the tests use it to make sure a case meant to exercise a fast path really runs it.
 enum { LP_GATHER_WINDOW = 0, LP_STENCIL_TILE, LP_VECTOR_GATHER, LP_SPLAT_SHEAR, LP_SPLAT_SHEAR_MC, LP_SPLAT_TILED,
-       LP_SPLAT_GLOBAL, LP_FLUID_LDS, LP_FLUID_2D, LP_FLUID_XPASS, LP_FLUID_ROCFFT, LP_SPLAT_2D, LP_COUNT };
+       LP_SPLAT_GLOBAL, LP_FLUID_LDS, LP_FLUID_2D, LP_FLUID_XPASS, LP_FLUID_ROCFFT, LP_SPLAT_2D, LP_SPLAT_AFFINE_BOX, LP_COUNT };
 extern std::atomic<long long> g_path_launches[LP_COUNT];
 inline void note_path(int p) { g_path_launches[p].fetch_add(1, std::memory_order_relaxed); }
 
@@ -68,6 +68,7 @@ void tune_splat(const int32_t *tile7, const int32_t *shear8, int shear_mc, int m
 void tune_fused(int stencil_tile, int gather_window);                                   // fused.hip
 void tune_fluid(int mode);                                                              // fft.hip
 void tune_fluid_passes(int ipw, int zy_persist, int xpass_wide, int xpass_persist);     // fft3.hip
+void tune_affine(int box);                                                              // affine.hip
 
 #define LAGO_HIP_TRY(expr)                                      \
     do {                                                        \
@@ -443,6 +444,34 @@ struct Splat2 {
         }
     }
 };
+
+// affine_interp_backward's image splat has two kernels (affine.hip: affine_splat_box_kernel for "regular" matrices --
+// invertible, with an inverse that does not blow a target box up beyond 4 x per axis -- and splat.hip's general tiled
+// kernel for the others); both are always launched and every workgroup decides by THIS function, from the matrix in
+// device memory, whether the batch item is its own (no host synchronisation).  Ai: the inverse (valid when true).
+template <typename R>
+__device__ __forceinline__ bool affine_item_regular(const R *An, double (&Ai)[9]) {
+    double a[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) a[q] = (double)An[q];
+    const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c0 + a[1] * c1 + a[2] * c2;
+    double big = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) big = fabs(a[q]) > big ? fabs(a[q]) : big;
+    if (!(fabs(det) > 1e-3) || !(big < 1e3)) return false;   // (NaN fails both)
+    const double id = 1.0 / det;
+    Ai[0] = c0 * id; Ai[1] = (a[2] * a[7] - a[1] * a[8]) * id; Ai[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    Ai[3] = c1 * id; Ai[4] = (a[0] * a[8] - a[2] * a[6]) * id; Ai[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    Ai[6] = c2 * id; Ai[7] = (a[1] * a[6] - a[0] * a[7]) * id; Ai[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    double rows = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double rs = fabs(Ai[3 * r]) + fabs(Ai[3 * r + 1]) + fabs(Ai[3 * r + 2]);
+        rows = rs > rows ? rs : rows;
+    }
+    return rows <= 4.0;
+}
 
 // No-return hardware float atomics (global_atomic_add_f32 / _f64 on gfx950).
 __device__ __forceinline__ void atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }

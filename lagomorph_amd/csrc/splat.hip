@@ -49,6 +49,7 @@ struct PosArgs {
     // reference), 1 from the caller's d_u contents, 2 from addgo * grad_out[component] (needs nc == 3)
     int umode;
     double addgo;
+    int gate;   // POS_AFFINE: 1 = only batch items whose matrix is NOT regular (common.hpp: affine_item_regular)
 };
 
 struct TileGeom {
@@ -133,6 +134,10 @@ __global__ __launch_bounds__(NT) void splat_tiled_kernel(R *__restrict__ d_I, R 
     const R *un = DISP ? static_cast<const R *>(pa.u) + (size_t)n * 3 * snv : nullptr;
     const R *An = MODE == POS_AFFINE ? static_cast<const R *>(pa.A) + (size_t)n * 9 : nullptr;
     const R *Tn = MODE == POS_AFFINE ? static_cast<const R *>(pa.T) + (size_t)n * 3 : nullptr;
+    if (MODE == POS_AFFINE && pa.gate) {   // (wave-uniform: the whole workgroup leaves)
+        double Ai[9];
+        if (affine_item_regular<R>(An, Ai)) return;
+    }
     const R *In = BC ? I : I + (size_t)n * nc * nv;
     R *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
     const R *gon = go + (size_t)n * nc * snv;
@@ -1219,7 +1224,7 @@ int interp_backward_lds(R *d_I, R *d_u, const R *go, const R *I, const R *u, dou
 // d_I already zeroed.  Same return convention as interp_backward_lds.
 template <typename R>
 int affine_splat_lds(R *d_I, const R *go, const R *A, const R *T, int nc, int64_t nn, const Geom &g, bool bc,
-                     hipStream_t s) {
+                     hipStream_t s, int gate) {
     TileGeom tg;
     size_t smem;
     int nt;
@@ -1231,6 +1236,7 @@ int affine_splat_lds(R *d_I, const R *go, const R *A, const R *T, int nc, int64_
     PosArgs pa{};
     pa.A = A;
     pa.T = T;
+    pa.gate = gate;
     hipError_t e = bc ? by_threads<R, POS_AFFINE, true, false, 4>(d_I, nullptr, go, nullptr, pa, nc, tg, smem, nt, s)
                       : by_threads<R, POS_AFFINE, false, false, 4>(d_I, nullptr, go, nullptr, pa, nc, tg, smem, nt, s);
     if (e != hipSuccess) return fail_hip(e, "affine_interp_backward (tiled splat)");
@@ -1262,9 +1268,9 @@ template int interp_backward_lds<float>(float *, float *, const float *, const f
 template int interp_backward_lds<double>(double *, double *, const double *, const double *, const double *, double,
                                          int, int64_t, const Geom &, bool, bool, int, double, hipStream_t);
 template int affine_splat_lds<float>(float *, const float *, const float *, const float *, int, int64_t, const Geom &,
-                                     bool, hipStream_t);
+                                     bool, hipStream_t, int);
 template int affine_splat_lds<double>(double *, const double *, const double *, const double *, int, int64_t,
-                                      const Geom &, bool, hipStream_t);
+                                      const Geom &, bool, hipStream_t, int);
 template int regrid_splat_lds<float>(float *, const float *, int64_t, const Geom &, const Geom &, const double *,
                                      const double *, hipStream_t);
 template int regrid_splat_lds<double>(double *, const double *, int64_t, const Geom &, const Geom &, const double *,

@@ -91,7 +91,7 @@ class LagoTuning(ctypes.Structure):
                 ("vector_kernels", ctypes.c_int32), ("launch_order", ctypes.c_int32), ("stencil_tile", ctypes.c_int32),
                 ("gather_window", ctypes.c_int32), ("fluid_mode", ctypes.c_int32), ("fluid_xpass_ipw", ctypes.c_int32),
                 ("fluid_zy_persist", ctypes.c_int32), ("fluid_xpass_wide", ctypes.c_int32),
-                ("fluid_xpass_persist", ctypes.c_int32)]
+                ("fluid_xpass_persist", ctypes.c_int32), ("affine_box", ctypes.c_int32)]
 
 
 _lib.lago_get_tuning.argtypes = [ctypes.POINTER(LagoTuning)]
@@ -253,7 +253,7 @@ def set_stencil_tile(on):
 _lib.lago_path_launches.restype = ctypes.c_longlong
 _lib.lago_path_launches.argtypes = [_int]
 PATHS = ("gather_window", "stencil_tile", "vector_gather", "splat_shear", "splat_shear_mc", "splat_tiled", "splat_global",
-         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft", "splat_2d")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
+         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft", "splat_2d", "splat_affine_box")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
 
 
 def path_launches(name=None):

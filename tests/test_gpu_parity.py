@@ -824,7 +824,7 @@ def test_persistent_x_pass_any_pair_count(ext, shape, batch, inverse):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("kind", ["near_identity", "rotation", "zoom", "flip"])
+@pytest.mark.parametrize("kind", ["near_identity", "rotation", "zoom", "flip", "singular", "shear_far"])
 @pytest.mark.parametrize("bc", [False, True])
 def test_affine_backward_tiled_splat(ext, dtype, kind, bc):
     """affine_interp_backward's image splat through the LDS window, several tiles per volume,
@@ -841,15 +841,29 @@ def test_affine_backward_tiled_splat(ext, dtype, kind, bc):
         A[1] = [[1, 0, 0], [0, c, -s], [0, s, c]]
     elif kind == "zoom":
         A = A * np.array([2.5, 0.4])[:, None, None]
+    elif kind == "singular":      # item 0: rank 2 (no inverse: the general kernel's), item 1: regular (the box kernel's)
+        A[0] = [[1.0, 0.5, 0.0], [2.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+        A[1] = A[1] + 0.05 * rng.standard_normal((3, 3))
+    elif kind == "shear_far":     # a tiny determinant's neighbour: inverse rows far above the box kernel's limit, and an image far outside the grid
+        A[0] = [[0.05, 0.0, 0.0], [0.0, 0.04, 0.0], [0.0, 0.0, 1.0]]
+        A[1] = [[1.0, 0.9, 0.0], [0.0, 1.0, 0.8], [0.3, 0.0, 1.0]]
     else:
         A[0, 2, 2] = -1.0
         A[1, 0, 0] = -1.0
     A = A.astype(I.dtype)
     T = (2.0 * rng.standard_normal((nn, 3))).astype(I.dtype)
     go = rnd(rng, (nn, nc) + sp, dtype)
+    before = ext.path_launches("splat_affine_box")
     dI, dA, dT = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, True, True)
+    assert ext.path_launches("splat_affine_box") == before + 1   # (by target boxes; singular / wild items: gated to the tiled kernel)
     oI, oA, oT = orc.affine_interp_backward(go, I, A, T, True, True, True)
-    assert_close(dI, oI, dtype, "affine d_I (tiled)")
+    assert_close(dI, oI, dtype, "affine d_I (target boxes)")
+    ext.tune(affine_box=0)
+    try:
+        dI1, _, _ = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, False, False)
+    finally:
+        ext.tune(affine_box=1)
+    assert_close(dI1, oI, dtype, "affine d_I (tiled)")
     ext.set_splat_mode(0)
     try:
         dI0, _, _ = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, False, False)
