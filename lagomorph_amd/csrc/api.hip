@@ -33,6 +33,9 @@ int finish_launch(hipStream_t s, const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, what);
     if (g_debug) {
+        // (not while the stream is being captured into a graph: a synchronisation would invalidate the capture)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return LAGO_OK;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail_hip(e, what);
     }
