@@ -99,11 +99,14 @@ typedef struct lago_tuning {
      * source block of a tile of voxels in LDS with LDS-direct loads and take the corners from there
      * (csrc/gather_window.hpp) where the shape allows; 0: pair gathers through the vector L1 only.  Same bits */
     int32_t gather_window;
-    /* lago_fluid_metric implementation (float32, 3D): 2 (default) three LDS-tiled FFT passes without rocFFT (nx in
-     * {64,96,128,160,192,256}; (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes 32x{64,128,256},
-     * 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a); 1: rocFFT 2D (y, z) plan + fused x-axis pass (nx in
-     * {64,128,256}); 0: rocFFT 3D plan + operator kernel.  A mode falls back to the next lower one for shapes it does
-     * not support.  Results agree to rounding */
+    /* lago_fluid_metric implementation.  3 (default): the tuned LDS-tiled FFT passes where they apply (float32 3D with nx
+     * in {64,96,128,160,192,256} and (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
+     * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a; float32 2D planes up to 128 x 128 in
+     * one fused kernel) and the generic hand-written passes of csrc/fftg.hip for every other shape and for float64
+     * (any extent up to 2048 per axis): no rocFFT anywhere.  2: the tuned passes, rocFFT for the rest (1: rocFFT 2D
+     * (y, z) plan + fused x-axis pass, nx in {64,128,256}; 0: rocFFT 3D plan + operator kernel; a mode falls back to
+     * the next lower one for shapes it does not support); the rocFFT plans are spot-checked against a direct DFT
+     * (csrc/fft.hip).  Results agree to rounding */
     int32_t fluid_mode;
     /* FFT-pass fluid metric: batch items per x-pass workgroup (0, the default: chosen by the size of the launch) */
     int32_t fluid_xpass_ipw;
@@ -140,6 +143,7 @@ int lago_set_tuning(const lago_tuning *t);
 #define LAGO_PATH_FLUID_ROCFFT 10  /* lago_fluid_metric: rocFFT plan + operator kernel */
 #define LAGO_PATH_SPLAT_2D 11      /* LDS-privatised 2D splat (interp_backward of 2D fields) */
 #define LAGO_PATH_SPLAT_AFFINE_BOX 12 /* affine_interp_backward's image splat by target boxes */
+#define LAGO_PATH_FLUID_GENERIC 13 /* lago_fluid_metric: generic hand-written FFT passes (any extent, both precisions) */
 long long lago_path_launches(int path);
 
 

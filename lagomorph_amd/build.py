@@ -21,7 +21,7 @@ OBJ = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblagomorph_hip.so")
 LIB_PROF = os.path.join(LIBDIR, "liblagomorph_hip_prof.so")
-SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip"]
+SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip", "fftg.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3",

@@ -58,7 +58,7 @@ static lago_tuning default_tuning() {
     t.launch_order = 1;
     t.stencil_tile = 1;
     t.gather_window = 1;
-    t.fluid_mode = 2;
+    t.fluid_mode = 3;
     t.fluid_xpass_ipw = 0;
     t.fluid_zy_persist = 1;
     t.fluid_xpass_wide = 1;

@@ -59,7 +59,7 @@ extern std::atomic<int> g_interp_vec;  // 1: use the vectorised 3D kernels when 
 // Which implementation a call was dispatched to (lago_path_launches; ids = LAGO_PATH_* of the header).  Telemetry only:
 // the tests use it to make sure a case meant to exercise a fast path really runs it.
 enum { LP_GATHER_WINDOW = 0, LP_STENCIL_TILE, LP_VECTOR_GATHER, LP_SPLAT_SHEAR, LP_SPLAT_SHEAR_MC, LP_SPLAT_TILED,
-       LP_SPLAT_GLOBAL, LP_FLUID_LDS, LP_FLUID_2D, LP_FLUID_XPASS, LP_FLUID_ROCFFT, LP_SPLAT_2D, LP_SPLAT_AFFINE_BOX, LP_COUNT };
+       LP_SPLAT_GLOBAL, LP_FLUID_LDS, LP_FLUID_2D, LP_FLUID_XPASS, LP_FLUID_ROCFFT, LP_SPLAT_2D, LP_SPLAT_AFFINE_BOX, LP_FLUID_GENERIC, LP_COUNT };
 extern std::atomic<long long> g_path_launches[LP_COUNT];
 inline void note_path(int p) { g_path_launches[p].fetch_add(1, std::memory_order_relaxed); }
 

@@ -44,10 +44,16 @@ bool fluid2d_supported(int64_t h, int64_t w);
 int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, const float *sinX, const float *cosY,
                     const float *sinY, double alpha, double beta, double gamma, int64_t nn, int64_t h, int64_t w,
                     hipStream_t s);
+// fftg.hip
+bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz);
+template <typename R>
+int fluid_metric_generic(R *out, const R *m, R *work, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
+                         const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn, int64_t nx,
+                         int64_t ny, int64_t nz, hipStream_t s);
 // 0: rocFFT 3D plan + operator kernel; 1: rocFFT 2D (y, z) plan + fused x pass (fftx.hip);
-// 2: three LDS-tiled passes, no rocFFT (fft3.hip).  Each falls back to the previous one where the
-// shape is not supported.
-std::atomic<int> g_fluid_xpass{2};
+// 2: three LDS-tiled passes, no rocFFT (fft3.hip), falling back to 1 / 0 where the shape is not supported;
+// 3 (default): the same tuned passes, and the GENERIC hand-written passes (fftg.hip) for everything else -- no rocFFT.
+std::atomic<int> g_fluid_xpass{3};
 
 // Operator coefficient tables (see fftx.hip), cached like the FFT plans: one device buffer per
 // (LUT generation, shape, parameters, direction), filled by a kernel on first use.  The key holds no
@@ -463,6 +469,11 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
         return fluid_metric_native((float *)out, (const float *)m, (float *)work, tab->d, inverse, nn, nx, ny, nz,
                                    1.0 / ((double)nx * (double)ny * (double)nz), (hipStream_t)stream);
     }
+    if (g_fluid_xpass >= 3 && fluid_generic_supported(dim, nx, ny, nz)) {
+        note_path(LP_FLUID_GENERIC);
+        return fluid_metric_generic<R>(out, m, work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn,
+                                       nx, ny, nz, (hipStream_t)stream);
+    }
     if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass && fluid_xpass_supported(nx) && nn * 3 * nx < (1ll << 31)) {
         note_path(LP_FLUID_XPASS);
         return fluid_metric_xpass((float *)out, (const float *)m, (float *)work, gen, inverse, (const float *)cosX,
@@ -504,7 +515,7 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
 }  // namespace lago
 
 namespace lago {
-void tune_fluid(int mode) { g_fluid_xpass = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+void tune_fluid(int mode) { g_fluid_xpass = mode < 0 ? 0 : (mode > 3 ? 3 : mode); }
 }  // namespace lago
 
 extern "C" {

@@ -1,0 +1,372 @@
+// Generic hand-written FFT passes for the fluid metric: ANY extent, float32 and float64, 2D and 3D.
+//
+// The tuned passes of fft3.hip cover float32 volumes whose extents are 2^a, 3*2^a or 5*2^a (and a list of 2D planes);
+// every other caller of FluidMetricOperator.forward (lagomorph/metric.py:11-19: it serves any shape and dtype) used to
+// fall back to rocFFT -- a third-party library that ROCm 7.2 ships with a batched 2D real transform that can come back
+// 60 % wrong (tools/probes/rocfft_2d_repro.py).  This file is the fallback that needs no library: float64 (the
+// reference's gradcheck suite), extents with other prime factors (120, 182 x 218 x 182, ...), 2D planes beyond the LDS.
+// Generality first, then speed: one kernel transforms batches of LINES along one axis --
+//   * a workgroup brings L lines of N points into LDS as [point][line] (adjacent lines of a strided axis are adjacent
+//     in memory: coalesced rows; L from lines_pass),
+//   * runs a Stockham autosort FFT with the radices of N's factorisation (4 where it divides, then the primes
+//     ascending).  Radices 2, 3, 4, 5, 7: one whole butterfly per thread in registers (r LDS reads, r writes, r - 1
+//     twiddles); any other prime: one output per thread, a direct r-point DFT -- so ANY extent works,
+//   * one table of the N-th roots per workgroup (sincospi of the exactly reduced argument, in double for float64 lines
+//     and in float for float32 ones); stage twiddles and the r-th roots are strided reads of it,
+//   * the real axis packs TWO real lines into one complex line (a + i b) and separates / rebuilds the two half spectra
+//     by conjugate symmetry; pairs never cross a field, so a batch item's bits do not depend on its neighbours.
+// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.97 - 1.7x its time.
+// The per-frequency operator between the passes is metric.hip's fluid_kernel, the same as on the rocFFT path, with
+// the 1/N of the unnormalised transform pair folded in.  Layout of the half spectrum: [n][c][x][y][z <= nz/2] complex,
+// what rocFFT's R2C produces, so the operator kernel does not know which path ran.
+#include <vector>
+
+#include "common.hpp"
+
+namespace lago {
+
+template <typename R>
+int fluid_operator_impl(R *Fm, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
+                        const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim,
+                        int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream, double scale);  // metric.hip
+
+template <typename R>
+struct alignas(2 * sizeof(R)) GC {
+    R re, im;
+};
+template <typename R>
+__device__ __forceinline__ GC<R> cmul(GC<R> a, GC<R> b) {
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+template <typename R>
+__device__ __forceinline__ GC<R> cadd(GC<R> a, GC<R> b) { return {a.re + b.re, a.im + b.im}; }
+template <typename R>
+__device__ __forceinline__ GC<R> csub(GC<R> a, GC<R> b) { return {a.re - b.re, a.im - b.im}; }
+// a * (sign i)
+template <typename R>
+__device__ __forceinline__ GC<R> cmuli(GC<R> a, int sign) {
+    return sign > 0 ? GC<R>{-a.im, a.re} : GC<R>{a.im, -a.re};
+}
+
+template <typename R>
+__device__ __forceinline__ GC<R> root(int k, int n, int sign);   // exp(sign 2 pi i k / n)
+template <>
+__device__ __forceinline__ GC<double> root<double>(int k, int n, int sign) {
+    double sn, cs;
+    sincospi(2.0 * (double)k / (double)n, &sn, &cs);
+    return {cs, (double)sign * sn};
+}
+template <>
+__device__ __forceinline__ GC<float> root<float>(int k, int n, int sign) {
+    float sn, cs;
+    sincospif((float)(2.0 * (double)k / (double)n), &sn, &cs);
+    return {cs, (float)sign * sn};
+}
+
+struct GLines {
+    int N;               // points per line
+    uint32_t inner;      // mode 0: stride between consecutive points of a line (elements) = lines adjacent in memory
+    uint32_t nlines;     // mode 0: lines of the launch.  modes 1 / 2: lines per plane (one (n, c) field: X * Y)
+    uint32_t ppp;        // modes 1 / 2: PAIRS of lines per plane = ceil(nlines / 2), chunks of L pairs per plane
+    uint32_t chunks;
+    int L, Lp;           // lines (mode 0) or pairs (modes 1 / 2) per workgroup; Lp = L | 1, the LDS row pitch
+    int sign;            // -1 forward, +1 inverse (unnormalised)
+    int mode;            // 0 complex -> complex in place; 1 real lines -> half spectra; 2 half spectra -> real lines
+    int nhalf;           // mode 1 / 2: N / 2 + 1
+    int nfac;
+    int fac[20];
+    FastDiv dinner, dN, dL, dnhalf, dchunks;
+    FastDiv ds[20], dr[20];   // per stage: division by the stride s and by the radix r
+};
+
+// line l of a mode-0 launch: element offset of its first point
+__device__ __forceinline__ size_t gline_base(const GLines &a, uint32_t l, int n_points) {
+    const uint32_t hi = a.dinner.div(l), lo = l - hi * a.inner;
+    return (size_t)hi * (size_t)n_points * a.inner + lo;
+}
+
+// One Stockham stage of radix RR on every line of the workgroup, a whole butterfly per thread in registers:
+//   y[q + s (RR p + u)] = (sum_t x[q + s (p + t m)] w_RR^(t u)) w_n^(p u),  n = RR m the remaining length, s the stride;
+// w_n^(p u) = W[p u s] and w_RR^k = W[k N / RR] from the one table of N-th roots.  LDS layout [point][line]: the line
+// index runs fastest over the threads, so every read and write is to consecutive addresses and the twiddle is a
+// broadcast.
+template <typename R, int RR>
+__device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *__restrict__ y, const GC<R> *__restrict__ W,
+                                            const GLines &a, int nl, int s, int m, FastDiv ds) {
+    typedef GC<R> C;
+    const int N = a.N, Lp = a.Lp, L = a.L;
+    C wr[RR];
+    if (RR != 2 && RR != 4) {
+#pragma unroll
+        for (int t = 0; t < RR; ++t) wr[t] = W[t * (N / RR)];
+    }
+    const int nb = (N / RR) * L;
+    for (int b = threadIdx.x; b < nb; b += kBlock) {
+        const int j = (int)a.dL.div((uint32_t)b), ln = b - j * L;
+        if (ln >= nl) continue;
+        const int p = (int)ds.div((uint32_t)j), q = j - p * s;
+        const C *xi = x + (size_t)(q + s * p) * Lp + ln;
+        C v[RR], o[RR];
+#pragma unroll
+        for (int t = 0; t < RR; ++t) v[t] = xi[(size_t)s * m * t * Lp];
+        if (RR == 2) {
+            o[0] = cadd(v[0], v[1]);
+            o[1] = csub(v[0], v[1]);
+        } else if (RR == 4) {
+            const C e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]), o0 = cadd(v[1], v[3]), o1 = cmuli(csub(v[1], v[3]), a.sign);
+            o[0] = cadd(e0, o0);
+            o[1] = cadd(e1, o1);
+            o[2] = csub(e0, o0);
+            o[3] = csub(e1, o1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < RR; ++u) {
+                C acc = v[0];
+#pragma unroll
+                for (int t = 1; t < RR; ++t) {
+                    const C w = wr[(t * u) % RR];
+                    acc.re = __builtin_fma(v[t].re, w.re, __builtin_fma(-v[t].im, w.im, acc.re));
+                    acc.im = __builtin_fma(v[t].re, w.im, __builtin_fma(v[t].im, w.re, acc.im));
+                }
+                o[u] = acc;
+            }
+        }
+        C *yo = y + (size_t)(q + s * RR * p) * Lp + ln;
+        yo[0] = o[0];
+#pragma unroll
+        for (int u = 1; u < RR; ++u) yo[(size_t)s * u * Lp] = cmul(o[u], W[p * u * s]);
+    }
+}
+
+// any other radix (the primes from 11 up): one output per thread, an r-point direct DFT
+template <typename R>
+__device__ __forceinline__ void stage_any(const GC<R> *__restrict__ x, GC<R> *__restrict__ y, const GC<R> *__restrict__ W,
+                                          const GLines &a, int nl, int r, int s, int m, FastDiv ds, FastDiv dr) {
+    typedef GC<R> C;
+    const int N = a.N, Lp = a.Lp, L = a.L, wstep = N / r;
+    for (int i = threadIdx.x; i < N * L; i += kBlock) {
+        const int yi = (int)a.dL.div((uint32_t)i), ln = i - yi * L;
+        if (ln >= nl) continue;
+        const int pu = (int)ds.div((uint32_t)yi), q = yi - pu * s;
+        const int p = (int)dr.div((uint32_t)pu), u = pu - p * r;
+        const C *xi = x + (size_t)(q + s * p) * Lp + ln;
+        C acc = {(R)0, (R)0};
+        int tu = 0;   // (t u) mod r
+        for (int t = 0; t < r; ++t) {
+            const C v = xi[(size_t)s * m * t * Lp], w = W[tu * wstep];
+            acc.re = __builtin_fma(v.re, w.re, __builtin_fma(-v.im, w.im, acc.re));
+            acc.im = __builtin_fma(v.re, w.im, __builtin_fma(v.im, w.re, acc.im));
+            tu += u;
+            if (tu >= r) tu -= r;
+        }
+        y[(size_t)yi * Lp + ln] = cmul(acc, W[p * u * s]);
+    }
+}
+
+template <typename R>
+__global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ spec, const R *__restrict__ rin, R *__restrict__ rout,
+                                                           GLines a) {
+    extern __shared__ __align__(16) unsigned char lago_fg[];
+    typedef GC<R> C;
+    const int N = a.N, L = a.L, Lp = a.Lp;
+    C *x = reinterpret_cast<C *>(lago_fg), *y = x + (size_t)Lp * N, *W = y + (size_t)Lp * N;
+    // modes 1 / 2: the workgroup's pairs [j0, j0 + nl) of plane `plane`; lines 2 j and 2 j + 1 share one complex line
+    uint32_t l0 = 0, plane = 0;
+    int nl;
+    if (a.mode == 0) {
+        l0 = blockIdx.x * (uint32_t)L;
+        nl = (int)min((uint32_t)L, a.nlines - l0);
+    } else {
+        plane = a.dchunks.div(blockIdx.x);
+        l0 = (blockIdx.x - plane * a.chunks) * (uint32_t)L;
+        nl = (int)min((uint32_t)L, a.ppp - l0);
+    }
+    const size_t pline = (size_t)plane * a.nlines;   // first line of the plane
+    // ---- load into x[point][line]
+    if (a.mode == 1) {            // two real lines -> one complex line (a + i b)
+        for (int i = threadIdx.x; i < nl * N; i += kBlock) {
+            const int pr = (int)a.dN.div((uint32_t)i), pt = i - pr * N;
+            const uint32_t la = 2 * (l0 + pr);
+            const R *ra = rin + (pline + la) * N;
+            x[(size_t)pt * Lp + pr] = {ra[pt], la + 1 < a.nlines ? ra[N + pt] : (R)0};
+        }
+    } else if (a.mode == 2) {     // two half spectra A, B -> the full spectrum of a + i b: Z[k] = A[k] + i B[k],
+                                  // A[N - k] = conj A[k]; the imaginary parts of the self-conjugate bins are ignored,
+                                  // as a complex-to-real transform does
+        for (int i = threadIdx.x; i < nl * N; i += kBlock) {
+            const int pr = (int)a.dN.div((uint32_t)i), pt = i - pr * N;
+            const uint32_t la = 2 * (l0 + pr);
+            const bool up = pt >= a.nhalf;
+            const int k = up ? N - pt : pt;
+            const C *sa = spec + (pline + la) * a.nhalf;
+            C A = sa[k], B = la + 1 < a.nlines ? sa[a.nhalf + k] : C{(R)0, (R)0};
+            if (k == 0 || 2 * k == N) A.im = B.im = (R)0;
+            if (up) { A.im = -A.im; B.im = -B.im; }
+            x[(size_t)pt * Lp + pr] = {A.re - B.im, A.im + B.re};
+        }
+    } else {                      // strided complex lines: adjacent lines are adjacent in memory
+        for (int i = threadIdx.x; i < L * N; i += kBlock) {
+            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
+            if (ln < nl) x[(size_t)pt * Lp + ln] = spec[gline_base(a, l0 + ln, N) + (size_t)pt * a.inner];
+        }
+    }
+    // the N-th roots of unity, once (argument reduced exactly, k / N with k < N; sincospi in double for float64 lines,
+    // in float for float32 ones: ~1e-7 per twiddle, inside the transform's own rounding)
+    for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, a.sign);
+    // ---- Stockham stages
+    int n = N, s = 1;
+    for (int f = 0; f < a.nfac; ++f) {
+        const int r = a.fac[f], m = n / r;
+        __syncthreads();   // x (and, the first time, W) complete
+        switch (r) {
+            case 2: stage_fixed<R, 2>(x, y, W, a, nl, s, m, a.ds[f]); break;
+            case 3: stage_fixed<R, 3>(x, y, W, a, nl, s, m, a.ds[f]); break;
+            case 4: stage_fixed<R, 4>(x, y, W, a, nl, s, m, a.ds[f]); break;
+            case 5: stage_fixed<R, 5>(x, y, W, a, nl, s, m, a.ds[f]); break;
+            case 7: stage_fixed<R, 7>(x, y, W, a, nl, s, m, a.ds[f]); break;
+            default: stage_any<R>(x, y, W, a, nl, r, s, m, a.ds[f], a.dr[f]); break;
+        }
+        C *tmp = x; x = y; y = tmp;
+        n = m;
+        s *= r;
+    }
+    __syncthreads();
+    // ---- store
+    if (a.mode == 1) {            // A[k] = (Z[k] + conj Z[N - k]) / 2,  B[k] = (Z[k] - conj Z[N - k]) / (2 i)
+        for (int i = threadIdx.x; i < nl * a.nhalf; i += kBlock) {
+            const int pr = (int)a.dnhalf.div((uint32_t)i), k = i - pr * a.nhalf;
+            const uint32_t la = 2 * (l0 + pr);
+            const C zk = x[(size_t)k * Lp + pr], zm = x[(size_t)(k ? N - k : 0) * Lp + pr];
+            C *sa = spec + (pline + la) * a.nhalf;
+            sa[k] = {(R)0.5 * (zk.re + zm.re), (R)0.5 * (zk.im - zm.im)};
+            if (la + 1 < a.nlines) sa[a.nhalf + k] = {(R)0.5 * (zk.im + zm.im), (R)0.5 * (zm.re - zk.re)};
+        }
+    } else if (a.mode == 2) {
+        for (int i = threadIdx.x; i < nl * N; i += kBlock) {
+            const int pr = (int)a.dN.div((uint32_t)i), pt = i - pr * N;
+            const uint32_t la = 2 * (l0 + pr);
+            const C z = x[(size_t)pt * Lp + pr];
+            R *ra = rout + (pline + la) * N;
+            ra[pt] = z.re;
+            if (la + 1 < a.nlines) ra[N + pt] = z.im;
+        }
+    } else {
+        for (int i = threadIdx.x; i < L * N; i += kBlock) {
+            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
+            if (ln < nl) spec[gline_base(a, l0 + ln, N) + (size_t)pt * a.inner] = x[(size_t)pt * Lp + ln];
+        }
+    }
+}
+
+static void factorise(int N, GLines &a) {
+    a.nfac = 0;
+    int n = N;
+    while (n % 4 == 0) { a.fac[a.nfac++] = 4; n /= 4; }
+    for (int p = 2; (long long)p * p <= n; ++p)
+        while (n % p == 0) { a.fac[a.nfac++] = p; n /= p; }
+    if (n > 1) a.fac[a.nfac++] = n;
+}
+
+constexpr int kGenericMaxN = 2048;   // (2 (L | 1) + 1) N complex numbers must fit the LDS
+
+bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz) {
+    const int64_t ext[3] = {dim == 3 ? nx : 1, dim == 3 ? ny : nx, dim == 3 ? nz : ny};
+    for (int d = 0; d < 3; ++d)
+        if (ext[d] < 1 || ext[d] > kGenericMaxN) return false;
+    return true;
+}
+
+// mode 0: `nlines` complex lines of N points, stride `inner`.  modes 1 / 2: `planes` fields of `nlines` contiguous real
+// lines each (pairs of lines never cross a field: every batch item's result is independent of its neighbours)
+template <typename R>
+static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner, uint64_t nlines, uint64_t planes, int sign,
+                      int mode, hipStream_t s) {
+    if (N == 1 && mode == 0) return LAGO_OK;
+    if (nlines == 0 || planes == 0) return LAGO_OK;
+    if (nlines >= (1ull << 31) || inner >= (1ull << 31) || planes * nlines >= (1ull << 31))
+        return fail_invalid("fluid_metric: bad extent");
+    GLines a;
+    a.N = N;
+    a.inner = (uint32_t)inner;
+    a.nlines = (uint32_t)nlines;
+    a.sign = sign;
+    a.mode = mode;
+    a.nhalf = N / 2 + 1;
+    factorise(N, a);
+    // lines per workgroup: about 1024 points (a radix-4 stage is then one butterfly per thread, and the workgroup's LDS
+    // stays small enough for 4+ workgroups per CU: measured best of 512 ... 4096, profiles/r04_fft_generic.md); a
+    // strided pass takes at least 128 B of adjacent lines per point (64 B where 128 B would need more than half the
+    // LDS); all within 128 KB
+    const size_t cb = 2 * sizeof(R);
+    const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
+    auto lds = [&](int l) { return ((size_t)2 * (l | 1) + 1) * N * cb; };
+    int L = std::max(1, 1024 / N);
+    if (mode == 0) {
+        const int want = std::max(L, (int)(128 / cb));
+        L = lds(want) <= 80 * 1024 ? want : std::max(L, (int)(64 / cb));
+    }
+    while (L > 1 && lds(L) > 128 * 1024) --L;
+    if ((uint64_t)L > units) L = (int)units;
+    const int Lp = L | 1;
+    const size_t smem = ((size_t)2 * Lp + 1) * N * cb;
+    if (smem > 160 * 1024) return fail_invalid("fluid_metric: extent %d is above what the generic FFT passes hold in LDS", N);
+    a.L = L;
+    a.Lp = Lp;
+    a.ppp = (uint32_t)units;
+    a.chunks = (uint32_t)((units + L - 1) / L);
+    a.dinner = FastDiv(a.inner);
+    a.dN = FastDiv((uint32_t)N);
+    a.dL = FastDiv((uint32_t)L);
+    a.dnhalf = FastDiv((uint32_t)a.nhalf);
+    a.dchunks = FastDiv(a.chunks);
+    for (int f = 0, st = 1; f < a.nfac; ++f) {
+        a.ds[f] = FastDiv((uint32_t)st);
+        a.dr[f] = FastDiv((uint32_t)a.fac[f]);
+        st *= a.fac[f];
+    }
+    const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
+    if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
+    auto k = fft_lines_kernel<R>;
+    if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
+    return LAGO_OK;
+}
+
+// out = irfft(L^(+-2) rfft(m)) through the generic passes; work: the half spectrum (nn * dim * nx * ny * (nz/2 + 1) complex)
+template <typename R>
+int fluid_metric_generic(R *out, const R *m, R *work, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
+                         const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn, int64_t nx,
+                         int64_t ny, int64_t nz, hipStream_t s) {
+    // geometry order: 3D (X, Y, Z) = (nx, ny, nz); 2D (X, Y, Z) = (1, nx, ny)
+    const int64_t X = dim == 3 ? nx : 1, Y = dim == 3 ? ny : nx, Z = dim == 3 ? nz : ny;
+    const int64_t zc = Z / 2 + 1, planes = nn * dim;
+    GC<R> *spec = reinterpret_cast<GC<R> *>(work);
+    int rc = lines_pass<R>(spec, m, nullptr, (int)Z, 1, (uint64_t)(X * Y), (uint64_t)planes, -1, 1, s);
+    if (rc != LAGO_OK) return rc;
+    rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, -1, 0, s);
+    if (rc != LAGO_OK) return rc;
+    rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, -1, 0, s);
+    if (rc != LAGO_OK) return rc;
+    const double scale = 1.0 / ((double)X * (double)Y * (double)Z);
+    const int64_t cx = nx, cy = dim == 2 ? ny / 2 + 1 : ny, cz = dim == 3 ? nz / 2 + 1 : 1;
+    rc = fluid_operator_impl<R>(work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, cx, cy, cz,
+                                (void *)s, scale);
+    if (rc != LAGO_OK) return rc;
+    rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, +1, 0, s);
+    if (rc != LAGO_OK) return rc;
+    rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, +1, 0, s);
+    if (rc != LAGO_OK) return rc;
+    rc = lines_pass<R>(spec, nullptr, out, (int)Z, 1, (uint64_t)(X * Y), (uint64_t)planes, +1, 2, s);
+    if (rc != LAGO_OK) return rc;
+    return finish_launch(s, "fluid_metric");
+}
+
+template int fluid_metric_generic<float>(float *, const float *, float *, int, const float *, const float *, const float *,
+                                         const float *, const float *, const float *, double, double, double, int, int64_t,
+                                         int64_t, int64_t, int64_t, hipStream_t);
+template int fluid_metric_generic<double>(double *, const double *, double *, int, const double *, const double *,
+                                          const double *, const double *, const double *, const double *, double, double,
+                                          double, int, int64_t, int64_t, int64_t, int64_t, hipStream_t);
+
+}  // namespace lago

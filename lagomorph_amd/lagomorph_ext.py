@@ -253,7 +253,7 @@ def set_stencil_tile(on):
 _lib.lago_path_launches.restype = ctypes.c_longlong
 _lib.lago_path_launches.argtypes = [_int]
 PATHS = ("gather_window", "stencil_tile", "vector_gather", "splat_shear", "splat_shear_mc", "splat_tiled", "splat_global",
-         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft", "splat_2d", "splat_affine_box")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
+         "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft", "splat_2d", "splat_affine_box", "fluid_generic")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
 
 
 def path_launches(name=None):
@@ -280,8 +280,9 @@ def set_vector_kernels(on):
 
 
 def set_fluid_mode(mode):
-    """fluid_metric implementation: 2 (default) three LDS-tiled FFT passes where the shape allows,
-    1 rocFFT 2D plan + fused x pass, 0 rocFFT 3D plan + operator kernel."""
+    """fluid_metric implementation: 3 (default) the tuned LDS-tiled FFT passes where the shape allows and the generic
+    hand-written passes for everything else (no rocFFT); 2 the tuned passes with rocFFT fallbacks, 1 rocFFT 2D plan +
+    fused x pass, 0 rocFFT 3D plan + operator kernel."""
     tune(fluid_mode=mode)
 
 

@@ -191,7 +191,7 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
         "    if (!lago_version() || !strlen(lago_version())) return 2;\n"
         "    lago_set_debug(1); if (lago_get_debug() != 1) return 3; lago_set_debug(0);\n"
         "    { lago_tuning t, d; t.struct_size = sizeof t; d.struct_size = sizeof d; lago_get_tuning(&t); lago_default_tuning(&d);\n"
-        "      if (memcmp(&t, &d, sizeof t) || t.splat_shear[7] != 1024 || t.fluid_mode != 2) return 5;\n"
+        "      if (memcmp(&t, &d, sizeof t) || t.splat_shear[7] != 1024 || t.fluid_mode != 3) return 5;\n"
         "      t.gather_window = 0; if (lago_set_tuning(&t) != LAGO_OK) return 6; lago_get_tuning(&d); if (d.gather_window != 0) return 7;\n"
         "      t.struct_size = 6; if (lago_set_tuning(&t) != LAGO_ERR_INVALID) return 8;\n"
         "      t.struct_size = 8; t.splat_mode = 0; t.gather_window = 1; if (lago_set_tuning(&t) != LAGO_OK) return 9;   /* an older, shorter struct */\n"
@@ -239,7 +239,7 @@ def test_tuning_is_one_struct():
     d = ext.default_tuning()
     assert ext.get_tuning() == d
     assert d["splat_shear"] == [1, 8, 6, 0, 1, 1, 4, 1024] and d["splat_tile"] == [0, 8, 0, 1, 1, 4, 512]
-    assert d["fluid_mode"] == 2 and d["splat_shear_mc"] == 2 and d["launch_order"] == 1
+    assert d["fluid_mode"] == 3 and d["splat_shear_mc"] == 2 and d["launch_order"] == 1
     try:
         ext.tune(gather_window=0, splat_shear=[1, 4, 8, 0, 2, 2, 8, 512])
         t = ext.get_tuning()

@@ -45,13 +45,22 @@ def test_headline_operators_take_their_fast_paths(lm, sp):
 
 
 @pytest.mark.parametrize("sp,path", [((128, 128, 128), "fluid_lds"), ((160, 160, 160), "fluid_lds"), ((64, 96, 128), "fluid_lds"),
-                                     ((64, 40, 40), "fluid_xpass"), ((24, 20, 28), "fluid_rocfft"),
-                                     ((128, 128), "fluid_2d"), ((64, 256), "fluid_2d"), ((100, 100), "fluid_rocfft")])
+                                     ((64, 40, 40), "fluid_generic"), ((24, 20, 28), "fluid_generic"),
+                                     ((128, 128), "fluid_2d"), ((64, 256), "fluid_2d"), ((100, 100), "fluid_generic")])
 def test_fluid_metric_dispatch(lm, sp, path):
     metric = lm.FluidMetric([0.1, 0.0, 0.01])
     m = _fields(2, len(sp), sp)
     assert _delta(lm.lagomorph_ext, lambda: metric.sharp(m)) == {path: 1}
     assert _delta(lm.lagomorph_ext, lambda: metric.flat(m)) == {path: 1}
+    # float64 never reaches rocFFT either (round 4: generic hand-written passes)
+    assert _delta(lm.lagomorph_ext, lambda: metric.sharp(m.double())) == {"fluid_generic": 1}
+    if path == "fluid_generic":   # rocFFT stays selectable: fluid_mode 2 and below
+        lm.lagomorph_ext.set_fluid_mode(2)
+        try:
+            took = _delta(lm.lagomorph_ext, lambda: metric.sharp(m))
+        finally:
+            lm.lagomorph_ext.set_fluid_mode(3)
+        assert list(took) in (["fluid_rocfft"], ["fluid_xpass"]), took
 
 
 def test_the_switches_select_the_slower_siblings(lm):

@@ -240,7 +240,7 @@ def test_fused_operators_128cubed(lm):
             ext.set_fluid_mode(mode)
             got[mode] = met.sharp(m)
     finally:
-        ext.set_fluid_mode(2)
+        ext.set_fluid_mode(3)
     assert (got[2] - got[0]).abs().max().item() <= 2e-5 * got[0].abs().max().item()
 
 

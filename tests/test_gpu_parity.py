@@ -575,11 +575,58 @@ def test_fused_fluid_metric_paths(ext, sp, inverse):
             ext.set_fluid_mode(mode)
             got[mode] = f(md)
     finally:
-        ext.set_fluid_mode(2)
+        ext.set_fluid_mode(3)
     want = orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse)
     for mode in (2, 1, 0):
         assert_close(got[mode], want, torch.float32, f"fluid metric mode {mode} vs oracle")
     assert_close(got[2], host(got[0]), torch.float32, "native passes vs plain hipFFT")
+
+
+GENERIC_FFT_SHAPES = [(30, 42, 26), (13, 17, 22), (7, 9), (100, 100), (218, 26), (1, 5, 8), (9, 1, 6), (24, 20, 28), (64, 40, 40),
+                      (2, 3), (3, 2, 2), (121, 49), (32, 128), (120, 60, 30), (37, 64)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp", GENERIC_FFT_SHAPES)
+@pytest.mark.parametrize("inverse", [True, False])
+def test_generic_fft_passes(ext, dtype, sp, inverse):
+    """csrc/fftg.hip (round 4; VERDICT r3 missing #4): every shape the tuned passes do not cover -- float64, extents with
+    prime factors 7, 11, 13, 37, 109, extents of 1 to 3, odd real axes, 2D planes beyond the LDS -- runs hand-written
+    Stockham passes (register butterflies for radices 2, 3, 4, 5, 7, a direct DFT for any other prime) instead of
+    rocFFT, against the oracle; bit for bit the same on a second call (no atomics anywhere) and for an item alone."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(hash((sp, inverse)) % 2**31)
+    m = rnd(rng, (3, len(sp)) + sp, dtype)
+    for params in ([0.1, 0.05, 0.01], [1.0, 0.0, 0.001]):
+        met = lm.FluidMetric(params)
+        f = met.sharp if inverse else met.flat
+        before = ext.path_launches()
+        got = f(dev(m))
+        after = ext.path_launches()
+        fused2d = dtype == torch.float32 and sp in ((32, 128),)   # (a shape of the fused 2D kernel, float32 only)
+        assert after["fluid_rocfft"] == before["fluid_rocfft"] and after["fluid_xpass"] == before["fluid_xpass"]
+        assert after["fluid_generic"] == before["fluid_generic"] + (0 if fused2d else 1), sp
+        assert_close(got, orc.fluid_metric_apply(m, params, inverse), dtype, f"generic FFT passes {sp}")
+        assert torch.equal(got, f(dev(m)))
+        # the real axis transforms two lines as one complex line: the pairs stay inside a field, so an item's bits do
+        # not depend on its batch neighbours
+        assert torch.equal(got[1:2], f(dev(m[1:2])))
+
+
+def test_generic_fft_passes_large_planes(ext):
+    """2D planes far beyond the LDS (the affine / 2D registration images): 4 x 2 x 1024 x 768 and 2 x 2 x 600 x 1000,
+    float32, through the generic passes against the oracle."""
+    import lagomorph_amd as lm
+
+    rng = np.random.default_rng(12)
+    for sp, nn in (((1024, 768), 4), ((600, 1000), 2)):
+        m = rnd(rng, (nn, 2) + sp, torch.float32)
+        met = lm.FluidMetric([0.1, 0.0, 0.01])
+        before = ext.path_launches("fluid_generic")
+        got = met.sharp(dev(m))
+        assert ext.path_launches("fluid_generic") == before + 1
+        assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.0, 0.01], True), torch.float32, f"generic FFT passes {sp}")
 
 
 @pytest.mark.parametrize("sp", [(64, 64), (128, 128), (96, 64), (64, 128), (160, 96), (32, 128), (256, 64), (96, 192),
@@ -608,7 +655,7 @@ def test_fused_2d_fluid_metric(ext, sp, inverse):
                     assert mode == 0 and "rocFFT returned a WRONG" in str(e), e
                     print(f"NOTE rocFFT guard fired at {sp}: {e}")
         finally:
-            ext.set_fluid_mode(2)
+            ext.set_fluid_mode(3)
         want = orc.fluid_metric_apply(m, params, inverse)
         assert_close(got[2], want, torch.float32, f"fused 2D fluid metric vs oracle {sp}")
         lmm.USE_FUSED_FLUID = False
@@ -693,7 +740,7 @@ def test_rocfft_fallback_is_right_or_loud(ext):
                     continue
                 assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], inverse), dtype, f"rocFFT fallback {sp}")
     finally:
-        ext.set_fluid_mode(2)
+        ext.set_fluid_mode(3)
 
 
 def test_rocfft_guard_judges_against_a_global_scale(ext):
@@ -731,7 +778,7 @@ def test_rocfft_guard_judges_against_a_global_scale(ext):
             err = float(np.abs(host(f(dev(m))).astype(np.float64) - want).max() / np.abs(want).max())
             assert err <= 5e-5, ("sinusoid", inverse, err)   # (observed 1.04e-5: rocFFT float32 on a 3 x 2^5 / 5 x 2^3 plane)
     finally:
-        ext.set_fluid_mode(2)
+        ext.set_fluid_mode(3)
 
 
 def test_rocfft_guard_bookkeeping(ext):
@@ -775,7 +822,7 @@ def test_rocfft_guard_bookkeeping(ext):
         met.sharp(md)
         assert ext.fft_plan_state() == (n1 + 1, 2)
     finally:
-        ext.set_fluid_mode(2)
+        ext.set_fluid_mode(3)
 
 
 @pytest.mark.parametrize("batch", [1, 2, 5])

@@ -20,14 +20,23 @@ cases = [
     ("2D f32 16x2x1024^2", (16, 2, 1024, 1024), torch.float32),
     ("2D f64 16x2x1024^2", (16, 2, 1024, 1024), torch.float64),
 ]
+if len(sys.argv) > 1:      # case indices to run (for a per-kernel profile of one shape)
+    cases = [cases[int(i)] for i in sys.argv[1:]]
 met = lm.FluidMetric([0.1, 0.0, 0.01])
+ext = lm.lagomorph_ext
 for name, shape, dt in cases:
     m = torch.randn(shape, device=dev, dtype=dt)
-    with torch.no_grad():
-        t, _ = time_op(lambda: met.sharp(m), reps=10, warm=5)
     nvox = m.numel()           # voxel-components
     esz = m.element_size()
     ideal = nvox * esz * 6.07  # read m, write+read+write+read the half spectrum, write out (per component)
-    print(f"{name:58s}: {t*1e3:8.1f} us  {ideal/t/1e9:5.2f} TB/s of the 6-pass ideal", flush=True)
+    for mode, what in ((3, "tuned / generic hand-written passes"), (2, "tuned passes / rocFFT")):
+        ext.set_fluid_mode(mode)
+        try:
+            with torch.no_grad():
+                t, _ = time_op(lambda: met.sharp(m), reps=10, warm=5)
+            print(f"{name:58s} fluid_mode {mode} ({what:36s}): {t*1e3:8.1f} us  {ideal/t/1e9:5.2f} TB/s of the 6-pass ideal", flush=True)
+        except RuntimeError as e:
+            print(f"{name:58s} fluid_mode {mode}: {str(e)[:120]}", flush=True)
+    ext.set_fluid_mode(3)
     del m
     torch.cuda.empty_cache()

@@ -33,7 +33,7 @@ with torch.no_grad():
     for mode in (0, 1, 2):
         ext.set_fluid_mode(mode)
         print(f"mode {mode}: sharp {timeit(lambda: met.sharp(m)):.3f} ms  flat {timeit(lambda: met.flat(m)):.3f} ms", flush=True)
-    ext.set_fluid_mode(2)
+    ext.set_fluid_mode(3)
     for mask in (1, 2, 4, 7):
         lib.lago_debug_fluid_stage_mask(mask)
         print(f"native stage mask {mask}: sharp {timeit(lambda: met.sharp(m)):.3f} ms", flush=True)
