@@ -143,7 +143,7 @@ def micro_interp_splat(ext, dev, size, batch=8):
         r["pair_Gvoxel_per_s"] = V / pair / 1e6
         res[label] = r
     # HBM bytes per launch of the two kernels from the PMC passes over tools/run_micro.py (same workload, same batch)
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic_micro.json", "r02_traffic_micro.json"))
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_traffic_micro.json", "r03_traffic_micro.json", "r02_traffic_micro.json"))
                   if os.path.exists(q)), "")
     if tpath and size == 128 and batch == 8:
         t = json.load(open(tpath))
@@ -705,7 +705,7 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
             # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
             traffic, tsrc = None, None
-            for tname in ("r03_traffic_expmap.json", "r02_traffic_expmap.json", "r01_traffic.json"):
+            for tname in ("r04_traffic_expmap.json", "r03_traffic_expmap.json", "r02_traffic_expmap.json", "r01_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and B == 32 and S == 128:
                     for name, rec in json.load(open(tpath)).items():
