@@ -518,6 +518,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--no-atlas", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two untimed comparison shoots (all steps through the general kernels; stream split): "
+                         "the profile runs use it, so that a kernel's average in the rocprofv3 summary is over the "
+                         "launches of the timed workload only")
     ap.add_argument("--atlas-size", type=int, default=160)
     ap.add_argument("--atlas-batch", type=int, default=32, help="subjects per atlas update over ALL GPUs")
     ap.add_argument("--atlas-steps", type=int, default=4)
@@ -616,21 +620,23 @@ def main():
         hmax = h.abs().max().item()
         # for comparison, untimed region: the same shoot with every Euler step through the general kernels (an explicit
         # zero phiinv switches off the closed-form first step; same result bit for bit)
-        z = torch.zeros_like(m)
-        lm.expmap(metric, m, num_steps=E, phiinv=z)
-        torch.cuda.synchronize()
-        tg0 = time.perf_counter()
-        for _ in range(min(args.steps, 3)):
-            hg = lm.expmap(metric, m, num_steps=E, phiinv=z)
-        torch.cuda.synchronize()
-        t_general = (time.perf_counter() - tg0) / min(args.steps, 3)
-        same_bits = bool(torch.equal(hg, h))
-        del hg, z
+        t_general, same_bits = None, None
+        if not args.no_extras:
+            z = torch.zeros_like(m)
+            lm.expmap(metric, m, num_steps=E, phiinv=z)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(min(args.steps, 3)):
+                hg = lm.expmap(metric, m, num_steps=E, phiinv=z)
+            torch.cuda.synchronize()
+            t_general = (time.perf_counter() - tg0) / min(args.steps, 3)
+            same_bits = bool(torch.equal(hg, h))
+            del hg, z
         # untimed region as well: the headline shoot cut into two sub-batches on HIP streams of their own (an option of
         # the product, off by default: lagomorph_amd.lddmm.EXPMAP_STREAMS, profiles/r04_stream_split.md)
         from lagomorph_amd import lddmm as _lddmm
         t_split, split_bits = None, None
-        if B >= 4:
+        if B >= 4 and not args.no_extras:
             _lddmm.EXPMAP_STREAMS = 2
             try:
                 for _ in range(2):
@@ -670,8 +676,8 @@ def main():
             "workload": f"lddmm.expmap, {E} Euler steps, global batch {GBATCH} x 3x{S}^3 fp32 sharded {B} per GPU "
                         "(BASELINE configs[3]); value counts voxels x Euler steps; shooting from the identity, the "
                         "first Euler step is evaluated in closed form (-dt sharp(m0): the bits EPDiff_step returns)",
-            "all_steps_through_the_general_kernels": {"ms_per_step": 1e3 * t_general, "local_voxel_steps_per_s":
-                                                      B * S ** 3 * E / t_general, "same_bits": same_bits},
+            "all_steps_through_the_general_kernels": None if t_general is None else {
+                "ms_per_step": 1e3 * t_general, "local_voxel_steps_per_s": B * S ** 3 * E / t_general, "same_bits": same_bits},
             "stream_split": None if t_split is None else {"parts": 2, "ms_per_step": 1e3 * t_split, "same_bits": split_bits,
                                                            "note": "option lddmm.EXPMAP_STREAMS = 2; not the headline"},
             "global_batch": GBATCH, "per_gpu_batch": B, "volume": [S, S, S], "euler_steps": E,

@@ -227,23 +227,24 @@ template __global__ void compose3_window_kernel<GW::NT, 8, false>(float *, const
 std::atomic<int> g_gather_window{1};  // 1: LDS-window gathers where the shape allows (default); 0: pair gathers only
 std::atomic<int> g_tile_cube{1};      // 1: 128^3 / 160^3 volumes take the instantiations with compile-time geometry
 
-// EXPERIMENT (round 4; tools/ab_streams.py): LAGO_EXP_GATHER_PAD=<bytes> makes the gather kernels of
-// the Euler step ask for at least that much LDS, so that only one of their workgroups fits a CU and the FFT passes of
-// ANOTHER stream can co-reside.  Read once; not part of the ABI.  Speed only.
-static size_t exp_gather_pad() {
+// Profiling builds only (-DLAGO_PROFILING; round 4, VERDICT r3 item 2, tools/ab_streams.py): LAGO_EXP_GATHER_PAD=<bytes>
+// makes the gather kernels of the Euler step ask for at least that much LDS, so that only one of their workgroups fits a
+// CU and the FFT passes of ANOTHER stream can co-reside (measured: 30 % slower, profiles/r04_stream_split.md).  The
+// product library reads no environment variable here.
+template <typename K>
+static size_t padded_smem(K k, size_t smem) {
+#ifdef LAGO_PROFILING
     static const size_t pad = [] {
         const char *e = getenv("LAGO_EXP_GATHER_PAD");
         return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)0;
     }();
-    return pad;
-}
-template <typename K>
-static size_t padded_smem(K k, size_t smem) {
-    const size_t pad = exp_gather_pad();
     if (pad > smem) {
         smem = pad;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
+#else
+    (void)k;
+#endif
     return smem;
 }
 

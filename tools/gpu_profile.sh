@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$repo" || exit 1
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
-B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-micro --no-atlas"
+B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-micro --no-atlas --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/expmap_trace -- $B > $out/bench_trace.json 2> $out/bench_trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/expmap_fetch -- $B > /dev/null 2> $out/expmap_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/expmap_write -- $B > /dev/null 2> $out/expmap_write.err
