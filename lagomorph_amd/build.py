@@ -23,6 +23,8 @@ LIB = os.path.join(LIBDIR, "liblagomorph_hip.so")
 LIB_PROF = os.path.join(LIBDIR, "liblagomorph_hip_prof.so")
 SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip", "fftg.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# extra compiler flags for A/B builds of tools/ (e.g. LAGO_HIPCC_EXTRA="-DLAGO_NT_X_LD=1"; use -f: objects are not keyed on flags)
+EXTRA = os.environ.get("LAGO_HIPCC_EXTRA", "").split()
 FLAGS = [
     "-O3",
     "--offload-arch=gfx950",
@@ -52,7 +54,7 @@ def _compile(src, force, verbose, profiling=False):
     path = os.path.join(CSRC, src)
     if not force and not _stale(obj, [path] + _deps()):
         return obj
-    cmd = [HIPCC] + FLAGS + (["-DLAGO_PROFILING"] if profiling else []) + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA + (["-DLAGO_PROFILING"] if profiling else []) + ["-c", path, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

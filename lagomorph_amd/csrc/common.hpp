@@ -236,6 +236,20 @@ typedef unsigned int lg_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ BufRsrc make_rsrc(const void *base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
+// A store with a cache policy chosen at build time: NT = 1 marks it non-temporal (streamed through the L2, evicted
+// first), which keeps a kernel's own output from displacing the lines its gathers / stencil neighbours re-read
+// (profiles/r04_cache_policy.md).
+template <int NT, typename R>
+__device__ __forceinline__ R ld_pol(const R *p) {   // (the same for a load of data that is read once)
+    if constexpr (NT != 0) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int NT, typename R>
+__device__ __forceinline__ void st_pol(R *p, R v) {
+    if constexpr (NT != 0) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 template <typename R>
 __device__ __forceinline__ R buf_load1(BufRsrc r, uint32_t off);
 template <>

@@ -13,6 +13,16 @@
 // of one XCD walk a contiguous range, common.hpp).
 #include "common.hpp"
 
+// Output stores of the stencil kernels (common.hpp: st_pol; profiles/r04_cache_policy.md): non-temporal for the two
+// backward kernels (jtv_bwd -6 %, jtv_adj_bwd -3 %: their outputs no longer displace the +-1 slab neighbours in the
+// L2), plain for the forward ones (jtv_adj_fwd measured 4 % slower with it)
+#ifndef LAGO_NT_STENCIL_BWD_ST
+#define LAGO_NT_STENCIL_BWD_ST 1
+#endif
+#ifndef LAGO_NT_STENCIL_FWD_ST
+#define LAGO_NT_STENCIL_FWD_ST 0
+#endif
+
 namespace lago {
 
 // Signed element offsets of the clamped +-1 neighbours along the DIM axes, the
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void jtv_fwd_kernel(R *__restrict__ out, co
             for (int d = 0; d < DIM; ++d) acc[d] = c == 0 ? gq[d] * wv[c] : lg_fma(gq[d], wv[c], acc[d]);
         }
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) on[(size_t)d * nv] = acc[d];
+        for (int d = 0; d < DIM; ++d) st_pol<LAGO_NT_STENCIL_FWD_ST>(&on[(size_t)d * nv], (R)(acc[d]));
     } else {
         for (int c = 0; c < nc; ++c) {
             st.grad(vn + (size_t)c * nv, gq);
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void jtv_fwd_kernel(R *__restrict__ out, co
                 for (int d = 0; d < DIM; ++d)
                     if (c == d) gq[d] = gq[d] + (R)1.0;
             }
-            on[(size_t)c * nv] = dotw<R, DIM>(gq, wv);
+            st_pol<LAGO_NT_STENCIL_FWD_ST>(&on[(size_t)c * nv], (R)(dotw<R, DIM>(gq, wv)));
         }
     }
 }
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
         for (int c = 0; c < DIM; ++c) {
             st.grad(vn + (size_t)c * nv, gq);
             if (DISP) gq[c] = gq[c] + (R)1.0;
-            dwn[(size_t)c * nv] = (R)0 + dotw<R, DIM>(gq, gov);
+            st_pol<LAGO_NT_STENCIL_BWD_ST>(&dwn[(size_t)c * nv], (R)((R)0 + dotw<R, DIM>(gq, gov)));
         }
         Nb<R, DIM> W[DIM], G[DIM];
 #pragma unroll
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
 #pragma unroll
             for (int d = 0; d < DIM; ++d)
                 acc = acc + st.dTv(W[c].c0, W[c].p[d], W[c].m[d], G[d].c0, G[d].p[d], G[d].m[d], d);
-            dvn[(size_t)c * nv] = acc_v ? dvn[(size_t)c * nv] + acc : acc;
+            st_pol<LAGO_NT_STENCIL_BWD_ST>(&dvn[(size_t)c * nv], (R)(acc_v ? dvn[(size_t)c * nv] + acc : acc));
         }
     } else {
         R dw[DIM];
@@ -183,10 +193,10 @@ __global__ __launch_bounds__(kBlock) void jtv_bwd_kernel(R *__restrict__ d_v, R 
             R acc = 0;
 #pragma unroll
             for (int d = 0; d < DIM; ++d) acc = acc + st.dTv(W[d].c0, W[d].p[d], W[d].m[d], G.c0, G.p[d], G.m[d], d);
-            dvn[(size_t)c * nv] = acc_v ? dvn[(size_t)c * nv] + acc : acc;
+            st_pol<LAGO_NT_STENCIL_BWD_ST>(&dvn[(size_t)c * nv], (R)(acc_v ? dvn[(size_t)c * nv] + acc : acc));
         }
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) dwn[(size_t)d * nv] = dw[d];
+        for (int d = 0; d < DIM; ++d) st_pol<LAGO_NT_STENCIL_BWD_ST>(&dwn[(size_t)d * nv], (R)(dw[d]));
     }
 }
 
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void jtv_adj_fwd_kernel(R *__restrict__ out
         R acc = 0;
 #pragma unroll
         for (int d = 0; d < DIM; ++d) acc = acc + st.dTv(W[d].c0, W[d].p[d], W[d].m[d], Z.c0, Z.p[d], Z.m[d], d);
-        on[(size_t)c * nv] = acc;
+        st_pol<LAGO_NT_STENCIL_FWD_ST>(&on[(size_t)c * nv], (R)(acc));
     }
 }
 
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void ad_star_small_kernel(R *__restrict__ o
         R b = 0;
 #pragma unroll
         for (int d = 0; d < DIM; ++d) b = b + st.dTv(V[d].c0, V[d].p[d], V[d].m[d], M[c].c0, M[c].p[d], M[c].m[d], d);
-        on[(size_t)c * nv] = a[c] - b;
+        st_pol<LAGO_NT_STENCIL_FWD_ST>(&on[(size_t)c * nv], (R)(a[c] - b));
     }
 }
 
@@ -275,10 +285,10 @@ __global__ __launch_bounds__(kBlock) void jtv_adj_bwd_kernel(R *__restrict__ d_v
         const R vc = vn[(size_t)c * nv];
 #pragma unroll
         for (int d = 0; d < DIM; ++d) dw[d] = c == 0 ? gq[d] * vc : lg_fma(gq[d], vc, dw[d]);
-        dvn[(size_t)c * nv] = (R)0 + dotw<R, DIM>(gq, wv);
+        st_pol<LAGO_NT_STENCIL_BWD_ST>(&dvn[(size_t)c * nv], (R)((R)0 + dotw<R, DIM>(gq, wv)));
     }
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) dwn[(size_t)d * nv] = dw[d];
+    for (int d = 0; d < DIM; ++d) st_pol<LAGO_NT_STENCIL_BWD_ST>(&dwn[(size_t)d * nv], (R)(dw[d]));
 }
 
 // ------------------------------------------------------------------ host entry points

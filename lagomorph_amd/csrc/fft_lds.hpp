@@ -35,6 +35,52 @@
 #include <stdint.h>
 
 namespace lago {
+
+// Cache policy of the passes' global traffic (read once / written once per pass).  LAGO_NT_* = 1 marks the access
+// non-temporal (`nt`: streamed through the L2, evicted first) -- build-time switches for the A/B of
+// profiles/r04_cache_policy.md; the defaults are what that measurement kept.
+#ifndef LAGO_NT_X_LD
+#define LAGO_NT_X_LD 0
+#endif
+#ifndef LAGO_NT_X_ST
+#define LAGO_NT_X_ST 1
+#endif
+#ifndef LAGO_NT_ZF_LD
+#define LAGO_NT_ZF_LD 0
+#endif
+#ifndef LAGO_NT_ZF_ST
+#define LAGO_NT_ZF_ST 0
+#endif
+#ifndef LAGO_NT_ZI_LD
+#define LAGO_NT_ZI_LD 0
+#endif
+#ifndef LAGO_NT_ZI_ST
+#define LAGO_NT_ZI_ST 0
+#endif
+typedef float lg_f32x4_t __attribute__((ext_vector_type(4)));
+template <int NT>
+__host__ __device__ __forceinline__ float4 ldg4(const float4 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (NT != 0) {
+        const lg_f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const lg_f32x4_t *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+#endif
+    return *p;
+}
+template <int NT>
+__host__ __device__ __forceinline__ void stg4(float4 *p, float4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (NT != 0) {
+        lg_f32x4_t w;
+        w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+        __builtin_nontemporal_store(w, reinterpret_cast<lg_f32x4_t *>(p));
+        return;
+    }
+#endif
+    *p = v;
+}
+
 namespace fl {
 
 #define LAGO_HD __host__ __device__ __forceinline__
@@ -401,7 +447,7 @@ struct XPass {
     // persistent workgroup can request its next tile while it transforms the current one (fft3.hip).
     LAGO_HD static void load_one(int tid, const Block &b, float4 (&v)[KLD], int k) {
         const int rg = tid >> 3, l8 = tid & 7;
-        v[k] = *reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8);
+        v[k] = ldg4<LAGO_NT_X_LD>(reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8));
     }
     LAGO_HD static void load_coef(int tid, Regs &r, const Block &b) {
         const int kc = tid & (KL - 1), row0 = tid / KL;
@@ -462,8 +508,8 @@ struct XPass {
             for (int k = 0; k < KLD; ++k) {
                 const float2 *s = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
                 const float2 a = s[0], c = s[1];
-                *reinterpret_cast<float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8) =
-                    make_float4(a.x, a.y, c.x, c.y);
+                stg4<LAGO_NT_X_ST>(reinterpret_cast<float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8),
+                                   make_float4(a.x, a.y, c.x, c.y));
             }
         }
     }
@@ -523,7 +569,7 @@ struct ZY {
     LAGO_HD static void fwd_load(int tid, const float *in, float4 (&v)[KV]) {
 #pragma unroll
         for (int k = 0; k < KV; ++k)
-            if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(in)[tid + k * NT];
+            if (tid + k * NT < F4) v[k] = ldg4<LAGO_NT_ZF_LD>(reinterpret_cast<const float4 *>(in) + (tid + k * NT));
     }
     LAGO_HD static void fwd_fill(int tid, const float4 (&v)[KV], float2 *P) {
         // a row of NZ reals is NZH complex z[j] = (x[2j], x[2j+1]) as it lies in memory
@@ -551,7 +597,7 @@ struct ZY {
     LAGO_HD static void inv_load(int tid, const float2 *mainp, const float2 *nyqp, float4 (&v)[KVX]) {
 #pragma unroll
         for (int k = 0; k < KV; ++k)
-            if (tid + k * NT < F4) v[k] = reinterpret_cast<const float4 *>(mainp)[tid + k * NT];
+            if (tid + k * NT < F4) v[k] = ldg4<LAGO_NT_ZI_LD>(reinterpret_cast<const float4 *>(mainp) + (tid + k * NT));
         inv_load_c0(tid, mainp, nyqp, v);
     }
     LAGO_HD static void inv_fill(int tid, const float4 (&v)[KVX], float2 *P) {
@@ -633,7 +679,7 @@ struct ZY {
                 const int e = (tid + k * NT) * 2, r = e / NZH, c = e % NZH;
                 const float2 *row = P + r * PZ;
                 const float2 a = row[c], cc = row[c + 1];
-                reinterpret_cast<float4 *>(mainp)[tid + k * NT] = make_float4(a.x, a.y, cc.x, cc.y);
+                stg4<LAGO_NT_ZF_ST>(reinterpret_cast<float4 *>(mainp) + (tid + k * NT), make_float4(a.x, a.y, cc.x, cc.y));
             }
             for (int r = tid; r < NY; r += NT) nyqp[r] = P[r * PZ + NZH];
         }
@@ -679,7 +725,7 @@ struct ZY {
                 if (tid + k * NT >= F4) continue;
                 const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
                 const float2 a = P[y * PZ + j], c = P[y * PZ + j + 1];
-                reinterpret_cast<float4 *>(out)[tid + k * NT] = make_float4(a.x, a.y, c.x, c.y);
+                stg4<LAGO_NT_ZI_ST>(reinterpret_cast<float4 *>(out) + (tid + k * NT), make_float4(a.x, a.y, c.x, c.y));
             }
         }
     }

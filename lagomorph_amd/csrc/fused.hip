@@ -116,6 +116,13 @@ __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__
 // LDS-window variant (gather_window.hpp): the three channels of v go through one 48 KB window in turn.
 // Same expressions as compose3_unroll_kernel; samples whose corners leave the window take them with that kernel's
 // pair gathers.
+#ifndef LAGO_NT_AD_ST
+#define LAGO_NT_AD_ST 1   // Ad_star output non-temporal: -3 % on the kernel (profiles/r04_cache_policy.md)
+#endif
+#ifndef LAGO_COMPOSE_AUX_LD
+#define LAGO_COMPOSE_AUX_LD 0
+#define LAGO_COMPOSE_AUX_ST 0
+#endif
 template <int NT, int U, bool UNIT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void compose3_window_kernel(
     float *__restrict__ out, const float *__restrict__ u, const float *__restrict__ v, double ds, double dt, Geom g, GWGrid w) {
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (int e = 0; e < U; ++e) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) uu[d][e] = buf_load1<float>(make_rsrc(un + (size_t)d * nv, plane), voff(e));
+            for (int d = 0; d < 3; ++d)
+                uu[d][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(un + (size_t)d * nv, plane), voff(e), 0, LAGO_COMPOSE_AUX_LD));
         }
 #pragma unroll
         for (int e = 0; e < U; ++e) {
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 // stored at once: holding the eight results back until the next window's loads are issued (one wait
                 // for both) cost four spilled values -- 134 MB of scratch writes per launch at 32 x 3 x 128^3, 11 % of
                 // the kernel's time
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a + b), ro, voff(e), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, a + b), ro, voff(e), 0, LAGO_COMPOSE_AUX_ST);
             }
             if (c < 2) {
                 __syncthreads();  // everyone has read channel c: the window is free
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(NT) void ad_star3_tile_kernel(R *__restrict__ out, 
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int e = 0; e < U; ++e)
-                if (q[e].ok) mo[(size_t)d * nv + q[e].s] = wv[d][e];
+                if (q[e].ok) st_pol<LAGO_NT_AD_ST>(&mo[(size_t)d * nv + q[e].s], wv[d][e]);
     }
     __syncthreads();
     const uint32_t sy = (uint32_t)t.P, sx = (uint32_t)t.RY * (uint32_t)t.P;
@@ -573,7 +581,9 @@ __global__ __launch_bounds__(NT) void ad_star3_tile_kernel(R *__restrict__ out, 
         }
 #pragma unroll
         for (int e = 0; e < U; ++e)
-            if (q[e].ok) on[(size_t)c * nv + q[e].s] = sacc[e];
+            if (q[e].ok) {
+                st_pol<LAGO_NT_AD_ST>(&on[(size_t)c * nv + q[e].s], sacc[e]);
+            }
     }
 }
 

@@ -8,6 +8,13 @@
 #include "common.hpp"
 #include "gather_window.hpp"
 
+#ifndef LAGO_NT_INTERP_LD
+#define LAGO_NT_INTERP_LD 0
+#endif
+#ifndef LAGO_NT_INTERP_ST
+#define LAGO_NT_INTERP_ST 1   // forward outputs non-temporal: C = 1 forward 82 -> 73 us at 8 x 128^3 (profiles/r04_cache_policy.md)
+#endif
+
 namespace lago {
 
 // ------------------------------------------------------------------ forward
@@ -63,9 +70,9 @@ __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restric
         s[e] = (bx * U + e) * kBlock + threadIdx.x;
         ok[e] = s[e] < g.nvox;
         if (!ok[e]) s[e] = 0;
-        ux[e] = un[s[e]];
-        uy[e] = un[nv + s[e]];
-        uz[e] = un[2 * nv + s[e]];
+        ux[e] = ld_pol<LAGO_NT_INTERP_LD>(un + s[e]);
+        uy[e] = ld_pol<LAGO_NT_INTERP_LD>(un + nv + s[e]);
+        uz[e] = ld_pol<LAGO_NT_INTERP_LD>(un + 2 * nv + s[e]);
     }
     Lerp3<R, false> L[U];  // nz >= 2 guaranteed by the host: no per-sample thin branch
     uint32_t ci = 0, cj = 0, ck = 0;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void interp_fwd3_unroll_kernel(R *__restric
         for (int e = 0; e < U; ++e) o[e] = L[e].value(Ic);
 #pragma unroll
         for (int e = 0; e < U; ++e)
-            if (ok[e]) on[(size_t)c * nv + s[e]] = o[e];
+            if (ok[e]) st_pol<LAGO_NT_INTERP_ST>(&on[(size_t)c * nv + s[e]], o[e]);
     }
 }
 
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         }
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ro, voff(e), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ro, voff(e), 0, LAGO_NT_INTERP_ST ? 2 : 0);
             }
             if (c + 1 < nc) {
                 __syncthreads();  // everyone has read channel c: the window is free

@@ -35,6 +35,16 @@
 // the reference's thread-owned accumulation.
 #include "common.hpp"
 
+#ifndef LAGO_NT_SPLAT_LD
+#define LAGO_NT_SPLAT_LD 1   // grad_out and u of the C = 1 sheared splat are read once: -1.9 % (profiles/r04_cache_policy.md)
+#endif
+#ifndef LAGO_NT_SPLAT_MC_LD
+#define LAGO_NT_SPLAT_MC_LD 1   // the same in the multi-channel form: interp_backward C = 3 -1.6 %
+#endif
+#ifndef LAGO_NT_SPLAT_ST
+#define LAGO_NT_SPLAT_ST 1   // d_u stores non-temporal: -1.3 % (profiles/r04_cache_policy.md)
+#endif
+
 namespace lago {
 
 // How a source voxel's sample position is obtained.
@@ -498,10 +508,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
             if ((int)a >= ex || (int)b >= ey || (int)kk >= ez) continue;
             const int vi = x0 + a, vj = y0 + b, vk = z0 + kk;
             const uint32_t sv = ((uint32_t)vi * ny + vj) * nz + vk;
-            const float gv = gc[sv];
-            const float hx = shear_pos<UNIT>(vi, dt, un[sv]);
-            const float hy = shear_pos<UNIT>(vj, dt, un[sv + nv]);
-            const float hz = shear_pos<UNIT>(vk, dt, un[sv + 2 * (size_t)nv]);
+            const float gv = ld_pol<LAGO_NT_SPLAT_LD>(gc + sv);
+            const float hx = shear_pos<UNIT>(vi, dt, ld_pol<LAGO_NT_SPLAT_LD>(un + sv));
+            const float hy = shear_pos<UNIT>(vj, dt, ld_pol<LAGO_NT_SPLAT_LD>(un + sv + nv));
+            const float hz = shear_pos<UNIT>(vk, dt, ld_pol<LAGO_NT_SPLAT_LD>(un + sv + 2 * (size_t)nv));
             const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
             const float t = hx - (float)fx, uu = hy - (float)fy, v = hz - (float)fz;
             const float omt = 1.f - t, omu = 1.f - uu, omv = 1.f - v;
@@ -597,7 +607,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
                 if (VPL > 0 && c + 1 < nc) {
                     rux[it % NV] = ix; ruy[it % NV] = iy; ruz[it % NV] = iz;
                 } else {
-                    dun[sv] = ix; dun[sv + nv] = iy; dun[sv + 2 * (size_t)nv] = iz;
+                    st_pol<LAGO_NT_SPLAT_ST>(&dun[sv], ix); st_pol<LAGO_NT_SPLAT_ST>(&dun[sv + nv], iy); st_pol<LAGO_NT_SPLAT_ST>(&dun[sv + 2 * (size_t)nv], iz);
                 }
             }
         }
@@ -712,9 +722,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
         const int vi = x0 + a, vj = y0 + b, vk = z0 + kk;
         const uint32_t sv = ((uint32_t)vi * ny + vj) * nz + vk;
         SV[it] = sv;
-        const float hx = shear_pos<UNIT>(vi, dt, un[sv]);
-        const float hy = shear_pos<UNIT>(vj, dt, un[sv + nv]);
-        const float hz = shear_pos<UNIT>(vk, dt, un[sv + 2 * (size_t)nv]);
+        const float hx = shear_pos<UNIT>(vi, dt, ld_pol<LAGO_NT_SPLAT_MC_LD>(un + sv));
+        const float hy = shear_pos<UNIT>(vj, dt, ld_pol<LAGO_NT_SPLAT_MC_LD>(un + sv + nv));
+        const float hz = shear_pos<UNIT>(vk, dt, ld_pol<LAGO_NT_SPLAT_MC_LD>(un + sv + 2 * (size_t)nv));
         const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
         FT[it] = hx - (float)fx;
         FU[it] = hy - (float)fy;
@@ -760,7 +770,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
     auto request_gv = [&](int c) {
         const BufRsrc rg = make_rsrc(gon + (size_t)c * nv, planeB);
 #pragma unroll
-        for (int it = 0; it < VPL; ++it) pgv[it] = buf_load1<float>(rg, SV[it] == DEAD ? DEAD : SV[it] * 4u);
+        for (int it = 0; it < VPL; ++it)
+            pgv[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, SV[it] == DEAD ? DEAD : SV[it] * 4u, 0, LAGO_NT_SPLAT_MC_LD ? 2 : 0));
     };
     request_gv(0);
     for (int c = 0; c < nc; ++c) {
@@ -910,7 +921,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
 #pragma unroll
     for (int it = 0; it < VPL; ++it)
         if (SV[it] != DEAD) {
-            dun[SV[it]] = rux[it]; dun[SV[it] + nv] = ruy[it]; dun[SV[it] + 2 * (size_t)nv] = ruz[it];
+            st_pol<LAGO_NT_SPLAT_ST>(&dun[SV[it]], rux[it]); st_pol<LAGO_NT_SPLAT_ST>(&dun[SV[it] + nv], ruy[it]); st_pol<LAGO_NT_SPLAT_ST>(&dun[SV[it] + 2 * (size_t)nv], ruz[it]);
         }
 }
 
