@@ -15,6 +15,10 @@
 
 #include "common.hpp"
 
+#ifndef LAGO_NT_AFFINE_ST
+#define LAGO_NT_AFFINE_ST 0
+#endif
+
 namespace lago {
 
 // splat.hip
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out,
         const R hz = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
         Lerp3<R> L;
         L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
-        for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
+        for (int c = 0; c < nc; ++c) st_pol<LAGO_NT_AFFINE_ST>(&on[(size_t)c * nv], L.value(In + (size_t)c * nv));
     } else {
         const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
         const R fi = (R)v.j - ox, fj = (R)v.k - oy;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out,
         const R hy = lg_fma(An[2], fi, An[3] * fj) + Tn[1] + oy;
         Lerp2<R> L;
         L.setup(hx, hy, g.ny, g.nz);
-        for (int c = 0; c < nc; ++c) on[(size_t)c * nv] = L.value(In + (size_t)c * nv);
+        for (int c = 0; c < nc; ++c) st_pol<LAGO_NT_AFFINE_ST>(&on[(size_t)c * nv], L.value(In + (size_t)c * nv));
     }
 }
 
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out,
         for (int k = 0; k < v.k; ++k) hz += Sz;
         Lerp3<R> L;
         L.setup(hx, hy, hz, rp.nx, rp.ny, rp.nz);
-        for (int q = 0; q < nq; ++q) out[(size_t)q * Nv + v.s] = L.value(I + (size_t)q * nvin);
+        for (int q = 0; q < nq; ++q) st_pol<LAGO_NT_AFFINE_ST>(&out[(size_t)q * Nv + v.s], L.value(I + (size_t)q * nvin));
     } else {
         const R Ox = (R)rp.O[0], Oy = (R)rp.O[1];
         const R Sx = (R)rp.S[0], Sy = (R)rp.S[1];
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out,
         const R hy = lg_fma((R)v.k - oy, Sy, Oy);
         Lerp2<R> L;
         L.setup(hx, hy, rp.ny, rp.nz);
-        for (int q = 0; q < nq; ++q) out[(size_t)q * Nv + v.s] = L.value(I + (size_t)q * nvin);
+        for (int q = 0; q < nq; ++q) st_pol<LAGO_NT_AFFINE_ST>(&out[(size_t)q * Nv + v.s], L.value(I + (size_t)q * nvin));
     }
 }
 

@@ -19,6 +19,11 @@
 #ifndef LAGO_NT_STENCIL_BWD_ST
 #define LAGO_NT_STENCIL_BWD_ST 1
 #endif
+// jtv_adj_bwd reads v and w at the centre voxel only (once): non-temporal loads -9.5 % (185 -> 167 us at 8 x 3 x 128^3);
+// the same for w in jtv_fwd: nothing
+#ifndef LAGO_NT_ADJB_LD
+#define LAGO_NT_ADJB_LD 1
+#endif
 #ifndef LAGO_NT_STENCIL_FWD_ST
 #define LAGO_NT_STENCIL_FWD_ST 0
 #endif
@@ -278,11 +283,11 @@ __global__ __launch_bounds__(kBlock) void jtv_adj_bwd_kernel(R *__restrict__ d_v
     R *dvn = d_v + base, *dwn = d_w + base;
     R wv[DIM], dw[DIM], gq[DIM];
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) wv[d] = wn[(size_t)d * nv];
+    for (int d = 0; d < DIM; ++d) wv[d] = ld_pol<LAGO_NT_ADJB_LD>(wn + (size_t)d * nv);
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
         st.grad(gon + (size_t)c * nv, gq);
-        const R vc = vn[(size_t)c * nv];
+        const R vc = ld_pol<LAGO_NT_ADJB_LD>(vn + (size_t)c * nv);
 #pragma unroll
         for (int d = 0; d < DIM; ++d) dw[d] = c == 0 ? gq[d] * vc : lg_fma(gq[d], vc, dw[d]);
         st_pol<LAGO_NT_STENCIL_BWD_ST>(&dvn[(size_t)c * nv], (R)((R)0 + dotw<R, DIM>(gq, wv)));

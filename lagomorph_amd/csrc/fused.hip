@@ -120,8 +120,10 @@ __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__
 #define LAGO_NT_AD_ST 1   // Ad_star output non-temporal: -3 % on the kernel (profiles/r04_cache_policy.md)
 #endif
 #ifndef LAGO_COMPOSE_AUX_LD
-#define LAGO_COMPOSE_AUX_LD 0
-#define LAGO_COMPOSE_AUX_ST 0
+// the window compose reads u once and writes once: both non-temporal (2 = nt) -4.7 % on the kernel, -0.9 % on the
+// shoot; either one alone: nothing (profiles/r04_cache_policy.md)
+#define LAGO_COMPOSE_AUX_LD 2
+#define LAGO_COMPOSE_AUX_ST 2
 #endif
 template <int NT, int U, bool UNIT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void compose3_window_kernel(
