@@ -116,6 +116,9 @@ __global__ __launch_bounds__(kBlock) void compose3_unroll_kernel(R *__restrict__
 // LDS-window variant (gather_window.hpp): the three channels of v go through one 48 KB window in turn.
 // Same expressions as compose3_unroll_kernel; samples whose corners leave the window take them with that kernel's
 // pair gathers.
+#ifndef LAGO_NT_AD_LD
+#define LAGO_NT_AD_LD 0
+#endif
 #ifndef LAGO_NT_AD_ST
 #define LAGO_NT_AD_ST 1   // Ad_star output non-temporal: -3 % on the kernel (profiles/r04_cache_policy.md)
 #endif
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(NT) void ad_star3_tile_kernel(R *__restrict__ out, 
     for (int e = 0; e < U; ++e) {
         q[e] = tile_voxel(t, g, x0, y0, threadIdx.x + (uint32_t)e * NT);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) pv[d][e] = pn[(size_t)d * nv + q[e].s];
+        for (int d = 0; d < 3; ++d) pv[d][e] = ld_pol<LAGO_NT_AD_LD>(pn + (size_t)d * nv + q[e].s);
     }
     TileHalo<R, NT, 3, RI, ZC> halo;
     halo.issue(pn, nv, t, g, x0, y0);

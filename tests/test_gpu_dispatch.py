@@ -63,6 +63,21 @@ def test_fluid_metric_dispatch(lm, sp, path):
         assert list(took) in (["fluid_rocfft"], ["fluid_xpass"]), took
 
 
+def test_extents_above_the_generic_passes_take_the_guarded_rocfft_path(lm):
+    """csrc/fftg.hip holds a line of at most 2048 points in LDS: a longer axis (2D, 4096 x 8) is the one shape class the
+    default mode still hands to rocFFT (spot-checked) -- and the answer is the oracle's."""
+    import numpy as np
+    from oracle import lago_oracle as orc
+
+    metric = lm.FluidMetric([0.1, 0.0, 0.01])
+    m = _fields(1, 2, (4096, 8))
+    took = _delta(lm.lagomorph_ext, lambda: metric.sharp(m))
+    assert list(took) == ["fluid_rocfft"], took
+    want = orc.fluid_metric_apply(m.cpu().numpy(), [0.1, 0.0, 0.01], True)
+    got = metric.sharp(m).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
 def test_the_switches_select_the_slower_siblings(lm):
     shim = lm.lagomorph_ext
     sp = (32, 32, 32)
