@@ -10,15 +10,20 @@
 //     in memory: coalesced rows; L from lines_pass),
 //   * runs a Stockham autosort FFT with the radices of N's factorisation (4 where it divides, then the primes
 //     ascending).  Radices 2, 3, 4, 5, 7: one whole butterfly per thread in registers (r LDS reads, r writes, r - 1
-//     twiddles); any other prime: one output per thread, a direct r-point DFT -- so ANY extent works,
+//     twiddles); any other prime: one output per thread, a direct r-point DFT -- so ANY extent works; a line whose
+//     length has a prime factor of 29 or more goes through Bluestein's identity instead (chirp, two power-of-two
+//     transforms of M >= 2 N - 1 points, a cached table): 182 x 218 x 182 and 193 x 229 x 193 volumes 2 - 5x faster,
 //   * one table of the N-th roots per workgroup (sincospi of the exactly reduced argument, in double for float64 lines
 //     and in float for float32 ones); stage twiddles and the r-th roots are strided reads of it,
 //   * the real axis packs TWO real lines into one complex line (a + i b) and separates / rebuilds the two half spectra
 //     by conjugate symmetry; pairs never cross a field, so a batch item's bits do not depend on its neighbours.
-// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.97 - 1.7x its time.
+// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.8 - 1.8x its time.
 // The per-frequency operator between the passes is metric.hip's fluid_kernel, the same as on the rocFFT path, with
 // the 1/N of the unnormalised transform pair folded in.  Layout of the half spectrum: [n][c][x][y][z <= nz/2] complex,
 // what rocFFT's R2C produces, so the operator kernel does not know which path ran.
+#include <map>
+#include <tuple>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -78,6 +83,10 @@ struct GLines {
     int fac[20];
     FastDiv dinner, dN, dL, dnhalf, dchunks;
     FastDiv ds[20], dr[20];   // per stage: division by the stride s and by the radix r
+    // Bluestein (M > 0): the N-point transform as a circular convolution of length M = 2^k >= 2 N - 1; fac / ds then
+    // describe the M-point transform (radix 4 and 2 only) and bhat is FFT_M of the conjugate chirp, 1 / M folded in
+    int M;
+    const void *bhat;
 };
 
 // line l of a mode-0 launch: element offset of its first point
@@ -93,9 +102,9 @@ __device__ __forceinline__ size_t gline_base(const GLines &a, uint32_t l, int n_
 // broadcast.
 template <typename R, int RR>
 __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *__restrict__ y, const GC<R> *__restrict__ W,
-                                            const GLines &a, int nl, int s, int m, FastDiv ds) {
+                                            const GLines &a, int N, int sgn, int nl, int s, int m, FastDiv ds) {
     typedef GC<R> C;
-    const int N = a.N, Lp = a.Lp, L = a.L;
+    const int Lp = a.Lp, L = a.L;
     C wr[RR];
     if (RR != 2 && RR != 4) {
 #pragma unroll
@@ -114,7 +123,7 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
             o[0] = cadd(v[0], v[1]);
             o[1] = csub(v[0], v[1]);
         } else if (RR == 4) {
-            const C e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]), o0 = cadd(v[1], v[3]), o1 = cmuli(csub(v[1], v[3]), a.sign);
+            const C e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]), o0 = cadd(v[1], v[3]), o1 = cmuli(csub(v[1], v[3]), sgn);
             o[0] = cadd(e0, o0);
             o[1] = cadd(e1, o1);
             o[2] = csub(e0, o0);
@@ -142,9 +151,9 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
 // any other radix (the primes from 11 up): one output per thread, an r-point direct DFT
 template <typename R>
 __device__ __forceinline__ void stage_any(const GC<R> *__restrict__ x, GC<R> *__restrict__ y, const GC<R> *__restrict__ W,
-                                          const GLines &a, int nl, int r, int s, int m, FastDiv ds, FastDiv dr) {
+                                          const GLines &a, int N, int nl, int r, int s, int m, FastDiv ds, FastDiv dr) {
     typedef GC<R> C;
-    const int N = a.N, Lp = a.Lp, L = a.L, wstep = N / r;
+    const int Lp = a.Lp, L = a.L, wstep = N / r;
     for (int i = threadIdx.x; i < N * L; i += kBlock) {
         const int yi = (int)a.dL.div((uint32_t)i), ln = i - yi * L;
         if (ln >= nl) continue;
@@ -164,13 +173,75 @@ __device__ __forceinline__ void stage_any(const GC<R> *__restrict__ x, GC<R> *__
     }
 }
 
+// All Stockham stages of an NP-point transform (factors a.fac, roots W of sign sgn) on the workgroup's lines; returns
+// the buffer that holds the result (x and y alternate).  Begins with a barrier (the caller's writes to x and W) and
+// ends with one.
+template <typename R>
+__device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W, const GLines &a, int NP, int sgn, int nl) {
+    int n = NP, s = 1;
+    for (int f = 0; f < a.nfac; ++f) {
+        const int r = a.fac[f], m = n / r;
+        __syncthreads();
+        switch (r) {
+            case 2: stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+            case 3: stage_fixed<R, 3>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+            case 4: stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+            case 5: stage_fixed<R, 5>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+            case 7: stage_fixed<R, 7>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+            default: stage_any<R>(x, y, W, a, NP, nl, r, s, m, a.ds[f], a.dr[f]); break;
+        }
+        GC<R> *tmp = x; x = y; y = tmp;
+        n = m;
+        s *= r;
+    }
+    __syncthreads();
+    return x;
+}
+
+// exp(sign pi i n^2 / N): the chirp of Bluestein's identity n k = (n^2 + k^2 - (k - n)^2) / 2, the argument reduced
+// exactly (n^2 mod 2 N in integers)
+template <typename R>
+__device__ __forceinline__ GC<R> chirp(int n, int N, int sign) {
+    const unsigned long long q = ((unsigned long long)n * (unsigned long long)n) % (2ull * (unsigned long long)N);
+    if constexpr (sizeof(R) == 8) {
+        double sn, cs;
+        sincospi((double)q / (double)N, &sn, &cs);
+        return {cs, (double)sign * sn};
+    } else {
+        float sn, cs;
+        sincospif((float)((double)q / (double)N), &sn, &cs);
+        return {cs, (float)sign * sn};
+    }
+}
+
+// bhat[k] = FFT_M(d)[k] / M with d[m] = conj(chirp)(|m|) for |m| < N (indices mod M), 0 elsewhere: one workgroup, once
+// per (N, sign, precision) -- lines_pass caches the table
+template <typename R>
+__global__ __launch_bounds__(kBlock) void bluestein_table_kernel(GC<R> *__restrict__ bhat, GLines a) {
+    extern __shared__ __align__(16) unsigned char lago_fg[];
+    typedef GC<R> C;
+    const int N = a.N, M = a.M;
+    C *x = reinterpret_cast<C *>(lago_fg), *y = x + M, *W = y + M;   // (a.L = a.Lp = 1)
+    for (int k = threadIdx.x; k < M; k += kBlock) {
+        W[k] = root<R>(k, M, -1);
+        const int idx = k < N ? k : (M - k < N ? M - k : -1);
+        C d = {(R)0, (R)0};
+        if (idx >= 0) { d = chirp<R>(idx, N, a.sign); d.im = -d.im; }
+        x[k] = d;
+    }
+    const C *res = run_stages<R>(x, y, W, a, M, -1, 1);
+    const R inv = (R)(1.0 / (double)M);
+    for (int k = threadIdx.x; k < M; k += kBlock) bhat[k] = {res[k].re * inv, res[k].im * inv};
+}
+
 template <typename R>
 __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ spec, const R *__restrict__ rin, R *__restrict__ rout,
                                                            GLines a) {
     extern __shared__ __align__(16) unsigned char lago_fg[];
     typedef GC<R> C;
     const int N = a.N, L = a.L, Lp = a.Lp;
-    C *x = reinterpret_cast<C *>(lago_fg), *y = x + (size_t)Lp * N, *W = y + (size_t)Lp * N;
+    const int NB = a.M ? a.M : N;   // rows of the two line buffers and entries of the root table
+    C *x = reinterpret_cast<C *>(lago_fg), *y = x + (size_t)Lp * NB, *W = y + (size_t)Lp * NB;
     // modes 1 / 2: the workgroup's pairs [j0, j0 + nl) of plane `plane`; lines 2 j and 2 j + 1 share one complex line
     uint32_t l0 = 0, plane = 0;
     int nl;
@@ -211,27 +282,45 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
             if (ln < nl) x[(size_t)pt * Lp + ln] = spec[gline_base(a, l0 + ln, N) + (size_t)pt * a.inner];
         }
     }
-    // the N-th roots of unity, once (argument reduced exactly, k / N with k < N; sincospi in double for float64 lines,
-    // in float for float32 ones: ~1e-7 per twiddle, inside the transform's own rounding)
-    for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, a.sign);
-    // ---- Stockham stages
-    int n = N, s = 1;
-    for (int f = 0; f < a.nfac; ++f) {
-        const int r = a.fac[f], m = n / r;
-        __syncthreads();   // x (and, the first time, W) complete
-        switch (r) {
-            case 2: stage_fixed<R, 2>(x, y, W, a, nl, s, m, a.ds[f]); break;
-            case 3: stage_fixed<R, 3>(x, y, W, a, nl, s, m, a.ds[f]); break;
-            case 4: stage_fixed<R, 4>(x, y, W, a, nl, s, m, a.ds[f]); break;
-            case 5: stage_fixed<R, 5>(x, y, W, a, nl, s, m, a.ds[f]); break;
-            case 7: stage_fixed<R, 7>(x, y, W, a, nl, s, m, a.ds[f]); break;
-            default: stage_any<R>(x, y, W, a, nl, r, s, m, a.ds[f], a.dr[f]); break;
+    if (a.M == 0) {
+        // the N-th roots of unity, once (argument reduced exactly, k / N with k < N; sincospi in double for float64
+        // lines, in float for float32 ones: ~1e-7 per twiddle, inside the transform's own rounding)
+        for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, a.sign);
+        x = run_stages<R>(x, y, W, a, N, a.sign, nl);
+    } else {
+        // Bluestein: X[k] = c[k] sum_n (x[n] c[n]) conj(c)[k - n], c = chirp: a circular convolution of length M through
+        // two M-point power-of-two transforms; the inverse one as conj(FFT(conj(.))) with the same roots
+        const int M = a.M;
+        C *Cq = W + M;   // the chirp, N entries
+        for (int k = threadIdx.x; k < M; k += kBlock) W[k] = root<R>(k, M, -1);
+        for (int k = threadIdx.x; k < N; k += kBlock) Cq[k] = chirp<R>(k, N, a.sign);
+        __syncthreads();
+        for (int i = threadIdx.x; i < L * M; i += kBlock) {
+            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
+            if (ln >= nl) continue;
+            C *e = x + (size_t)pt * Lp + ln;
+            *e = pt < N ? cmul(*e, Cq[pt]) : C{(R)0, (R)0};
         }
-        C *tmp = x; x = y; y = tmp;
-        n = m;
-        s *= r;
+        C *res = run_stages<R>(x, y, W, a, M, -1, nl);
+        const C *bh = reinterpret_cast<const C *>(a.bhat);
+        for (int i = threadIdx.x; i < L * M; i += kBlock) {
+            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
+            if (ln >= nl) continue;
+            C *e = res + (size_t)pt * Lp + ln;
+            const C pr = cmul(*e, bh[pt]);
+            *e = {pr.re, -pr.im};
+        }
+        C *other = res == x ? y : x;
+        res = run_stages<R>(res, other, W, a, M, -1, nl);
+        for (int i = threadIdx.x; i < L * N; i += kBlock) {
+            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
+            if (ln >= nl) continue;
+            C *e = res + (size_t)pt * Lp + ln;
+            *e = cmul(C{e->re, -e->im}, Cq[pt]);
+        }
+        __syncthreads();
+        x = res;
     }
-    __syncthreads();
     // ---- store
     if (a.mode == 1) {            // A[k] = (Z[k] + conj Z[N - k]) / 2,  B[k] = (Z[k] - conj Z[N - k]) / (2 i)
         for (int i = threadIdx.x; i < nl * a.nhalf; i += kBlock) {
@@ -277,6 +366,60 @@ bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz) {
     return true;
 }
 
+// ---- Bluestein tables: FFT_M of the conjugate chirp, per (N, sign, precision, device); computed on first use by one
+// workgroup and kept for the life of the process (at most a few hundred KB each).  The first use synchronises the
+// stream once (another stream may be the next user); while a stream is being captured a missing table is not built and
+// the direct-DFT stages serve that call.
+struct BluKey {
+    int N, sign, esize, dev;
+    bool operator<(const BluKey &o) const {
+        return std::tie(N, sign, esize, dev) < std::tie(o.N, o.sign, o.esize, o.dev);
+    }
+};
+static std::mutex g_blu_mu;
+static std::map<BluKey, void *> *g_blu = nullptr;   // (heap: never destroyed, as the coefficient cache of fft.hip)
+
+static int largest_prime_factor(int n) {
+    int best = 1;
+    for (int p = 2; (long long)p * p <= n; ++p)
+        while (n % p == 0) { best = p; n /= p; }
+    return n > 1 ? n : best;
+}
+
+template <typename R>
+static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const BluKey key{N, sign, (int)sizeof(R), dev};
+    std::lock_guard<std::mutex> lk(g_blu_mu);
+    if (!g_blu) g_blu = new std::map<BluKey, void *>();
+    auto it = g_blu->find(key);
+    if (it != g_blu->end()) return it->second;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    const size_t cb = 2 * sizeof(R);
+    void *d = nullptr;
+    if (hipMalloc(&d, (size_t)M * cb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    GLines a;
+    a.N = N; a.M = M; a.sign = sign; a.L = 1; a.Lp = 1; a.mode = 0; a.inner = 1; a.nlines = 1; a.ppp = 1; a.chunks = 1;
+    a.nhalf = N / 2 + 1; a.bhat = nullptr;
+    a.nfac = 0;
+    for (int m = M; m > 1;) { const int r = m % 4 == 0 ? 4 : 2; a.fac[a.nfac++] = r; m /= r; }
+    a.dinner = FastDiv(1u); a.dN = FastDiv((uint32_t)N); a.dL = FastDiv(1u); a.dnhalf = FastDiv((uint32_t)a.nhalf); a.dchunks = FastDiv(1u);
+    for (int f = 0, st = 1; f < a.nfac; ++f) { a.ds[f] = FastDiv((uint32_t)st); a.dr[f] = FastDiv((uint32_t)a.fac[f]); st *= a.fac[f]; }
+    const size_t smem = (size_t)3 * M * cb;
+    auto k = bluestein_table_kernel<R>;
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    hipLaunchKernelGGL(k, dim3(1), dim3(kBlock), smem, s, reinterpret_cast<GC<R> *>(d), a);
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    (*g_blu)[key] = d;
+    return d;
+}
+
 // mode 0: `nlines` complex lines of N points, stride `inner`.  modes 1 / 2: `planes` fields of `nlines` contiguous real
 // lines each (pairs of lines never cross a field: every batch item's result is independent of its neighbours)
 template <typename R>
@@ -294,12 +437,58 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     a.mode = mode;
     a.nhalf = N / 2 + 1;
     factorise(N, a);
+    a.M = 0;
+    a.bhat = nullptr;
+    const size_t cb = 2 * sizeof(R);
+    const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
+    // A prime factor r costs N r multiply-adds per line in the direct-DFT stage; from about 29 up the whole line is
+    // cheaper as a Bluestein convolution (two power-of-two transforms of M >= 2 N - 1 points): 182 x 218 x 182 brain
+    // volumes (218 = 2 * 109) 10.1 -> 5.2 ms per call, 193 x 229 x 193 22.1 -> 4.4 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
+    // numbers of LDS and the cached table; otherwise the direct stages serve.
+    if (largest_prime_factor(N) >= 29) {   // (measured: 17 the same, 11 and 13 much slower than their direct stages)
+        int M = 1;
+        while (M < 2 * N - 1) M <<= 1;
+        auto ldsb = [&](int l) { return (((size_t)2 * (l | 1) + 1) * M + N) * cb; };
+        int L = std::max(1, 2048 / M);
+        // (about 2048 points per workgroup and at least 32 B of adjacent lines on a strided pass: measured best of
+        // 512 ... 4096 points x 16 ... 128 B)
+        if (mode == 0) L = std::max(L, (int)(32 / cb));
+        while (L > 1 && ldsb(L) > 96 * 1024) --L;
+        if ((uint64_t)L > units) L = (int)units;
+        const void *tab = ldsb(L) <= 160 * 1024 ? bluestein_table<R>(N, M, sign, s) : nullptr;
+        if (tab) {
+            a.M = M;
+            a.bhat = tab;
+            a.nfac = 0;
+            for (int m = M; m > 1;) { const int r = m % 4 == 0 ? 4 : 2; a.fac[a.nfac++] = r; m /= r; }
+            const int Lp = L | 1;
+            const size_t smem = ldsb(L);
+            a.L = L;
+            a.Lp = Lp;
+            a.ppp = (uint32_t)units;
+            a.chunks = (uint32_t)((units + L - 1) / L);
+            a.dinner = FastDiv(a.inner);
+            a.dN = FastDiv((uint32_t)N);
+            a.dL = FastDiv((uint32_t)L);
+            a.dnhalf = FastDiv((uint32_t)a.nhalf);
+            a.dchunks = FastDiv(a.chunks);
+            for (int f = 0, st = 1; f < a.nfac; ++f) {
+                a.ds[f] = FastDiv((uint32_t)st);
+                a.dr[f] = FastDiv((uint32_t)a.fac[f]);
+                st *= a.fac[f];
+            }
+            const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
+            if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
+            auto k = fft_lines_kernel<R>;
+            if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
+            return LAGO_OK;
+        }
+    }
     // lines per workgroup: about 1024 points (a radix-4 stage is then one butterfly per thread, and the workgroup's LDS
     // stays small enough for 4+ workgroups per CU: measured best of 512 ... 4096, profiles/r04_fft_generic.md); a
     // strided pass takes at least 128 B of adjacent lines per point (64 B where 128 B would need more than half the
     // LDS); all within 128 KB
-    const size_t cb = 2 * sizeof(R);
-    const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
     auto lds = [&](int l) { return ((size_t)2 * (l | 1) + 1) * N * cb; };
     int L = std::max(1, 1024 / N);
     if (mode == 0) {
