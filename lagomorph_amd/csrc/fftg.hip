@@ -176,19 +176,26 @@ __device__ __forceinline__ void stage_any(const GC<R> *__restrict__ x, GC<R> *__
 // All Stockham stages of an NP-point transform (factors a.fac, roots W of sign sgn) on the workgroup's lines; returns
 // the buffer that holds the result (x and y alternate).  Begins with a barrier (the caller's writes to x and W) and
 // ends with one.
-template <typename R>
+// RMAX = 4: the factors are 4 and 2 only (power-of-two lengths, every Bluestein line) -- the kernel then carries neither
+// the odd-radix butterflies nor the direct stage and needs about half the registers: more workgroups per CU.
+template <typename R, int RMAX>
 __device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W, const GLines &a, int NP, int sgn, int nl) {
     int n = NP, s = 1;
     for (int f = 0; f < a.nfac; ++f) {
         const int r = a.fac[f], m = n / r;
         __syncthreads();
-        switch (r) {
-            case 2: stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
-            case 3: stage_fixed<R, 3>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
-            case 4: stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
-            case 5: stage_fixed<R, 5>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
-            case 7: stage_fixed<R, 7>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
-            default: stage_any<R>(x, y, W, a, NP, nl, r, s, m, a.ds[f], a.dr[f]); break;
+        if constexpr (RMAX <= 4) {
+            if (r == 4) stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
+            else stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
+        } else {
+            switch (r) {
+                case 2: stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+                case 3: stage_fixed<R, 3>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+                case 4: stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+                case 5: stage_fixed<R, 5>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+                case 7: stage_fixed<R, 7>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+                default: stage_any<R>(x, y, W, a, NP, nl, r, s, m, a.ds[f], a.dr[f]); break;
+            }
         }
         GC<R> *tmp = x; x = y; y = tmp;
         n = m;
@@ -229,12 +236,12 @@ __global__ __launch_bounds__(kBlock) void bluestein_table_kernel(GC<R> *__restri
         if (idx >= 0) { d = chirp<R>(idx, N, a.sign); d.im = -d.im; }
         x[k] = d;
     }
-    const C *res = run_stages<R>(x, y, W, a, M, -1, 1);
+    const C *res = run_stages<R, 4>(x, y, W, a, M, -1, 1);
     const R inv = (R)(1.0 / (double)M);
     for (int k = threadIdx.x; k < M; k += kBlock) bhat[k] = {res[k].re * inv, res[k].im * inv};
 }
 
-template <typename R>
+template <typename R, int RMAX>
 __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ spec, const R *__restrict__ rin, R *__restrict__ rout,
                                                            GLines a) {
     extern __shared__ __align__(16) unsigned char lago_fg[];
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
         // the N-th roots of unity, once (argument reduced exactly, k / N with k < N; sincospi in double for float64
         // lines, in float for float32 ones: ~1e-7 per twiddle, inside the transform's own rounding)
         for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, a.sign);
-        x = run_stages<R>(x, y, W, a, N, a.sign, nl);
+        x = run_stages<R, RMAX>(x, y, W, a, N, a.sign, nl);
     } else {
         // Bluestein: X[k] = c[k] sum_n (x[n] c[n]) conj(c)[k - n], c = chirp: a circular convolution of length M through
         // two M-point power-of-two transforms; the inverse one as conj(FFT(conj(.))) with the same roots
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
             C *e = x + (size_t)pt * Lp + ln;
             *e = pt < N ? cmul(*e, Cq[pt]) : C{(R)0, (R)0};
         }
-        C *res = run_stages<R>(x, y, W, a, M, -1, nl);
+        C *res = run_stages<R, 4>(x, y, W, a, M, -1, nl);
         const C *bh = reinterpret_cast<const C *>(a.bhat);
         for (int i = threadIdx.x; i < L * M; i += kBlock) {
             const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
             *e = {pr.re, -pr.im};
         }
         C *other = res == x ? y : x;
-        res = run_stages<R>(res, other, W, a, M, -1, nl);
+        res = run_stages<R, 4>(res, other, W, a, M, -1, nl);
         for (int i = threadIdx.x; i < L * N; i += kBlock) {
             const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
             if (ln >= nl) continue;
@@ -479,7 +486,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
             }
             const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
             if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
-            auto k = fft_lines_kernel<R>;
+            auto k = fft_lines_kernel<R, 4>;
             if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
             return LAGO_OK;
@@ -516,7 +523,9 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     }
     const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
     if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
-    auto k = fft_lines_kernel<R>;
+    bool pow2 = true;   // (factors 4 and 2 only: the instantiation without the odd radices)
+    for (int f = 0; f < a.nfac; ++f) pow2 = pow2 && (a.fac[f] == 2 || a.fac[f] == 4);
+    auto k = pow2 ? fft_lines_kernel<R, 4> : fft_lines_kernel<R, 7>;
     if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
     return LAGO_OK;
