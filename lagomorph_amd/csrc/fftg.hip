@@ -82,7 +82,7 @@ struct GLines {
     int nfac;
     int fac[20];
     FastDiv dinner, dN, dL, dnhalf, dchunks;
-    FastDiv ds[20], dr[20];   // per stage: division by the stride s and by the radix r
+    FastDiv ds[20], dr[20];   // per stage: division by the stride s and by (r + 1) / 2 (the items of a direct-DFT butterfly)
     // Bluestein (M > 0): the N-point transform as a circular convolution of length M = 2^k >= 2 N - 1; fac / ds then
     // describe the M-point transform (radix 4 and 2 only) and bhat is FFT_M of the conjugate chirp, 1 / M folded in
     int M;
@@ -148,28 +148,47 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
     }
 }
 
-// any other radix (the primes from 11 up): one output per thread, an r-point direct DFT
+// any other radix (the odd primes from 11 up): a direct r-point DFT, one thread per PAIR of outputs (u, r - u) -- their
+// twiddles are complex conjugates, so the pair shares its r inputs and r roots and costs 4 instead of 8 real
+// multiply-adds per input: with x = a + i b and w = c + i s,  X[u] = (P - Q) + i (R + T),  X[r - u] = (P + Q) + i (T - R),
+// P = sum a c, Q = sum b s, R = sum a s, T = sum b c.  u = 0 (the plain sum) is an item of its own.
 template <typename R>
 __device__ __forceinline__ void stage_any(const GC<R> *__restrict__ x, GC<R> *__restrict__ y, const GC<R> *__restrict__ W,
                                           const GLines &a, int N, int nl, int r, int s, int m, FastDiv ds, FastDiv dr) {
     typedef GC<R> C;
-    const int Lp = a.Lp, L = a.L, wstep = N / r;
-    for (int i = threadIdx.x; i < N * L; i += kBlock) {
-        const int yi = (int)a.dL.div((uint32_t)i), ln = i - yi * L;
+    const int Lp = a.Lp, L = a.L, wstep = N / r, h = (r + 1) / 2;   // h items per butterfly: u = 0 and (r - 1) / 2 pairs
+    const FastDiv dh = dr;
+    const int items = m * s * h * L;   // butterflies (m s) x items x lines
+    for (int i = threadIdx.x; i < items; i += kBlock) {
+        const int w0 = (int)a.dL.div((uint32_t)i), ln = i - w0 * L;
         if (ln >= nl) continue;
-        const int pu = (int)ds.div((uint32_t)yi), q = yi - pu * s;
-        const int p = (int)dr.div((uint32_t)pu), u = pu - p * r;
+        const int j = (int)dh.div((uint32_t)w0), u = w0 - j * h;   // butterfly j = q + s p, item u
+        const int p = (int)ds.div((uint32_t)j), q = j - p * s;
         const C *xi = x + (size_t)(q + s * p) * Lp + ln;
-        C acc = {(R)0, (R)0};
+        C *yo = y + (size_t)(q + s * r * p) * Lp + ln;
+        if (u == 0) {
+            C acc = {(R)0, (R)0};
+            for (int t = 0; t < r; ++t) {
+                const C v = xi[(size_t)s * m * t * Lp];
+                acc.re += v.re;
+                acc.im += v.im;
+            }
+            yo[0] = acc;
+            continue;
+        }
+        R P = 0, Q = 0, Rr = 0, T = 0;
         int tu = 0;   // (t u) mod r
         for (int t = 0; t < r; ++t) {
             const C v = xi[(size_t)s * m * t * Lp], w = W[tu * wstep];
-            acc.re = __builtin_fma(v.re, w.re, __builtin_fma(-v.im, w.im, acc.re));
-            acc.im = __builtin_fma(v.re, w.im, __builtin_fma(v.im, w.re, acc.im));
+            P = __builtin_fma(v.re, w.re, P);
+            Q = __builtin_fma(v.im, w.im, Q);
+            Rr = __builtin_fma(v.re, w.im, Rr);
+            T = __builtin_fma(v.im, w.re, T);
             tu += u;
             if (tu >= r) tu -= r;
         }
-        y[(size_t)yi * Lp + ln] = cmul(acc, W[p * u * s]);
+        yo[(size_t)s * u * Lp] = cmul(C{P - Q, Rr + T}, W[p * u * s]);
+        yo[(size_t)s * (r - u) * Lp] = cmul(C{P + Q, T - Rr}, W[p * (r - u) * s]);
     }
 }
 
@@ -413,7 +432,7 @@ static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
     a.nfac = 0;
     for (int m = M; m > 1;) { const int r = m % 4 == 0 ? 4 : 2; a.fac[a.nfac++] = r; m /= r; }
     a.dinner = FastDiv(1u); a.dN = FastDiv((uint32_t)N); a.dL = FastDiv(1u); a.dnhalf = FastDiv((uint32_t)a.nhalf); a.dchunks = FastDiv(1u);
-    for (int f = 0, st = 1; f < a.nfac; ++f) { a.ds[f] = FastDiv((uint32_t)st); a.dr[f] = FastDiv((uint32_t)a.fac[f]); st *= a.fac[f]; }
+    for (int f = 0, st = 1; f < a.nfac; ++f) { a.ds[f] = FastDiv((uint32_t)st); a.dr[f] = FastDiv((uint32_t)(a.fac[f] + 1) / 2u); st *= a.fac[f]; }
     const size_t smem = (size_t)3 * M * cb;
     auto k = bluestein_table_kernel<R>;
     if (smem > 64 * 1024 &&
@@ -450,7 +469,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
     // A prime factor r costs N r multiply-adds per line in the direct-DFT stage; from about 29 up the whole line is
     // cheaper as a Bluestein convolution (two power-of-two transforms of M >= 2 N - 1 points): 182 x 218 x 182 brain
-    // volumes (218 = 2 * 109) 10.1 -> 5.2 ms per call, 193 x 229 x 193 22.1 -> 4.4 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
+    // volumes (218 = 2 * 109) 10.1 -> 4.7 ms per call, 193 x 229 x 193 22.1 -> 4.2 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
     // numbers of LDS and the cached table; otherwise the direct stages serve.
     if (largest_prime_factor(N) >= 29) {   // (measured: 17 the same, 11 and 13 much slower than their direct stages)
         int M = 1;
@@ -481,7 +500,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
             a.dchunks = FastDiv(a.chunks);
             for (int f = 0, st = 1; f < a.nfac; ++f) {
                 a.ds[f] = FastDiv((uint32_t)st);
-                a.dr[f] = FastDiv((uint32_t)a.fac[f]);
+                a.dr[f] = FastDiv((uint32_t)(a.fac[f] + 1) / 2u);
                 st *= a.fac[f];
             }
             const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
@@ -518,7 +537,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     a.dchunks = FastDiv(a.chunks);
     for (int f = 0, st = 1; f < a.nfac; ++f) {
         a.ds[f] = FastDiv((uint32_t)st);
-        a.dr[f] = FastDiv((uint32_t)a.fac[f]);
+        a.dr[f] = FastDiv((uint32_t)(a.fac[f] + 1) / 2u);
         st *= a.fac[f];
     }
     const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
