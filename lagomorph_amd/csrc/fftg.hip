@@ -129,16 +129,24 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
             o[2] = csub(e0, o0);
             o[3] = csub(e1, o1);
         } else {
+            // odd radix: X[0] the plain sum; the outputs u and RR - u share their products (conjugate roots, see stage_any)
+            C s0 = v[0];
 #pragma unroll
-            for (int u = 0; u < RR; ++u) {
-                C acc = v[0];
+            for (int t = 1; t < RR; ++t) s0 = cadd(s0, v[t]);
+            o[0] = s0;
+#pragma unroll
+            for (int u = 1; u <= (RR - 1) / 2; ++u) {
+                R P = v[0].re, Q = 0, Rr = 0, T = v[0].im;
 #pragma unroll
                 for (int t = 1; t < RR; ++t) {
                     const C w = wr[(t * u) % RR];
-                    acc.re = __builtin_fma(v[t].re, w.re, __builtin_fma(-v[t].im, w.im, acc.re));
-                    acc.im = __builtin_fma(v[t].re, w.im, __builtin_fma(v[t].im, w.re, acc.im));
+                    P = __builtin_fma(v[t].re, w.re, P);
+                    Q = __builtin_fma(v[t].im, w.im, Q);
+                    Rr = __builtin_fma(v[t].re, w.im, Rr);
+                    T = __builtin_fma(v[t].im, w.re, T);
                 }
-                o[u] = acc;
+                o[u] = {P - Q, Rr + T};
+                o[RR - u] = {P + Q, T - Rr};
             }
         }
         C *yo = y + (size_t)(q + s * RR * p) * Lp + ln;
