@@ -17,7 +17,7 @@
 //     and in float for float32 ones); stage twiddles and the r-th roots are strided reads of it,
 //   * the real axis packs TWO real lines into one complex line (a + i b) and separates / rebuilds the two half spectra
 //     by conjugate symmetry; pairs never cross a field, so a batch item's bits do not depend on its neighbours.
-// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.8 - 1.8x its time.
+// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.63 - 1.6x its time.
 // The per-frequency operator between the passes is metric.hip's fluid_kernel, the same as on the rocFFT path, with
 // the 1/N of the unnormalised transform pair folded in.  Layout of the half spectrum: [n][c][x][y][z <= nz/2] complex,
 // what rocFFT's R2C produces, so the operator kernel does not know which path ran.
@@ -106,7 +106,7 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
     typedef GC<R> C;
     const int Lp = a.Lp, L = a.L;
     C wr[RR];
-    if (RR != 2 && RR != 4) {
+    if (RR != 2 && RR != 4 && RR != 8) {
 #pragma unroll
         for (int t = 0; t < RR; ++t) wr[t] = W[t * (N / RR)];
     }
@@ -122,6 +122,22 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
         if (RR == 2) {
             o[0] = cadd(v[0], v[1]);
             o[1] = csub(v[0], v[1]);
+        } else if (RR == 8) {
+            // two 4-point transforms of the even and the odd inputs, then X[u] = E[u] + w8^u O[u], X[u + 4] = E[u] - w8^u O[u]
+            // with w8 = exp(sgn 2 pi i / 8): w8^1 = (1 + sgn i) / sqrt 2, w8^2 = sgn i, w8^3 = (-1 + sgn i) / sqrt 2
+            const C a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]), a2 = cadd(v[2], v[6]), a3 = cmuli(csub(v[2], v[6]), sgn);
+            const C b0 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]), b2 = cadd(v[3], v[7]), b3 = cmuli(csub(v[3], v[7]), sgn);
+            const C E0 = cadd(a0, a2), E1 = cadd(a1, a3), E2 = csub(a0, a2), E3 = csub(a1, a3);
+            const C O0 = cadd(b0, b2), O1 = cadd(b1, b3), O2 = csub(b0, b2), O3 = csub(b1, b3);
+            const R h = (R)0.70710678118654752440;
+            const C i1 = cmuli(O1, sgn), i3 = cmuli(O3, sgn);
+            const C t1 = {h * (O1.re + i1.re), h * (O1.im + i1.im)};      // w8^1 O1
+            const C t2 = cmuli(O2, sgn);                                  // w8^2 O2
+            const C t3 = {h * (i3.re - O3.re), h * (i3.im - O3.im)};      // w8^3 O3
+            o[0] = cadd(E0, O0); o[4] = csub(E0, O0);
+            o[1] = cadd(E1, t1); o[5] = csub(E1, t1);
+            o[2] = cadd(E2, t2); o[6] = csub(E2, t2);
+            o[3] = cadd(E3, t3); o[7] = csub(E3, t3);
         } else if (RR == 4) {
             const C e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]), o0 = cadd(v[1], v[3]), o1 = cmuli(csub(v[1], v[3]), sgn);
             o[0] = cadd(e0, o0);
@@ -211,8 +227,9 @@ __device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W,
     for (int f = 0; f < a.nfac; ++f) {
         const int r = a.fac[f], m = n / r;
         __syncthreads();
-        if constexpr (RMAX <= 4) {
-            if (r == 4) stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
+        if constexpr (RMAX <= 4) {   // (power-of-two lengths: radix 8, 4, 2)
+            if (r == 8) stage_fixed<R, 8>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
+            else if (r == 4) stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
             else stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
         } else {
             switch (r) {
@@ -382,7 +399,17 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
     }
 }
 
+// power-of-two length: radix-8 stages first (512 = 8 * 8 * 8: three LDS round trips instead of five), then 4, then 2
+static void factorise_pow2(int N, GLines &a) {
+    a.nfac = 0;
+    int n = N;
+    while (n % 8 == 0) { a.fac[a.nfac++] = 8; n /= 8; }
+    while (n % 4 == 0) { a.fac[a.nfac++] = 4; n /= 4; }
+    while (n % 2 == 0) { a.fac[a.nfac++] = 2; n /= 2; }
+}
+
 static void factorise(int N, GLines &a) {
+    if (N > 1 && (N & (N - 1)) == 0) { factorise_pow2(N, a); return; }
     a.nfac = 0;
     int n = N;
     while (n % 4 == 0) { a.fac[a.nfac++] = 4; n /= 4; }
@@ -437,8 +464,7 @@ static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
     GLines a;
     a.N = N; a.M = M; a.sign = sign; a.L = 1; a.Lp = 1; a.mode = 0; a.inner = 1; a.nlines = 1; a.ppp = 1; a.chunks = 1;
     a.nhalf = N / 2 + 1; a.bhat = nullptr;
-    a.nfac = 0;
-    for (int m = M; m > 1;) { const int r = m % 4 == 0 ? 4 : 2; a.fac[a.nfac++] = r; m /= r; }
+    factorise_pow2(M, a);
     a.dinner = FastDiv(1u); a.dN = FastDiv((uint32_t)N); a.dL = FastDiv(1u); a.dnhalf = FastDiv((uint32_t)a.nhalf); a.dchunks = FastDiv(1u);
     for (int f = 0, st = 1; f < a.nfac; ++f) { a.ds[f] = FastDiv((uint32_t)st); a.dr[f] = FastDiv((uint32_t)(a.fac[f] + 1) / 2u); st *= a.fac[f]; }
     const size_t smem = (size_t)3 * M * cb;
@@ -477,7 +503,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
     // A prime factor r costs N r multiply-adds per line in the direct-DFT stage; from about 29 up the whole line is
     // cheaper as a Bluestein convolution (two power-of-two transforms of M >= 2 N - 1 points): 182 x 218 x 182 brain
-    // volumes (218 = 2 * 109) 10.1 -> 4.7 ms per call, 193 x 229 x 193 22.1 -> 4.2 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
+    // volumes (218 = 2 * 109) 10.1 -> 4.1 ms per call, 193 x 229 x 193 22.1 -> 3.4 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
     // numbers of LDS and the cached table; otherwise the direct stages serve.
     if (largest_prime_factor(N) >= 29) {   // (measured: 17 the same, 11 and 13 much slower than their direct stages)
         int M = 1;
@@ -493,8 +519,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
         if (tab) {
             a.M = M;
             a.bhat = tab;
-            a.nfac = 0;
-            for (int m = M; m > 1;) { const int r = m % 4 == 0 ? 4 : 2; a.fac[a.nfac++] = r; m /= r; }
+            factorise_pow2(M, a);
             const int Lp = L | 1;
             const size_t smem = ldsb(L);
             a.L = L;
@@ -551,7 +576,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
     if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
     bool pow2 = true;   // (factors 4 and 2 only: the instantiation without the odd radices)
-    for (int f = 0; f < a.nfac; ++f) pow2 = pow2 && (a.fac[f] == 2 || a.fac[f] == 4);
+    for (int f = 0; f < a.nfac; ++f) pow2 = pow2 && (a.fac[f] == 2 || a.fac[f] == 4 || a.fac[f] == 8);
     auto k = pow2 ? fft_lines_kernel<R, 4> : fft_lines_kernel<R, 7>;
     if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
