@@ -238,6 +238,7 @@ __device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W,
                 case 4: stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
                 case 5: stage_fixed<R, 5>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
                 case 7: stage_fixed<R, 7>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+                case 8: stage_fixed<R, 8>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
                 default: stage_any<R>(x, y, W, a, NP, nl, r, s, m, a.ds[f], a.dr[f]); break;
             }
         }
@@ -412,6 +413,7 @@ static void factorise(int N, GLines &a) {
     if (N > 1 && (N & (N - 1)) == 0) { factorise_pow2(N, a); return; }
     a.nfac = 0;
     int n = N;
+    while (n % 8 == 0) { a.fac[a.nfac++] = 8; n /= 8; }   // (the power of two in radix-8 stages first: 120 = 8 * 3 * 5)
     while (n % 4 == 0) { a.fac[a.nfac++] = 4; n /= 4; }
     for (int p = 2; (long long)p * p <= n; ++p)
         while (n % p == 0) { a.fac[a.nfac++] = p; n /= p; }
