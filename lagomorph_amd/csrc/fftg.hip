@@ -17,7 +17,7 @@
 //     and in float for float32 ones); stage twiddles and the r-th roots are strided reads of it,
 //   * the real axis packs TWO real lines into one complex line (a + i b) and separates / rebuilds the two half spectra
 //     by conjugate symmetry; pairs never cross a field, so a batch item's bits do not depend on its neighbours.
-// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.63 - 1.6x its time.
+// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.58 - 1.6x its time.
 // The per-frequency operator between the passes is metric.hip's fluid_kernel, the same as on the rocFFT path, with
 // the 1/N of the unnormalised transform pair folded in.  Layout of the half spectrum: [n][c][x][y][z <= nz/2] complex,
 // what rocFFT's R2C produces, so the operator kernel does not know which path ran.
@@ -100,9 +100,11 @@ __device__ __forceinline__ size_t gline_base(const GLines &a, uint32_t l, int n_
 // w_n^(p u) = W[p u s] and w_RR^k = W[k N / RR] from the one table of N-th roots.  LDS layout [point][line]: the line
 // index runs fastest over the threads, so every read and write is to consecutive addresses and the twiddle is a
 // broadcast.
+// `pre` (Bluestein's second transform, first stage): input point i is taken as conj(x[i] pre[i]).
 template <typename R, int RR>
 __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *__restrict__ y, const GC<R> *__restrict__ W,
-                                            const GLines &a, int N, int sgn, int nl, int s, int m, FastDiv ds) {
+                                            const GLines &a, int N, int sgn, int nl, int s, int m, FastDiv ds,
+                                            const GC<R> *__restrict__ pre = nullptr) {
     typedef GC<R> C;
     const int Lp = a.Lp, L = a.L;
     C wr[RR];
@@ -119,6 +121,13 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
         C v[RR], o[RR];
 #pragma unroll
         for (int t = 0; t < RR; ++t) v[t] = xi[(size_t)s * m * t * Lp];
+        if (pre) {   // (workgroup-uniform)
+#pragma unroll
+            for (int t = 0; t < RR; ++t) {
+                const C pr = cmul(v[t], pre[q + s * (p + t * m)]);
+                v[t] = {pr.re, -pr.im};
+            }
+        }
         if (RR == 2) {
             o[0] = cadd(v[0], v[1]);
             o[1] = csub(v[0], v[1]);
@@ -222,15 +231,17 @@ __device__ __forceinline__ void stage_any(const GC<R> *__restrict__ x, GC<R> *__
 // RMAX = 4: the factors are 4 and 2 only (power-of-two lengths, every Bluestein line) -- the kernel then carries neither
 // the odd-radix butterflies nor the direct stage and needs about half the registers: more workgroups per CU.
 template <typename R, int RMAX>
-__device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W, const GLines &a, int NP, int sgn, int nl) {
+__device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W, const GLines &a, int NP, int sgn, int nl,
+                                             const GC<R> *pre = nullptr) {
     int n = NP, s = 1;
     for (int f = 0; f < a.nfac; ++f) {
         const int r = a.fac[f], m = n / r;
         __syncthreads();
         if constexpr (RMAX <= 4) {   // (power-of-two lengths: radix 8, 4, 2)
-            if (r == 8) stage_fixed<R, 8>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
-            else if (r == 4) stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
-            else stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]);
+            const GC<R> *pf = f == 0 ? pre : nullptr;
+            if (r == 8) stage_fixed<R, 8>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
+            else if (r == 4) stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
+            else stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
         } else {
             switch (r) {
                 case 2: stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
@@ -306,13 +317,24 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
         nl = (int)min((uint32_t)L, a.ppp - l0);
     }
     const size_t pline = (size_t)plane * a.nlines;   // first line of the plane
+    // Bluestein: the chirp first -- the lines are multiplied by it while they are loaded, rows N .. M - 1 are zero
+    C *Cq = W + NB;   // (N entries behind the root table)
+    if (a.M) {
+        for (int k = threadIdx.x; k < N; k += kBlock) Cq[k] = chirp<R>(k, N, a.sign);
+        for (int i = threadIdx.x; i < L * (a.M - N); i += kBlock) {
+            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
+            x[(size_t)(N + pt) * Lp + ln] = C{(R)0, (R)0};
+        }
+        __syncthreads();
+    }
+    auto put = [&](int pt, int ln, C v) { x[(size_t)pt * Lp + ln] = a.M ? cmul(v, Cq[pt]) : v; };
     // ---- load into x[point][line]
     if (a.mode == 1) {            // two real lines -> one complex line (a + i b)
         for (int i = threadIdx.x; i < nl * N; i += kBlock) {
             const int pr = (int)a.dN.div((uint32_t)i), pt = i - pr * N;
             const uint32_t la = 2 * (l0 + pr);
             const R *ra = rin + (pline + la) * N;
-            x[(size_t)pt * Lp + pr] = {ra[pt], la + 1 < a.nlines ? ra[N + pt] : (R)0};
+            put(pt, pr, C{ra[pt], la + 1 < a.nlines ? ra[N + pt] : (R)0});
         }
     } else if (a.mode == 2) {     // two half spectra A, B -> the full spectrum of a + i b: Z[k] = A[k] + i B[k],
                                   // A[N - k] = conj A[k]; the imaginary parts of the self-conjugate bins are ignored,
@@ -326,12 +348,12 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
             C A = sa[k], B = la + 1 < a.nlines ? sa[a.nhalf + k] : C{(R)0, (R)0};
             if (k == 0 || 2 * k == N) A.im = B.im = (R)0;
             if (up) { A.im = -A.im; B.im = -B.im; }
-            x[(size_t)pt * Lp + pr] = {A.re - B.im, A.im + B.re};
+            put(pt, pr, C{A.re - B.im, A.im + B.re});
         }
     } else {                      // strided complex lines: adjacent lines are adjacent in memory
         for (int i = threadIdx.x; i < L * N; i += kBlock) {
             const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
-            if (ln < nl) x[(size_t)pt * Lp + ln] = spec[gline_base(a, l0 + ln, N) + (size_t)pt * a.inner];
+            if (ln < nl) put(pt, ln, spec[gline_base(a, l0 + ln, N) + (size_t)pt * a.inner]);
         }
     }
     if (a.M == 0) {
@@ -341,44 +363,24 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
         x = run_stages<R, RMAX>(x, y, W, a, N, a.sign, nl);
     } else {
         // Bluestein: X[k] = c[k] sum_n (x[n] c[n]) conj(c)[k - n], c = chirp: a circular convolution of length M through
-        // two M-point power-of-two transforms; the inverse one as conj(FFT(conj(.))) with the same roots
+        // two M-point power-of-two transforms; the inverse one as conj(FFT(conj(.))) with the same roots.  The product
+        // with the table is taken by the second transform's first stage as it reads, the final conj(.) c[k] by the store.
         const int M = a.M;
-        C *Cq = W + M;   // the chirp, N entries
         for (int k = threadIdx.x; k < M; k += kBlock) W[k] = root<R>(k, M, -1);
-        for (int k = threadIdx.x; k < N; k += kBlock) Cq[k] = chirp<R>(k, N, a.sign);
-        __syncthreads();
-        for (int i = threadIdx.x; i < L * M; i += kBlock) {
-            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
-            if (ln >= nl) continue;
-            C *e = x + (size_t)pt * Lp + ln;
-            *e = pt < N ? cmul(*e, Cq[pt]) : C{(R)0, (R)0};
-        }
         C *res = run_stages<R, 4>(x, y, W, a, M, -1, nl);
-        const C *bh = reinterpret_cast<const C *>(a.bhat);
-        for (int i = threadIdx.x; i < L * M; i += kBlock) {
-            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
-            if (ln >= nl) continue;
-            C *e = res + (size_t)pt * Lp + ln;
-            const C pr = cmul(*e, bh[pt]);
-            *e = {pr.re, -pr.im};
-        }
         C *other = res == x ? y : x;
-        res = run_stages<R, 4>(res, other, W, a, M, -1, nl);
-        for (int i = threadIdx.x; i < L * N; i += kBlock) {
-            const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
-            if (ln >= nl) continue;
-            C *e = res + (size_t)pt * Lp + ln;
-            *e = cmul(C{e->re, -e->im}, Cq[pt]);
-        }
-        __syncthreads();
-        x = res;
+        x = run_stages<R, 4>(res, other, W, a, M, -1, nl, reinterpret_cast<const C *>(a.bhat));
     }
+    auto get = [&](int pt, int ln) {
+        const C v = x[(size_t)pt * Lp + ln];
+        return a.M ? cmul(C{v.re, -v.im}, Cq[pt]) : v;
+    };
     // ---- store
     if (a.mode == 1) {            // A[k] = (Z[k] + conj Z[N - k]) / 2,  B[k] = (Z[k] - conj Z[N - k]) / (2 i)
         for (int i = threadIdx.x; i < nl * a.nhalf; i += kBlock) {
             const int pr = (int)a.dnhalf.div((uint32_t)i), k = i - pr * a.nhalf;
             const uint32_t la = 2 * (l0 + pr);
-            const C zk = x[(size_t)k * Lp + pr], zm = x[(size_t)(k ? N - k : 0) * Lp + pr];
+            const C zk = get(k, pr), zm = get(k ? N - k : 0, pr);
             C *sa = spec + (pline + la) * a.nhalf;
             sa[k] = {(R)0.5 * (zk.re + zm.re), (R)0.5 * (zk.im - zm.im)};
             if (la + 1 < a.nlines) sa[a.nhalf + k] = {(R)0.5 * (zk.im + zm.im), (R)0.5 * (zm.re - zk.re)};
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
         for (int i = threadIdx.x; i < nl * N; i += kBlock) {
             const int pr = (int)a.dN.div((uint32_t)i), pt = i - pr * N;
             const uint32_t la = 2 * (l0 + pr);
-            const C z = x[(size_t)pt * Lp + pr];
+            const C z = get(pt, pr);
             R *ra = rout + (pline + la) * N;
             ra[pt] = z.re;
             if (la + 1 < a.nlines) ra[N + pt] = z.im;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
     } else {
         for (int i = threadIdx.x; i < L * N; i += kBlock) {
             const int pt = (int)a.dL.div((uint32_t)i), ln = i - pt * L;
-            if (ln < nl) spec[gline_base(a, l0 + ln, N) + (size_t)pt * a.inner] = x[(size_t)pt * Lp + ln];
+            if (ln < nl) spec[gline_base(a, l0 + ln, N) + (size_t)pt * a.inner] = get(pt, ln);
         }
     }
 }
@@ -505,7 +507,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
     // A prime factor r costs N r multiply-adds per line in the direct-DFT stage; from about 29 up the whole line is
     // cheaper as a Bluestein convolution (two power-of-two transforms of M >= 2 N - 1 points): 182 x 218 x 182 brain
-    // volumes (218 = 2 * 109) 10.1 -> 4.1 ms per call, 193 x 229 x 193 22.1 -> 3.4 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
+    // volumes (218 = 2 * 109) 10.1 -> 3.8 ms per call, 193 x 229 x 193 22.1 -> 2.9 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
     // numbers of LDS and the cached table; otherwise the direct stages serve.
     if (largest_prime_factor(N) >= 29) {   // (measured: 17 the same, 11 and 13 much slower than their direct stages)
         int M = 1;
