@@ -17,7 +17,7 @@
 //     and in float for float32 ones); stage twiddles and the r-th roots are strided reads of it,
 //   * the real axis packs TWO real lines into one complex line (a + i b) and separates / rebuilds the two half spectra
 //     by conjugate symmetry; pairs never cross a field, so a batch item's bits do not depend on its neighbours.
-// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.58 - 1.6x its time.
+// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.58 - 1.55x its time.
 // The per-frequency operator between the passes is metric.hip's fluid_kernel, the same as on the rocFFT path, with
 // the 1/N of the unnormalised transform pair folded in.  Layout of the half spectrum: [n][c][x][y][z <= nz/2] complex,
 // what rocFFT's R2C produces, so the operator kernel does not know which path ran.
@@ -87,12 +87,46 @@ struct GLines {
     // describe the M-point transform (radix 4 and 2 only) and bhat is FFT_M of the conjugate chirp, 1 / M folded in
     int M;
     const void *bhat;
+    int inplace;         // power-of-two stages in place (one line buffer; host: L N <= 8192)
 };
 
 // line l of a mode-0 launch: element offset of its first point
 __device__ __forceinline__ size_t gline_base(const GLines &a, uint32_t l, int n_points) {
     const uint32_t hi = a.dinner.div(l), lo = l - hi * a.inner;
     return (size_t)hi * (size_t)n_points * a.inner + lo;
+}
+
+// radix-2 / 4 / 8 butterflies on registers: o[u] = sum_t v[t] w^(t u), w = exp(sgn 2 pi i / RR)
+template <typename R, int RR>
+__device__ __forceinline__ void bfly_pow2(const GC<R> (&v)[RR], GC<R> (&o)[RR], int sgn) {
+    typedef GC<R> C;
+    if constexpr (RR == 2) {
+        o[0] = cadd(v[0], v[1]);
+        o[1] = csub(v[0], v[1]);
+    } else if constexpr (RR == 8) {
+        // two 4-point transforms of the even and the odd inputs, then X[u] = E[u] + w8^u O[u], X[u + 4] = E[u] - w8^u O[u]
+        // with w8 = exp(sgn 2 pi i / 8): w8^1 = (1 + sgn i) / sqrt 2, w8^2 = sgn i, w8^3 = (-1 + sgn i) / sqrt 2
+        const C a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]), a2 = cadd(v[2], v[6]), a3 = cmuli(csub(v[2], v[6]), sgn);
+        const C b0 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]), b2 = cadd(v[3], v[7]), b3 = cmuli(csub(v[3], v[7]), sgn);
+        const C E0 = cadd(a0, a2), E1 = cadd(a1, a3), E2 = csub(a0, a2), E3 = csub(a1, a3);
+        const C O0 = cadd(b0, b2), O1 = cadd(b1, b3), O2 = csub(b0, b2), O3 = csub(b1, b3);
+        const R h = (R)0.70710678118654752440;
+        const C i1 = cmuli(O1, sgn), i3 = cmuli(O3, sgn);
+        const C t1 = {h * (O1.re + i1.re), h * (O1.im + i1.im)};      // w8^1 O1
+        const C t2 = cmuli(O2, sgn);                                  // w8^2 O2
+        const C t3 = {h * (i3.re - O3.re), h * (i3.im - O3.im)};      // w8^3 O3
+        o[0] = cadd(E0, O0); o[4] = csub(E0, O0);
+        o[1] = cadd(E1, t1); o[5] = csub(E1, t1);
+        o[2] = cadd(E2, t2); o[6] = csub(E2, t2);
+        o[3] = cadd(E3, t3); o[7] = csub(E3, t3);
+    } else {
+        static_assert(RR == 4, "bfly_pow2: radix 2, 4 or 8");
+        const C e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]), o0 = cadd(v[1], v[3]), o1 = cmuli(csub(v[1], v[3]), sgn);
+        o[0] = cadd(e0, o0);
+        o[1] = cadd(e1, o1);
+        o[2] = csub(e0, o0);
+        o[3] = csub(e1, o1);
+    }
 }
 
 // One Stockham stage of radix RR on every line of the workgroup, a whole butterfly per thread in registers:
@@ -128,31 +162,8 @@ __device__ __forceinline__ void stage_fixed(const GC<R> *__restrict__ x, GC<R> *
                 v[t] = {pr.re, -pr.im};
             }
         }
-        if (RR == 2) {
-            o[0] = cadd(v[0], v[1]);
-            o[1] = csub(v[0], v[1]);
-        } else if (RR == 8) {
-            // two 4-point transforms of the even and the odd inputs, then X[u] = E[u] + w8^u O[u], X[u + 4] = E[u] - w8^u O[u]
-            // with w8 = exp(sgn 2 pi i / 8): w8^1 = (1 + sgn i) / sqrt 2, w8^2 = sgn i, w8^3 = (-1 + sgn i) / sqrt 2
-            const C a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]), a2 = cadd(v[2], v[6]), a3 = cmuli(csub(v[2], v[6]), sgn);
-            const C b0 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]), b2 = cadd(v[3], v[7]), b3 = cmuli(csub(v[3], v[7]), sgn);
-            const C E0 = cadd(a0, a2), E1 = cadd(a1, a3), E2 = csub(a0, a2), E3 = csub(a1, a3);
-            const C O0 = cadd(b0, b2), O1 = cadd(b1, b3), O2 = csub(b0, b2), O3 = csub(b1, b3);
-            const R h = (R)0.70710678118654752440;
-            const C i1 = cmuli(O1, sgn), i3 = cmuli(O3, sgn);
-            const C t1 = {h * (O1.re + i1.re), h * (O1.im + i1.im)};      // w8^1 O1
-            const C t2 = cmuli(O2, sgn);                                  // w8^2 O2
-            const C t3 = {h * (i3.re - O3.re), h * (i3.im - O3.im)};      // w8^3 O3
-            o[0] = cadd(E0, O0); o[4] = csub(E0, O0);
-            o[1] = cadd(E1, t1); o[5] = csub(E1, t1);
-            o[2] = cadd(E2, t2); o[6] = csub(E2, t2);
-            o[3] = cadd(E3, t3); o[7] = csub(E3, t3);
-        } else if (RR == 4) {
-            const C e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]), o0 = cadd(v[1], v[3]), o1 = cmuli(csub(v[1], v[3]), sgn);
-            o[0] = cadd(e0, o0);
-            o[1] = cadd(e1, o1);
-            o[2] = csub(e0, o0);
-            o[3] = csub(e1, o1);
+        if constexpr (RR == 2 || RR == 4 || RR == 8) {
+            bfly_pow2<R, RR>(v, o, sgn);
         } else {
             // odd radix: X[0] the plain sum; the outputs u and RR - u share their products (conjugate roots, see stage_any)
             C s0 = v[0];
@@ -225,12 +236,61 @@ __device__ __forceinline__ void stage_any(const GC<R> *__restrict__ x, GC<R> *__
     }
 }
 
+// The same stage IN PLACE for the power-of-two radices: every thread first reads all its butterflies (at most 32 complex
+// numbers: 32 / RR butterflies) into registers, a barrier, then writes them to their Stockham positions in the SAME
+// buffer -- half the LDS of the ping-pong form, which is what long strided lines need (1024 points x 8 lines of
+// float32: 64 KB instead of 128: two workgroups per CU, or twice the adjacent lines).  The host keeps
+// (N / RR) L <= 256 * (32 / RR), i.e. L N <= 8192.
+template <typename R, int RR>
+__device__ __forceinline__ void stage_inplace(GC<R> *__restrict__ x, const GC<R> *__restrict__ W, const GLines &a, int N, int sgn,
+                                              int nl, int s, int m, FastDiv ds, const GC<R> *__restrict__ pre) {
+    typedef GC<R> C;
+    constexpr int TM = 32 / RR;
+    const int Lp = a.Lp, L = a.L, nb = (N / RR) * L;
+    C v[TM][RR];
+#pragma unroll
+    for (int tr = 0; tr < TM; ++tr) {
+        const int b = (int)threadIdx.x + tr * kBlock;
+        if (b < nb) {
+            const int j = (int)a.dL.div((uint32_t)b), ln = b - j * L;
+            const int p = (int)ds.div((uint32_t)j), q = j - p * s;
+            const C *xi = x + (size_t)(q + s * p) * Lp + ln;
+#pragma unroll
+            for (int t = 0; t < RR; ++t) v[tr][t] = xi[(size_t)s * m * t * Lp];
+            if (pre) {
+#pragma unroll
+                for (int t = 0; t < RR; ++t) {
+                    const C pr = cmul(v[tr][t], pre[q + s * (p + t * m)]);
+                    v[tr][t] = {pr.re, -pr.im};
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tr = 0; tr < TM; ++tr) {
+        const int b = (int)threadIdx.x + tr * kBlock;
+        if (b < nb) {
+            const int j = (int)a.dL.div((uint32_t)b), ln = b - j * L;
+            if (ln < nl) {
+                const int p = (int)ds.div((uint32_t)j), q = j - p * s;
+                C o[RR];
+                bfly_pow2<R, RR>(v[tr], o, sgn);
+                C *yo = x + (size_t)(q + s * RR * p) * Lp + ln;
+                yo[0] = o[0];
+#pragma unroll
+                for (int u = 1; u < RR; ++u) yo[(size_t)s * u * Lp] = cmul(o[u], W[p * u * s]);
+            }
+        }
+    }
+}
+
 // All Stockham stages of an NP-point transform (factors a.fac, roots W of sign sgn) on the workgroup's lines; returns
 // the buffer that holds the result (x and y alternate).  Begins with a barrier (the caller's writes to x and W) and
 // ends with one.
 // RMAX = 4: the factors are 4 and 2 only (power-of-two lengths, every Bluestein line) -- the kernel then carries neither
 // the odd-radix butterflies nor the direct stage and needs about half the registers: more workgroups per CU.
-template <typename R, int RMAX>
+template <typename R, int RMAX, bool INPL = false>
 __device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W, const GLines &a, int NP, int sgn, int nl,
                                              const GC<R> *pre = nullptr) {
     int n = NP, s = 1;
@@ -239,7 +299,11 @@ __device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W,
         __syncthreads();
         if constexpr (RMAX <= 4) {   // (power-of-two lengths: radix 8, 4, 2)
             const GC<R> *pf = f == 0 ? pre : nullptr;
-            if (r == 8) stage_fixed<R, 8>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
+            if constexpr (INPL) {   // (y == x)
+                if (r == 8) stage_inplace<R, 8>(x, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
+                else if (r == 4) stage_inplace<R, 4>(x, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
+                else stage_inplace<R, 2>(x, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
+            } else if (r == 8) stage_fixed<R, 8>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
             else if (r == 4) stage_fixed<R, 4>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
             else stage_fixed<R, 2>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f], pf);
         } else {
@@ -297,14 +361,14 @@ __global__ __launch_bounds__(kBlock) void bluestein_table_kernel(GC<R> *__restri
     for (int k = threadIdx.x; k < M; k += kBlock) bhat[k] = {res[k].re * inv, res[k].im * inv};
 }
 
-template <typename R, int RMAX>
+template <typename R, int RMAX, bool INPL = false>
 __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ spec, const R *__restrict__ rin, R *__restrict__ rout,
                                                            GLines a) {
     extern __shared__ __align__(16) unsigned char lago_fg[];
     typedef GC<R> C;
     const int N = a.N, L = a.L, Lp = a.Lp;
     const int NB = a.M ? a.M : N;   // rows of the two line buffers and entries of the root table
-    C *x = reinterpret_cast<C *>(lago_fg), *y = x + (size_t)Lp * NB, *W = y + (size_t)Lp * NB;
+    C *x = reinterpret_cast<C *>(lago_fg), *y = INPL ? x : x + (size_t)Lp * NB, *W = y + (size_t)Lp * NB;
     // modes 1 / 2: the workgroup's pairs [j0, j0 + nl) of plane `plane`; lines 2 j and 2 j + 1 share one complex line
     uint32_t l0 = 0, plane = 0;
     int nl;
@@ -360,16 +424,16 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
         // the N-th roots of unity, once (argument reduced exactly, k / N with k < N; sincospi in double for float64
         // lines, in float for float32 ones: ~1e-7 per twiddle, inside the transform's own rounding)
         for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, a.sign);
-        x = run_stages<R, RMAX>(x, y, W, a, N, a.sign, nl);
+        x = run_stages<R, RMAX, INPL>(x, y, W, a, N, a.sign, nl);
     } else {
         // Bluestein: X[k] = c[k] sum_n (x[n] c[n]) conj(c)[k - n], c = chirp: a circular convolution of length M through
         // two M-point power-of-two transforms; the inverse one as conj(FFT(conj(.))) with the same roots.  The product
         // with the table is taken by the second transform's first stage as it reads, the final conj(.) c[k] by the store.
         const int M = a.M;
         for (int k = threadIdx.x; k < M; k += kBlock) W[k] = root<R>(k, M, -1);
-        C *res = run_stages<R, 4>(x, y, W, a, M, -1, nl);
+        C *res = run_stages<R, 4, INPL>(x, y, W, a, M, -1, nl);
         C *other = res == x ? y : x;
-        x = run_stages<R, 4>(res, other, W, a, M, -1, nl, reinterpret_cast<const C *>(a.bhat));
+        x = run_stages<R, 4, INPL>(res, other, W, a, M, -1, nl, reinterpret_cast<const C *>(a.bhat));
     }
     auto get = [&](int pt, int ln) {
         const C v = x[(size_t)pt * Lp + ln];
@@ -467,7 +531,7 @@ static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
     if (hipMalloc(&d, (size_t)M * cb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     GLines a;
     a.N = N; a.M = M; a.sign = sign; a.L = 1; a.Lp = 1; a.mode = 0; a.inner = 1; a.nlines = 1; a.ppp = 1; a.chunks = 1;
-    a.nhalf = N / 2 + 1; a.bhat = nullptr;
+    a.nhalf = N / 2 + 1; a.bhat = nullptr; a.inplace = 0;
     factorise_pow2(M, a);
     a.dinner = FastDiv(1u); a.dN = FastDiv((uint32_t)N); a.dL = FastDiv(1u); a.dnhalf = FastDiv((uint32_t)a.nhalf); a.dchunks = FastDiv(1u);
     for (int f = 0, st = 1; f < a.nfac; ++f) { a.ds[f] = FastDiv((uint32_t)st); a.dr[f] = FastDiv((uint32_t)(a.fac[f] + 1) / 2u); st *= a.fac[f]; }
@@ -503,6 +567,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     factorise(N, a);
     a.M = 0;
     a.bhat = nullptr;
+    a.inplace = 0;
     const size_t cb = 2 * sizeof(R);
     const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
     // A prime factor r costs N r multiply-adds per line in the direct-DFT stage; from about 29 up the whole line is
@@ -559,9 +624,22 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
         L = lds(want) <= 80 * 1024 ? want : std::max(L, (int)(64 / cb));
     }
     while (L > 1 && lds(L) > 128 * 1024) --L;
+    bool pow2 = true;   // (factors 8, 4 and 2 only: the instantiation without the odd radices)
+    for (int f = 0; f < a.nfac; ++f) pow2 = pow2 && (a.fac[f] == 2 || a.fac[f] == 4 || a.fac[f] == 8);
+    // long power-of-two lines of a strided pass (1024-point image rows: 123 KB for six lines in the ping-pong form, one
+    // workgroup per CU): the stages run in place -- one line buffer, up to 8192 points in the registers of the workgroup
+    if (pow2 && mode == 0 && lds(L) > 64 * 1024) {
+        auto ldsi = [&](int l) { return ((size_t)(l | 1) + 1) * N * cb; };
+        int Li = std::min((int)(128 / cb), 8192 / N);
+        while (Li > 1 && ldsi(Li) > 80 * 1024) --Li;
+        if (Li >= L) {
+            L = Li;
+            a.inplace = 1;
+        }
+    }
     if ((uint64_t)L > units) L = (int)units;
     const int Lp = L | 1;
-    const size_t smem = ((size_t)2 * Lp + 1) * N * cb;
+    const size_t smem = a.inplace ? ((size_t)Lp + 1) * N * cb : ((size_t)2 * Lp + 1) * N * cb;
     if (smem > 160 * 1024) return fail_invalid("fluid_metric: extent %d is above what the generic FFT passes hold in LDS", N);
     a.L = L;
     a.Lp = Lp;
@@ -579,9 +657,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     }
     const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
     if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
-    bool pow2 = true;   // (factors 4 and 2 only: the instantiation without the odd radices)
-    for (int f = 0; f < a.nfac; ++f) pow2 = pow2 && (a.fac[f] == 2 || a.fac[f] == 4 || a.fac[f] == 8);
-    auto k = pow2 ? fft_lines_kernel<R, 4> : fft_lines_kernel<R, 7>;
+    auto k = a.inplace ? fft_lines_kernel<R, 4, true> : pow2 ? fft_lines_kernel<R, 4> : fft_lines_kernel<R, 7>;
     if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
     return LAGO_OK;
