@@ -8,16 +8,19 @@
 // Generality first, then speed: one kernel transforms batches of LINES along one axis --
 //   * a workgroup brings L lines of N points into LDS as [point][line] (adjacent lines of a strided axis are adjacent
 //     in memory: coalesced rows; L from lines_pass),
-//   * runs a Stockham autosort FFT with the radices of N's factorisation (4 where it divides, then the primes
+//   * runs a Stockham autosort FFT with the radices of N's factorisation (8 and 4 where they divide, then the primes
 //     ascending).  Radices 2, 3, 4, 5, 7: one whole butterfly per thread in registers (r LDS reads, r writes, r - 1
-//     twiddles); any other prime: one output per thread, a direct r-point DFT -- so ANY extent works; a line whose
+//     twiddles); any other prime: a direct r-point DFT, one thread per conjugate pair of outputs -- so ANY extent works; a line whose
 //     length has a prime factor of 29 or more goes through Bluestein's identity instead (chirp, two power-of-two
 //     transforms of M >= 2 N - 1 points, a cached table): 182 x 218 x 182 and 193 x 229 x 193 volumes 2 - 5x faster,
+//   * lengths whose factors are 8, 4 and 2 only (and every Bluestein transform) run an instantiation without the odd
+//     radices (half the registers); long strided power-of-two lines run their stages IN PLACE (stage_inplace: the
+//     butterflies of a stage held in registers across a barrier, one line buffer instead of two),
 //   * one table of the N-th roots per workgroup (sincospi of the exactly reduced argument, in double for float64 lines
 //     and in float for float32 ones); stage twiddles and the r-th roots are strided reads of it,
 //   * the real axis packs TWO real lines into one complex line (a + i b) and separates / rebuilds the two half spectra
 //     by conjugate symmetry; pairs never cross a field, so a batch item's bits do not depend on its neighbours.
-// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.58 - 1.55x its time.
+// Measured against rocFFT on the shapes it used to serve (profiles/r04_fft_generic.md): 0.52 - 1.55x its time.
 // The per-frequency operator between the passes is metric.hip's fluid_kernel, the same as on the rocFFT path, with
 // the 1/N of the unnormalised transform pair folded in.  Layout of the half spectrum: [n][c][x][y][z <= nz/2] complex,
 // what rocFFT's R2C produces, so the operator kernel does not know which path ran.
@@ -572,7 +575,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     const uint64_t units = mode == 0 ? nlines : (nlines + 1) / 2;
     // A prime factor r costs N r multiply-adds per line in the direct-DFT stage; from about 29 up the whole line is
     // cheaper as a Bluestein convolution (two power-of-two transforms of M >= 2 N - 1 points): 182 x 218 x 182 brain
-    // volumes (218 = 2 * 109) 10.1 -> 3.8 ms per call, 193 x 229 x 193 22.1 -> 2.9 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
+    // volumes (218 = 2 * 109) 10.1 -> 3.6 ms per call, 193 x 229 x 193 22.1 -> 2.6 (profiles/r04_fft_generic.md).  Needs (2 (L | 1) + 1) M + N complex
     // numbers of LDS and the cached table; otherwise the direct stages serve.
     if (largest_prime_factor(N) >= 29) {   // (measured: 17 the same, 11 and 13 much slower than their direct stages)
         int M = 1;
@@ -584,13 +587,24 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
         if (mode == 0) L = std::max(L, (int)(32 / cb));
         while (L > 1 && ldsb(L) > 96 * 1024) --L;
         if ((uint64_t)L > units) L = (int)units;
-        const void *tab = ldsb(L) <= 160 * 1024 ? bluestein_table<R>(N, M, sign, s) : nullptr;
+        // a strided pass: the stages in place (one line buffer), more adjacent lines per point for the same LDS
+        auto ldsbi = [&](int l) { return (((size_t)(l | 1) + 1) * M + N) * cb; };
+        bool inpl = false;
+        // (64 B of adjacent lines: 182 x 218 x 182 3840 -> 3561 us; 128 B: 3735)
+        if (mode == 0) {
+            int Li = std::min((int)(64 / cb), 8192 / M);
+            while (Li > 1 && ldsbi(Li) > 80 * 1024) --Li;
+            if ((uint64_t)Li > units) Li = (int)units;
+            if (Li > L) { L = Li; inpl = true; }
+        }
+        const void *tab = (inpl ? ldsbi(L) : ldsb(L)) <= 160 * 1024 ? bluestein_table<R>(N, M, sign, s) : nullptr;
         if (tab) {
             a.M = M;
             a.bhat = tab;
+            a.inplace = inpl ? 1 : 0;
             factorise_pow2(M, a);
             const int Lp = L | 1;
-            const size_t smem = ldsb(L);
+            const size_t smem = inpl ? ldsbi(L) : ldsb(L);
             a.L = L;
             a.Lp = Lp;
             a.ppp = (uint32_t)units;
@@ -607,7 +621,7 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
             }
             const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
             if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
-            auto k = fft_lines_kernel<R, 4>;
+            auto k = inpl ? fft_lines_kernel<R, 4, true> : fft_lines_kernel<R, 4>;
             if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
             return LAGO_OK;
