@@ -317,6 +317,14 @@ __device__ __forceinline__ GC<R> *run_stages(GC<R> *x, GC<R> *y, const GC<R> *W,
                 case 5: stage_fixed<R, 5>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
                 case 7: stage_fixed<R, 7>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
                 case 8: stage_fixed<R, 8>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break;
+                case 11:
+                    if constexpr (RMAX >= 13) { stage_fixed<R, 11>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break; }
+                    [[fallthrough]];
+                case 13:
+                    if constexpr (RMAX >= 13) {
+                        if (r == 13) { stage_fixed<R, 13>(x, y, W, a, NP, sgn, nl, s, m, a.ds[f]); break; }
+                    }
+                    [[fallthrough]];
                 default: stage_any<R>(x, y, W, a, NP, nl, r, s, m, a.ds[f], a.dr[f]); break;
             }
         }
@@ -671,7 +679,16 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     }
     const uint64_t grid = mode == 0 ? a.chunks : planes * a.chunks;
     if (grid >= (1ull << 31)) return fail_invalid("fluid_metric: bad extent");
-    auto k = a.inplace ? fft_lines_kernel<R, 4, true> : pow2 ? fft_lines_kernel<R, 4> : fft_lines_kernel<R, 7>;
+    // a factor 11 or 13 beside powers of two only (176 = 16 * 11, 208 = 16 * 13): the instantiation that holds their
+    // butterflies in registers too (152 / 161 VGPRs; with a radix-7 stage in the same line it loses: 91 = 7 * 13)
+    bool r13 = false, odd_small = false;
+    for (int f = 0; f < a.nfac; ++f) {
+        r13 = r13 || a.fac[f] == 11 || a.fac[f] == 13;
+        odd_small = odd_small || a.fac[f] == 3 || a.fac[f] == 5 || a.fac[f] == 7;
+    }
+    auto k = a.inplace ? fft_lines_kernel<R, 4, true>
+             : pow2    ? fft_lines_kernel<R, 4>
+             : (r13 && !odd_small) ? fft_lines_kernel<R, 13> : fft_lines_kernel<R, 7>;
     if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, rin, rout, a);
     return LAGO_OK;
