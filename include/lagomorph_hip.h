@@ -103,8 +103,9 @@ typedef struct lago_tuning {
      * in {64,96,128,160,192,256} and (ny, nz) any pair of {64,96,128,160,192} or one of the power-of-two planes
      * 32x{64,128,256}, 64x256, 128x256, 256x{64,128}: lengths 2^a, 3*2^a, 5*2^a; float32 2D planes up to 128 x 128 in
      * one fused kernel) and the generic hand-written passes of csrc/fftg.hip for every other shape and for float64
-     * (any extent up to 2048 per axis, lines with a prime factor >= 29 through Bluestein's convolution; an axis longer
-     * than 2048 is the one case left to the spot-checked rocFFT path): no rocFFT call otherwise.  2: the tuned passes, rocFFT for the rest (1: rocFFT 2D
+     * (any extent up to 4096 (float32) / 2048 (float64) points per axis, lines with a prime factor >= 29 through
+     * Bluestein's convolution; a longer axis is the one case left to the spot-checked rocFFT path): no rocFFT call
+     * otherwise.  2: the tuned passes, rocFFT for the rest (1: rocFFT 2D
      * (y, z) plan + fused x-axis pass, nx in {64,128,256}; 0: rocFFT 3D plan + operator kernel; a mode falls back to
      * the next lower one for shapes it does not support); the rocFFT plans are spot-checked against a direct DFT
      * (csrc/fft.hip).  Results agree to rounding */

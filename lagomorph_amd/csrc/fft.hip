@@ -45,7 +45,7 @@ int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, 
                     const float *sinY, double alpha, double beta, double gamma, int64_t nn, int64_t h, int64_t w,
                     hipStream_t s);
 // fftg.hip
-bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz);
+bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz, size_t esize);
 template <typename R>
 int fluid_metric_generic(R *out, const R *m, R *work, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
                          const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn, int64_t nx,
@@ -469,7 +469,7 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
         return fluid_metric_native((float *)out, (const float *)m, (float *)work, tab->d, inverse, nn, nx, ny, nz,
                                    1.0 / ((double)nx * (double)ny * (double)nz), (hipStream_t)stream);
     }
-    if (g_fluid_xpass >= 3 && fluid_generic_supported(dim, nx, ny, nz)) {
+    if (g_fluid_xpass >= 3 && fluid_generic_supported(dim, nx, ny, nz, sizeof(R))) {
         note_path(LP_FLUID_GENERIC);
         return fluid_metric_generic<R>(out, m, work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn,
                                        nx, ny, nz, (hipStream_t)stream);

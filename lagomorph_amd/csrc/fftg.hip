@@ -497,12 +497,13 @@ static void factorise(int N, GLines &a) {
     if (n > 1) a.fac[a.nfac++] = n;
 }
 
-constexpr int kGenericMaxN = 2048;   // (2 (L | 1) + 1) N complex numbers must fit the LDS
-
-bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz) {
+// three line buffers' worth of complex numbers (ping-pong + roots) must fit the LDS for ONE line: 4096 points of
+// float32, 2048 of float64
+bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz, size_t esize) {
+    const int64_t maxn = esize == 4 ? 4096 : 2048;
     const int64_t ext[3] = {dim == 3 ? nx : 1, dim == 3 ? ny : nx, dim == 3 ? nz : ny};
     for (int d = 0; d < 3; ++d)
-        if (ext[d] < 1 || ext[d] > kGenericMaxN) return false;
+        if (ext[d] < 1 || ext[d] > maxn) return false;
     return true;
 }
 

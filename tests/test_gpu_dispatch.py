@@ -64,18 +64,22 @@ def test_fluid_metric_dispatch(lm, sp, path):
 
 
 def test_extents_above_the_generic_passes_take_the_guarded_rocfft_path(lm):
-    """csrc/fftg.hip holds a line of at most 2048 points in LDS: a longer axis (2D, 4096 x 8) is the one shape class the
-    default mode still hands to rocFFT (spot-checked) -- and the answer is the oracle's."""
+    """csrc/fftg.hip holds a line of at most 4096 float32 / 2048 float64 points in LDS: a longer axis is the one shape
+    class the default mode still hands to rocFFT (spot-checked).  Both sides of the limit, against the oracle."""
     import numpy as np
     from oracle import lago_oracle as orc
 
     metric = lm.FluidMetric([0.1, 0.0, 0.01])
-    m = _fields(1, 2, (4096, 8))
-    took = _delta(lm.lagomorph_ext, lambda: metric.sharp(m))
-    assert list(took) == ["fluid_rocfft"], took
-    want = orc.fluid_metric_apply(m.cpu().numpy(), [0.1, 0.0, 0.01], True)
-    got = metric.sharp(m).cpu().numpy()
-    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    for sp, dtype, path in (((4096, 8), torch.float32, "fluid_generic"), ((8192, 4), torch.float32, "fluid_rocfft"),
+                            ((2048, 6), torch.float64, "fluid_generic"), ((4096, 8), torch.float64, "fluid_rocfft"),
+                            ((3000, 6), torch.float32, "fluid_generic")):
+        m = _fields(1, 2, sp).to(dtype)
+        took = _delta(lm.lagomorph_ext, lambda: metric.sharp(m))
+        assert list(took) == [path], (sp, dtype, took)
+        want = orc.fluid_metric_apply(m.cpu().numpy(), [0.1, 0.0, 0.01], True)
+        got = metric.sharp(m).cpu().numpy()
+        tol = 1e-5 if dtype == torch.float32 else 1e-11
+        assert np.abs(got - want).max() <= tol * np.abs(want).max(), (sp, dtype)
 
 
 def test_the_switches_select_the_slower_siblings(lm):
