@@ -219,6 +219,18 @@ def micro_ops(lm, dev, size, batch=8):
         med, _ = time_op(fn, reps=20, warm=20)
         out["ops"][name] = {"ms": med, "alg_bytes_per_voxel": bpv, "GBps": bpv * V / med / 1e6,
                             "frac_of_hbm_peak": bpv * V / med / 1e6 / HBM_PEAK_GBPS}
+    # BASELINE configs[0]: 2D affine_interp forward + adjoint, batch 2, 1 x 64 x 64 random images (the reference runs it
+    # on its CPU path: cpu_baseline.reference_cpu_path times that code on this host).  32 KB of data: a launch-latency
+    # figure, not a bandwidth one -- no roofline fraction is quoted for it.
+    I0 = torch.randn((2, 1, 64, 64), device=dev, generator=g)
+    A0 = (torch.eye(2, device=dev)[None] + 0.1 * torch.randn((2, 2, 2), device=dev, generator=g)).contiguous()
+    T0 = torch.randn((2, 2), device=dev, generator=g)
+    go0 = torch.randn((2, 1, 64, 64), device=dev, generator=g)
+    f_ms, _ = time_op(lambda: ext.affine_interp_forward(I0, A0, T0), reps=100, warm=20)
+    b_ms, _ = time_op(lambda: ext.affine_interp_backward(go0, I0, A0, T0, True, True, True), reps=100, warm=20)
+    out["configs0"] = {"workload": "2D affine_interp forward + adjoint (d_I, d_A, d_T), batch 2, 1x64x64 fp32 (BASELINE configs[0])",
+                       "forward_us": 1e3 * f_ms, "adjoint_us": 1e3 * b_ms, "pair_us": 1e3 * (f_ms + b_ms),
+                       "voxels": 2 * 64 * 64, "pair_voxels_per_s": 2 * 64 * 64 / ((f_ms + b_ms) * 1e-3)}
     return out
 
 
@@ -362,6 +374,51 @@ def atlas_leg(lm, dev, world, rank, args):
         "alg_bytes_per_voxel": bpv, "achieved_GBps": gbps,
         "frac_of_hbm_peak": gbps / (HBM_PEAK_GBPS * world), "finite": finite,
     }
+
+
+def reference_cpu_path(lm, dev, size):
+    """The reference's OWN CPU code beside the GPU kernel that replaces it: `affine_interp_cpu_forward`
+    of extension/cpu/affine.cpp:129-169, compiled from the reference tree into oracle/_ref/lagomorph_ref_cpu.so by
+    oracle/build_ref.py (the prebuilt file travels to the GPU box), timed on this host next to `affine_interp_forward`
+    through HIP on the same inputs.  The reference's loop is serial (no OpenMP, no at::parallel_for): one core is all it
+    ever uses.  BASELINE configs[0] (2D, batch 2, 1 x 64 x 64) and a bounded 3D sample (2 of the 8 x 1 x size^3 items)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import build_ref
+
+    ref = build_ref.load_ref()
+    if ref is None:
+        return {"available": False, "note": "oracle/_ref/lagomorph_ref_cpu.so not in the tree (built from /root/reference by __graft_entry__.build())"}
+    ext = lm.lagomorph_ext
+    g = torch.Generator().manual_seed(5)
+    out = {"available": True, "kind": "reference", "cores": 1,
+           "source": "lagomorph/extension/cpu/affine.cpp:129-169 (affine_interp_cpu_forward), compiled unmodified; serial code"}
+    prev = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for tag, shape, d, reps in (("configs0_2d_batch2_1x64x64", (2, 1, 64, 64), 2, 200),
+                                    (f"3d_batch2_1x{size}^3", (2, 1, size, size, size), 3, 3)):
+            I = torch.randn(shape, generator=g)
+            A = (torch.eye(d)[None] + 0.1 * torch.randn((shape[0], d, d), generator=g)).contiguous()
+            T = torch.randn((shape[0], d), generator=g)
+            want = ref.affine_interp_cpu_forward(I, A, T)   # untimed: page in
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                want = ref.affine_interp_cpu_forward(I, A, T)
+            cpu_s = (time.perf_counter() - t0) / reps
+            Ig, Ag, Tg = I.to(dev), A.to(dev), T.to(dev)
+            gpu_ms, _ = time_op(lambda: ext.affine_interp_forward(Ig, Ag, Tg), reps=50, warm=20)
+            got = ext.affine_interp_forward(Ig, Ag, Tg).cpu()
+            V = I.numel()
+            out[tag] = {"voxels": V, "reference_cpu_s": cpu_s, "reference_cpu_voxels_per_s": V / cpu_s,
+                        "hip_ms": gpu_ms, "hip_voxels_per_s": V / (gpu_ms * 1e-3),
+                        # the CPU path steps its position incrementally along a row, the CUDA path (and the HIP kernel)
+                        # evaluates it per voxel: they agree to rounding only, as the reference's own
+                        # test_affine_interp_gpucpu_match asserts (allclose)
+                        "max_abs_diff_hip_vs_reference_cpu": float((got - want).abs().max()),
+                        "max_abs_reference": float(want.abs().max())}
+    finally:
+        torch.set_num_threads(prev)
+    return out
 
 
 def cpu_baseline(size, euler_steps, sample_batch=1):
@@ -599,6 +656,12 @@ def main():
 
         names = ["interp_forward", "jacobian_times_vectorfield_forward", "fluid_operator", "fluid_metric", "compose",
                  "Ad_star"]
+        from lagomorph_amd import lddmm as _lddmm
+        default_streams = _lddmm.EXPMAP_STREAMS
+        # TIMED REGION: the product's default path -- a forward-only shoot of 4+ batch items is cut into two sub-batches
+        # on HIP streams of their own (lddmm.EXPMAP_STREAMS = 2, bit-identical to one stream).  HIP events of the
+        # wrapped entry points are recorded on the stream each call is launched on; with two parts in flight they
+        # measure a kernel BESIDE the other part's kernels (reported as breakdown_ms_per_step, not as a roofline).
         with KernelTimer(ext, names) as kt:
             for _ in range(args.warmup):
                 step()
@@ -616,41 +679,43 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             kt.enabled = False
-            ksum = kt.summary()
+            ksum_timed = kt.summary()
         hmax = h.abs().max().item()
-        # for comparison, untimed region: the same shoot with every Euler step through the general kernels (an explicit
-        # zero phiinv switches off the closed-form first step; same result bit for bit)
-        t_general, same_bits = None, None
-        if not args.no_extras:
-            z = torch.zeros_like(m)
-            lm.expmap(metric, m, num_steps=E, phiinv=z)
-            torch.cuda.synchronize()
-            tg0 = time.perf_counter()
-            for _ in range(min(args.steps, 3)):
-                hg = lm.expmap(metric, m, num_steps=E, phiinv=z)
-            torch.cuda.synchronize()
-            t_general = (time.perf_counter() - tg0) / min(args.steps, 3)
-            same_bits = bool(torch.equal(hg, h))
-            del hg, z
-        # untimed region as well: the headline shoot cut into two sub-batches on HIP streams of their own (an option of
-        # the product, off by default: lagomorph_amd.lddmm.EXPMAP_STREAMS, profiles/r04_stream_split.md)
-        from lagomorph_amd import lddmm as _lddmm
-        t_split, split_bits = None, None
-        if B >= 4 and not args.no_extras:
-            _lddmm.EXPMAP_STREAMS = 2
-            try:
-                for _ in range(2):
-                    hs = step()
+        # ROOFLINE PASS (same process, same inputs, right after the timed region): the same shoots on
+        # ONE stream, so that a launch's HIP-event duration is the time the kernel needs by itself.  `roofline` and
+        # `single_stream` below come from here; the headline does not.
+        _lddmm.EXPMAP_STREAMS = 1
+        try:
+            with KernelTimer(ext, names) as kt1:
+                step()
                 torch.cuda.synchronize()
+                kt1.enabled = True
                 ts0 = time.perf_counter()
-                for _ in range(min(args.steps, 5)):
-                    hs = step()
+                for _ in range(args.steps):
+                    h1 = step()
                 torch.cuda.synchronize()
-                t_split = (time.perf_counter() - ts0) / min(args.steps, 5)
-                split_bits = bool(torch.equal(hs, h))
-                del hs
-            finally:
-                _lddmm.EXPMAP_STREAMS = 1
+                t_single = (time.perf_counter() - ts0) / args.steps
+                kt1.enabled = False
+                ksum = kt1.summary()
+            single_bits = bool(torch.equal(h1, h))
+            del h1
+            # for comparison, untimed: the same single-stream shoot with every Euler step through the general kernels
+            # (an explicit zero phiinv switches off the closed-form first step; same result bit for bit)
+            t_general, same_bits = None, None
+            if not args.no_extras:
+                z = torch.zeros_like(m)
+                lm.expmap(metric, m, num_steps=E, phiinv=z)
+                torch.cuda.synchronize()
+                tg0 = time.perf_counter()
+                for _ in range(min(args.steps, 3)):
+                    hg = lm.expmap(metric, m, num_steps=E, phiinv=z)
+                torch.cuda.synchronize()
+                t_general = (time.perf_counter() - tg0) / min(args.steps, 3)
+                same_bits = bool(torch.equal(hg, h))
+                del hg, z
+        finally:
+            _lddmm.EXPMAP_STREAMS = default_streams
+        split_active = default_streams >= 2 and B >= 2 * default_streams
         del h
     elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
     if world > 1:
@@ -675,11 +740,16 @@ def main():
         "config": {
             "workload": f"lddmm.expmap, {E} Euler steps, global batch {GBATCH} x 3x{S}^3 fp32 sharded {B} per GPU "
                         "(BASELINE configs[3]); value counts voxels x Euler steps; shooting from the identity, the "
-                        "first Euler step is evaluated in closed form (-dt sharp(m0): the bits EPDiff_step returns)",
+                        "first Euler step is evaluated in closed form (-dt sharp(m0): the bits EPDiff_step returns); "
+                        + (f"the product's default path: each rank's shoot runs as {default_streams} sub-batches on HIP "
+                           "streams of their own (lddmm.EXPMAP_STREAMS, bit-identical)" if split_active else
+                           "one HIP stream (the sub-batch split needs 4+ items per rank)"),
+            "streams": default_streams if split_active else 1,
+            "single_stream": {"ms_per_step": 1e3 * t_single, "same_bits": single_bits,
+                              "note": "the same shoots with lddmm.EXPMAP_STREAMS = 1, after the timed region: the pass "
+                                      "the roofline object's launch durations are measured in"},
             "all_steps_through_the_general_kernels": None if t_general is None else {
                 "ms_per_step": 1e3 * t_general, "local_voxel_steps_per_s": B * S ** 3 * E / t_general, "same_bits": same_bits},
-            "stream_split": None if t_split is None else {"parts": 2, "ms_per_step": 1e3 * t_split, "same_bits": split_bits,
-                                                           "note": "option lddmm.EXPMAP_STREAMS = 2; not the headline"},
             "global_batch": GBATCH, "per_gpu_batch": B, "volume": [S, S, S], "euler_steps": E,
             "parallelism": f"batch-sharded x{world}, no data-path collective in expmap; the atlas step "
                            "(atlas_step below) all-reduces the atlas gradient over RCCL",
@@ -725,13 +795,20 @@ def main():
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": tsrc,
                 "bytes_per_launch": bytes_per_launch, "mean_launch_ms": k["mean_ms"], "launches": k["launches"],
+                "measured_in": "the single-stream pass that follows the timed region in this process (config.single_stream): "
+                               "HIP events on the launch stream around each of its launches",
                 "others": {n: {"mean_launch_ms": present[n]["mean_ms"],
                                "frac": 36.0 * V / (present[n]["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                            for n in present if n != op},
             }
         total_ms = 1e3 * T
-        result["breakdown_ms_per_step"] = {n: s["total_ms"] / args.steps for n, s in ksum.items()}
+        result["breakdown_ms_per_step"] = {n: s["total_ms"] / args.steps for n, s in ksum_timed.items()}
         result["breakdown_ms_per_step"]["wall"] = total_ms / args.steps
+        result["breakdown_ms_per_step"]["note"] = ("timed region; sums of per-launch HIP-event durations over BOTH streams "
+                                                   "(they overlap in time, so they add up to more than the wall)"
+                                                   if split_active else "timed region, one stream")
+        result["breakdown_ms_per_step_single_stream"] = {n: s["total_ms"] / args.steps for n, s in ksum.items()}
+        result["breakdown_ms_per_step_single_stream"]["wall"] = 1e3 * t_single
         if not args.no_micro and world == 1:
             result["interp_splat"] = micro_interp_splat(ext, dev, S)
             torch.cuda.empty_cache()
@@ -743,6 +820,10 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S, E, args.cpu_sample_batch)
+            try:
+                result["cpu_baseline"]["reference_cpu_path"] = reference_cpu_path(lm, dev, S)
+            except Exception as e:  # the checker's absence must not cost the line
+                result["cpu_baseline"]["reference_cpu_path"] = {"available": False, "error": repr(e)}
         if SHARE_GPU:
             result["debug_shared_gpu"] = "LAGO_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo -- a plumbing check, NOT a measurement"
         print(json.dumps(result), flush=True)

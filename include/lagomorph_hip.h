@@ -210,7 +210,10 @@ long long lago_path_launches(int path);
      * initialised, results independent of the launch; only the association of the weight products differs from     \
      * the reference's (wz (wy (wx m)) against wx wy wz m).  ws: two temporaries of ws_elems / 2 elements each,     \
      * ws_elems >= 2 nn nc max(nx Ny Nz, nx ny Nz) (3D; 2D: >= 2 nn nc nx Ny with (nx, ny) the 2D extents; may be   \
-     * null when ws_elems == 0 suffices).  Not in the reference's extension surface. */                             \
+     * null when ws_elems == 0 suffices).  Inputs the passes do not cover (a non-positive spacing, spacings        \
+     * >= 1e6 or so small that rounding moves a sample by more than 64 output cells, |origin| >= 1e9, 2^31 elements  \
+     * or more in a pass) are served by lago_regrid_backward: every call the reference accepts is accepted.          \
+     * Not in the reference's extension surface. */                                                                 \
     int lago_regrid_backward_sep##SUF(REAL *d_I, const REAL *grad_out, REAL *ws, int64_t ws_elems, int dim,         \
                                       int64_t nn, int64_t nc, int64_t nx, int64_t ny, int64_t nz, int64_t Nx,       \
                                       int64_t Ny, int64_t Nz, const double *origin, const double *spacing,          \

@@ -67,6 +67,56 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out,
     }
 }
 
+// 3D, several voxels per lane (round 5).  The kernel above gives a lane ONE voxel: four pair gathers, one lerp, one
+// 4-byte store, then the wave retires -- 65 536 workgroups of one dependent memory round trip each at 8 x 128^3
+// (52 us = 0.32 of HBM peak, profiles/r05_affine_regrid_forward.md).  Here a lane owns voxel tid of each of VPT
+// consecutive 256-voxel slabs of one batch item: the positions of all its voxels first, then per channel every gather
+// of the VPT voxels in flight together.  Same expressions per voxel: bit-identical.
+#ifndef LAGO_AFFINE_VPT
+#define LAGO_AFFINE_VPT 4
+#endif
+template <typename R, bool BC, int VPT>
+__global__ __launch_bounds__(kBlock) void affine_fwd3_multi_kernel(R *__restrict__ out, const R *__restrict__ I,
+                                                                   const R *__restrict__ A, const R *__restrict__ T,
+                                                                   int nc, Geom g) {
+    const uint32_t L = block_order(blockIdx.x, g.nblocks, g.rev);
+    const uint32_t n = g.dnbx.div(L);
+    const uint32_t s0 = (L - n * g.nbx) * (uint32_t)(kBlock * VPT) + threadIdx.x;
+    const size_t nv = g.nvox;
+    const R *An = A + (size_t)n * 9;
+    const R *Tn = T + (size_t)n * 3;
+    const R *In = BC ? I : I + (size_t)n * nc * nv;
+    R *on = out + (size_t)n * nc * nv;
+    const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
+    const R a0 = An[0], a1 = An[1], a2 = An[2], a3 = An[3], a4 = An[4], a5 = An[5], a6 = An[6], a7 = An[7], a8 = An[8];
+    const R t0 = Tn[0], t1 = Tn[1], t2 = Tn[2];
+    Lerp3<R> Lq[VPT];
+    bool ok[VPT];
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+        const uint32_t sv = s0 + (uint32_t)(e * kBlock);
+        ok[e] = sv < g.nvox;
+        const uint32_t sl = ok[e] ? sv : 0u;
+        const uint32_t ii = g.dyz.div(sl);
+        const uint32_t rr = sl - ii * (uint32_t)(g.ny * g.nz);
+        const uint32_t jj = g.dz.div(rr);
+        const R fi = (R)(int)ii - ox, fj = (R)(int)jj - oy, fk = (R)(int)(rr - jj * (uint32_t)g.nz) - oz;
+        const R hx = lg_fma(a2, fk, lg_fma(a0, fi, a1 * fj)) + t0 + ox;   // cuda/affine.cu:42-61
+        const R hy = lg_fma(a5, fk, lg_fma(a3, fi, a4 * fj)) + t1 + oy;
+        const R hz = lg_fma(a8, fk, lg_fma(a6, fi, a7 * fj)) + t2 + oz;
+        Lq[e].setup(hx, hy, hz, g.nx, g.ny, g.nz);
+    }
+    for (int c = 0; c < nc; ++c) {
+        const R *Ic = In + (size_t)c * nv;
+        R val[VPT];
+#pragma unroll
+        for (int e = 0; e < VPT; ++e) val[e] = Lq[e].value(Ic);
+#pragma unroll
+        for (int e = 0; e < VPT; ++e)
+            if (ok[e]) st_pol<LAGO_NT_AFFINE_ST>(&on[(size_t)c * nv + s0 + (uint32_t)(e * kBlock)], val[e]);
+    }
+}
+
 // ------------------------------------------------------------------ affine backward
 
 template <typename R>
@@ -413,6 +463,45 @@ __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out,
     }
 }
 
+// 3D, planes in the grid (round 5).  The kernel above loops over ALL nn * nc planes inside one thread -- 24 dependent
+// gather / store round trips per wave at 8 x 3 planes, and only Nv / 256 workgroups (101 us for 64^3 -> 128^3 = 0.28
+// of HBM peak) -- and every lane finds its hz by up to nz sequential adds.  Here blockIdx.y picks a group of QPT planes
+// whose gathers are all in flight together, and the reference's running sum `hz += Sz` (cuda/affine.cu:669-675) is
+// evaluated ONCE per workgroup, by one lane into an LDS table of nz entries -- the same sequentially rounded values.
+#ifndef LAGO_REGRID_QPT
+#define LAGO_REGRID_QPT 4
+#endif
+constexpr int kRegridTab = 1024;   // longest output row the table form serves
+template <typename R, int QPT>
+__global__ __launch_bounds__(kBlock) void regrid_fwd3_planes_kernel(R *__restrict__ out, const R *__restrict__ I,
+                                                                    int nq, Geom g, RegridParams rp) {
+    __shared__ R hzt[kRegridTab];
+    const R Sz = (R)rp.S[2];
+    if (threadIdx.x == 0) {
+        R hz = lg_fma(-half_extent<R>(g.nz), Sz, (R)rp.O[2]);
+        for (int k = 0; k < g.nz; ++k) {
+            hzt[k] = hz;
+            hz += Sz;
+        }
+    }
+    __syncthreads();
+    const Vox v = locate(g);  // (one "batch item": the planes are blockIdx.y's)
+    if (!v.valid) return;
+    const size_t Nv = g.nvox;
+    const size_t nvin = (size_t)rp.nx * rp.ny * rp.nz;
+    const R hx = lg_fma((R)v.i - half_extent<R>(g.nx), (R)rp.S[0], (R)rp.O[0]);
+    const R hy = lg_fma((R)v.j - half_extent<R>(g.ny), (R)rp.S[1], (R)rp.O[1]);
+    Lerp3<R> L;
+    L.setup(hx, hy, hzt[v.k], rp.nx, rp.ny, rp.nz);
+    const int q0 = (int)blockIdx.y * QPT;
+    R val[QPT];
+#pragma unroll
+    for (int e = 0; e < QPT; ++e) val[e] = L.value(I + (size_t)min(q0 + e, nq - 1) * nvin);
+#pragma unroll
+    for (int e = 0; e < QPT; ++e)
+        if (q0 + e < nq) st_pol<LAGO_NT_AFFINE_ST>(&out[(size_t)(q0 + e) * Nv + v.s], val[e]);
+}
+
 template <typename R, int DIM>
 __global__ __launch_bounds__(kBlock) void regrid_bwd_kernel(R *__restrict__ d_I, const R *__restrict__ go, int nq,
                                                             Geom g, RegridParams rp) {
@@ -468,6 +557,7 @@ struct SepAxis {
     uint32_t Q;           // elements of the faster axes (contiguous run per index of this axis)
     uint32_t total;       // P * nin * Q threads
     double O, S, o;       // origin, spacing, half extent of the OUTPUT grid along this axis (as the splat takes them)
+    int slack;            // candidate window: the double inverse map +- slack output indices (sep_axis_slack)
     FastDiv dQ, dn;
 };
 
@@ -479,11 +569,12 @@ __global__ __launch_bounds__(kBlock) void regrid_bwd_axis_kernel(R *__restrict__
     const uint32_t p = ax.dn.div(pz);
     const int zi = (int)(pz - p * (uint32_t)ax.nin);
     const R O = (R)ax.O, S = (R)ax.S, o = (R)ax.o;   // (half_extent<R>: already rounded through R by the host)
-    // a superset of the contributing output indices from the inverse map in double (+- 1 for the float rounding of h);
-    // the border cells collect everything that is clamped onto them
+    // a superset of the contributing output indices from the inverse map in double, +- ax.slack for the rounding of h
+    // in R (the host bounds it: sep_axis_slack); clamped in double, so the casts cannot overflow; the border cells
+    // collect everything that is clamped onto them
     int lo = 0, hi = ax.Nout - 1;
-    if (zi > 0) lo = max(0, (int)floor(((double)zi - 1.0 - ax.O) / ax.S + ax.o) - 1);
-    if (zi < ax.nin - 1) hi = min(ax.Nout - 1, (int)ceil(((double)zi + 1.0 - ax.O) / ax.S + ax.o) + 1);
+    if (zi > 0) lo = (int)fmax(0.0, fmin((double)(ax.Nout - 1), floor(((double)zi - 1.0 - ax.O) / ax.S + ax.o) - (double)ax.slack));
+    if (zi < ax.nin - 1) hi = (int)fmax(0.0, fmin((double)(ax.Nout - 1), ceil(((double)zi + 1.0 - ax.O) / ax.S + ax.o) + (double)ax.slack));
     const R *g = G + ((size_t)p * ax.Nout) * ax.Q + q;
     R acc = (R)0;
     // branch-free body, four candidates per trip: the loads do not wait for the membership tests (a candidate that does
@@ -546,27 +637,60 @@ __global__ __launch_bounds__(kBlock) void regrid_bwd_axis_stream_kernel(R *__res
     }
 }
 
+// How far (in output indices) the position h = fma(zo - o, S, O) evaluated in R can sit from its exact value: the three
+// roundings (zo - o, the fma, o itself) are each within eps |h|-sized terms, |h| <= |O| + Nout S; divided by S that is
+// an index distance.  The gather kernel widens its candidate window by 1 + that (with a tiny spacing the
+// fixed +- 1 did not cover the rounding).
+template <typename R>
+static double sep_axis_slack(double O, double S, int64_t Nout) {
+    const double eps = sizeof(R) == 4 ? 1.1920928955078125e-7 : 2.220446049250313e-16;
+    return 1.0 + ceil(4.0 * eps * (fabs(O) + (double)Nout * S + 1.0) / S);
+}
+
+template <typename R>
+static int regrid_backward_impl(R *d_I, const R *go, int dim, int64_t nn, int64_t nc, int64_t nx, int64_t ny,
+                                int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz, const double *origin,
+                                const double *spacing, void *stream);
+
+// Separable where the map allows it; every input the reference's splat accepts is accepted here too: what the passes do
+// not cover (non-positive, huge or tiny spacings, far origins, 2^31 elements or more per pass) goes to
+// regrid_backward_impl, which needs no workspace.
 template <typename R>
 static int regrid_backward_sep_impl(R *d_I, const R *go, R *ws, int64_t ws_elems, int dim, int64_t nn, int64_t nc,
                                     int64_t nx, int64_t ny, int64_t nz, int64_t Nx, int64_t Ny, int64_t Nz,
                                     const double *origin, const double *spacing, void *stream) {
     if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional regridding is supported");
     if (!origin || !spacing) return fail_invalid("regrid_backward: bad extent");
+    const int64_t a_nx = nx, a_ny = ny, a_nz = nz, a_Nx = Nx, a_Ny = Ny, a_Nz = Nz;   // as the caller gave them
     if (dim == 2) { nz = ny; ny = nx; nx = 1; Nz = Ny; Ny = Nx; Nx = 1; }
     const int64_t planes = nn * nc;
     if (nn < 0 || nc < 0 || nx < 1 || ny < 1 || nz < 1 || Nx < 1 || Ny < 1 || Nz < 1) return fail_invalid("regrid_backward: bad extent");
     const int64_t n_in[3] = {nx, ny, nz}, N_out[3] = {Nx, Ny, Nz};
     double O[3] = {0, 0, 0}, S[3] = {1, 1, 1};
     for (int d = 0; d < dim; ++d) { O[3 - dim + d] = origin[d]; S[3 - dim + d] = spacing[d]; }
-    for (int d = 3 - dim; d < 3; ++d)
-        if (!(S[d] > 0.0) || !(S[d] < 1e6) || !(fabs(O[d]) < 1e9))
-            return fail_invalid("regrid_backward (separable): needs positive spacings");
+    const int first = 3 - dim;
+    int slack[3] = {1, 1, 1};
+    bool sep = true;
+    for (int d = first; d < 3; ++d) {
+        if (!(S[d] > 0.0) || !(S[d] < 1e6) || !(fabs(O[d]) < 1e9)) { sep = false; break; }
+        const double sl = sep_axis_slack<R>(O[d], S[d], N_out[d]);
+        if (!(sl <= 64.0)) { sep = false; break; }
+        slack[d] = (int)sl;
+    }
+    {   // element counts of every pass: 32-bit indices with the multiply-high division (n < 2^31, common.hpp: FastDiv)
+        int64_t cur[3] = {Nx, Ny, Nz};
+        for (int a = first; a < 3 && sep; ++a) {
+            if (planes * cur[0] * cur[1] * cur[2] >= (1ll << 40)) sep = false;
+            cur[a] = n_in[a];
+            if (planes * cur[0] * cur[1] * cur[2] >= (1ll << 31)) sep = false;
+        }
+    }
+    if (!sep) return regrid_backward_impl<R>(d_I, go, dim, nn, nc, a_nx, a_ny, a_nz, a_Nx, a_Ny, a_Nz, origin, spacing, stream);
     hipStream_t s = (hipStream_t)stream;
     if (planes == 0 || nx * ny * nz == 0) return LAGO_OK;
     // passes over the axes x, y, z (2D: y, z), slowest first: extents (cx, cy, cz) go from the output grid to the input grid
     int64_t cur[3] = {Nx, Ny, Nz};
     const R *src = go;
-    const int first = 3 - dim;
     for (int a = first; a < 3; ++a) {
         int64_t nxt[3] = {cur[0], cur[1], cur[2]};
         nxt[a] = n_in[a];
@@ -575,7 +699,6 @@ static int regrid_backward_sep_impl(R *d_I, const R *go, R *ws, int64_t ws_elems
         // temporaries alternate between the two halves of the workspace
         R *dst = last ? d_I : ws + ((a - first) & 1 ? ws_elems / 2 : 0);
         if (!last && (out_elems > ws_elems / 2 || !ws)) return fail_invalid("regrid_backward (separable): workspace too small");
-        if (out_elems >= (1ll << 32) || planes * cur[0] * cur[1] * cur[2] >= (1ll << 40)) return fail_invalid("regrid_backward: bad extent");
         SepAxis ax;
         ax.Nout = (int)N_out[a];
         ax.nin = (int)n_in[a];
@@ -585,6 +708,7 @@ static int regrid_backward_sep_impl(R *d_I, const R *go, R *ws, int64_t ws_elems
         ax.total = (uint32_t)out_elems;
         ax.O = O[a];
         ax.S = S[a];
+        ax.slack = slack[a];
         ax.o = (double)(R)(.5 * (double)(R)((int)N_out[a] - 1));   // half_extent<R> (device helper), on the host
         ax.dQ = FastDiv(ax.Q);
         ax.dn = FastDiv((uint32_t)ax.nin);
@@ -614,6 +738,15 @@ static int affine_forward_impl(R *out, const R *I, const R *A, const R *T, int d
     if (g.nblocks == 0 || nc == 0) return LAGO_OK;
     if (!out || !I || !A || !T) return fail_invalid("affine_interp_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    // large 3D launches: several voxels per lane (same bits); small ones keep one voxel per lane -- more workgroups
+    if (dim == 3 && (int64_t)g.nvox * nn >= (1ll << 20)) {
+        Geom gm;
+        if (make_geom(gm, 3, nn, nx, ny, nz, kBlock * LAGO_AFFINE_VPT)) {
+            if (bc) hipLaunchKernelGGL((affine_fwd3_multi_kernel<R, true, LAGO_AFFINE_VPT>), dim3(gm.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, gm);
+            else hipLaunchKernelGGL((affine_fwd3_multi_kernel<R, false, LAGO_AFFINE_VPT>), dim3(gm.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, gm);
+            return finish_launch(s, "affine_interp_forward");
+        }
+    }
 #define LAUNCH(D, B) \
     hipLaunchKernelGGL((affine_fwd_kernel<R, D, B>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, g)
     if (dim == 3) {
@@ -656,7 +789,7 @@ static int affine_backward_impl(R *d_I, R *d_A, R *d_T, const R *go, const R *I,
     if (dim != 2 && dim != 3)
         return fail_invalid("Only two- and three-dimensional affine interpolation is supported");
     Geom g;
-    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("affine_interp_backward: bad extent");
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz, kBlock, true)) return fail_invalid("affine_interp_backward: bad extent");
     hipStream_t s = (hipStream_t)stream;
     const size_t nI = (size_t)(bc ? 1 : nn) * nc * g.nvox;
     if ((need_I && nI && !d_I) || (need_A && nn && !d_A) || (need_T && nn && !d_T) ||
@@ -718,7 +851,11 @@ static int regrid_forward_impl(R *out, const R *I, int dim, int64_t nn, int64_t 
     if (g.nblocks == 0 || nn * nc == 0) return LAGO_OK;
     if (!out || !I) return fail_invalid("regrid_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (dim == 3)
+    const int64_t groups = (nn * nc + LAGO_REGRID_QPT - 1) / LAGO_REGRID_QPT;
+    if (dim == 3 && g.nz <= kRegridTab && groups <= 65535)
+        hipLaunchKernelGGL((regrid_fwd3_planes_kernel<R, LAGO_REGRID_QPT>), dim3(g.nblocks, (uint32_t)groups), dim3(kBlock), 0, s, out,
+                           I, (int)(nn * nc), g, rp);
+    else if (dim == 3)
         hipLaunchKernelGGL((regrid_fwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp);
     else
         hipLaunchKernelGGL((regrid_fwd_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp);
@@ -732,7 +869,7 @@ static int regrid_backward_impl(R *d_I, const R *go, int dim, int64_t nn, int64_
     if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional regridding is supported");
     Geom g;
     RegridParams rp;
-    if (nn < 0 || nc < 0 || nn * nc >= (1ll << 31) || !make_geom(g, dim, 1, Nx, Ny, Nz) ||
+    if (nn < 0 || nc < 0 || nn * nc >= (1ll << 31) || !make_geom(g, dim, 1, Nx, Ny, Nz, kBlock, true) ||
         !make_regrid(rp, dim, nx, ny, nz, origin, spacing))
         return fail_invalid("regrid_backward: bad extent");
     hipStream_t s = (hipStream_t)stream;
@@ -742,11 +879,12 @@ static int regrid_backward_impl(R *d_I, const R *go, int dim, int64_t nn, int64_
     if (g.nblocks && nn * nc) {
         if (dim == 3 && g_splat_mode >= 1) {
             Geom gt;
-            if (make_geom(gt, 3, 1, nx, ny, nz)) {
+            if (make_geom(gt, 3, 1, nx, ny, nz, kBlock, true)) {
                 const int rc = regrid_splat_lds<R>(d_I, go, nn * nc, gt, g, rp.O, rp.S, s);
                 if (rc <= 0) return rc;  // done (or failed); 1 = shape left to the plain kernel
             }
         }
+        note_path(LP_SPLAT_GLOBAL);
         if (dim == 3)
             hipLaunchKernelGGL((regrid_bwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, d_I, go, (int)(nn * nc), g, rp);
         else

@@ -103,7 +103,12 @@ struct Geom {
     FastDiv dyz, dz, dnbx;
 };
 
-inline bool make_geom(Geom &g, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, int vox_per_block = kBlock) {
+// scatter = true: the launch feeds a scatter-add (splats, the d_A / d_T reductions).  Float atomics round in arrival
+// order, so the block order of such a launch shows in the last bits of its result: it is then always ascending and the
+// call leaves the alternation counter alone -- the bits of a scatter-add never depend on which calls (of any kind, valid
+// or rejected) this process has made before (tests/test_gpu_dispatch.py: test_scatter_direction_is_history_free).
+inline bool make_geom(Geom &g, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, int vox_per_block = kBlock,
+                      bool scatter = false) {
     // one channel of one batch item is addressed with 32-bit byte offsets: nvox * 8 < 2^32
     if (dim == 2) {
         nz = ny;
@@ -121,7 +126,7 @@ inline bool make_geom(Geom &g, int dim, int64_t nn, int64_t nx, int64_t ny, int6
     int64_t nb = (int64_t)g.nbx * nn;
     if (nb >= (1ll << 31)) return false;
     g.nblocks = (uint32_t)nb;
-    g.rev = next_direction();
+    g.rev = scatter ? 0 : next_direction();
     g.dyz = FastDiv((uint32_t)(ny * nz));
     g.dz = FastDiv((uint32_t)nz);
     g.dnbx = FastDiv(g.nbx);

@@ -46,6 +46,8 @@ int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, 
                     hipStream_t s);
 // fftg.hip
 bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz, size_t esize);
+void bluestein_cache_clear();   // fftg.hip
+int bluestein_cache_entries();
 template <typename R>
 int fluid_metric_generic(R *out, const R *m, R *work, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
                          const R *cosZ, const R *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn, int64_t nx,
@@ -520,6 +522,7 @@ void tune_fluid(int mode) { g_fluid_xpass = mode < 0 ? 0 : (mode > 3 ? 3 : mode)
 
 extern "C" {
 void lago_fluid_cache_clear(void) {
+    lago::bluestein_cache_clear();       // the generic passes' chirp tables (fftg.hip)
     std::vector<lago::CoefRef> dropped;  // released after the lock
     std::lock_guard<std::mutex> lk(lago::g_plan_mu);
     dropped.swap(lago::g_tabs);

@@ -497,20 +497,41 @@ static void factorise(int N, GLines &a) {
     if (n > 1) a.fac[a.nfac++] = n;
 }
 
+static int largest_prime_factor(int n) {
+    int best = 1;
+    for (int p = 2; (long long)p * p <= n; ++p)
+        while (n % p == 0) { best = p; n /= p; }
+    return n > 1 ? n : best;
+}
+// LDS bytes of ONE Bluestein line in the ping-pong form (lines_pass below: (2 (L | 1) + 1) M + N complex numbers at
+// L = 1), M >= 2 N - 1 a power of two.  (lines_pass takes the in-place form only to widen a pass that already fits.)
+static size_t bluestein_lds(int N, size_t cb) {
+    int M = 1;
+    while (M < 2 * N - 1) M <<= 1;
+    return ((size_t)3 * M + N) * cb;
+}
+
 // three line buffers' worth of complex numbers (ping-pong + roots) must fit the LDS for ONE line: 4096 points of
-// float32, 2048 of float64
+// float32, 2048 of float64.  A line with a prime factor of 29 or more runs as a Bluestein convolution, whose
+// power-of-two length M >= 2 N - 1 needs its own room; where even one such line does not fit (N above 2048 in
+// float32, above 1024 in float64) the direct-DFT stage would cost N r multiply-adds per line (r = 4093: 17 M per
+// line) -- such a shape is NOT taken here and goes to the guarded rocFFT plan.
 bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz, size_t esize) {
     const int64_t maxn = esize == 4 ? 4096 : 2048;
     const int64_t ext[3] = {dim == 3 ? nx : 1, dim == 3 ? ny : nx, dim == 3 ? nz : ny};
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < 3; ++d) {
         if (ext[d] < 1 || ext[d] > maxn) return false;
+        if (largest_prime_factor((int)ext[d]) >= 29 && bluestein_lds((int)ext[d], 2 * esize) > 160 * 1024) return false;
+    }
     return true;
 }
 
 // ---- Bluestein tables: FFT_M of the conjugate chirp, per (N, sign, precision, device); computed on first use by one
-// workgroup and kept for the life of the process (at most a few hundred KB each).  The first use synchronises the
-// stream once (another stream may be the next user); while a stream is being captured a missing table is not built and
-// the direct-DFT stages serve that call.
+// workgroup and kept (at most a few hundred KB each, at most kBluMax tables: a full cache is emptied before the next
+// insertion) until lago_fluid_cache_clear() releases them.  The first use synchronises the stream once (another stream
+// may be the next user); while THIS stream is being captured a missing table is not built and the direct-DFT stages
+// serve that call; the allocation itself runs with the thread's capture mode relaxed, so that a global-mode capture in
+// progress on another thread is not invalidated by it.
 struct BluKey {
     int N, sign, esize, dev;
     bool operator<(const BluKey &o) const {
@@ -519,12 +540,19 @@ struct BluKey {
 };
 static std::mutex g_blu_mu;
 static std::map<BluKey, void *> *g_blu = nullptr;   // (heap: never destroyed, as the coefficient cache of fft.hip)
-
-static int largest_prime_factor(int n) {
-    int best = 1;
-    for (int p = 2; (long long)p * p <= n; ++p)
-        while (n % p == 0) { best = p; n /= p; }
-    return n > 1 ? n : best;
+constexpr size_t kBluMax = 64;
+static void blu_release_locked() {   // hipFree waits for the device: no kernel still reads a table
+    if (!g_blu) return;
+    for (auto &kv : *g_blu) (void)hipFree(kv.second);
+    g_blu->clear();
+}
+void bluestein_cache_clear() {
+    std::lock_guard<std::mutex> lk(g_blu_mu);
+    blu_release_locked();
+}
+int bluestein_cache_entries() {
+    std::lock_guard<std::mutex> lk(g_blu_mu);
+    return g_blu ? (int)g_blu->size() : 0;
 }
 
 template <typename R>
@@ -540,7 +568,14 @@ static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     const size_t cb = 2 * sizeof(R);
     void *d = nullptr;
-    if (hipMalloc(&d, (size_t)M * cb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (g_blu->size() >= kBluMax) blu_release_locked();
+    {
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+        const hipError_t e = hipMalloc(&d, (size_t)M * cb);
+        if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
     GLines a;
     a.N = N; a.M = M; a.sign = sign; a.L = 1; a.Lp = 1; a.mode = 0; a.inner = 1; a.nlines = 1; a.ppp = 1; a.chunks = 1;
     a.nhalf = N / 2 + 1; a.bhat = nullptr; a.inplace = 0;

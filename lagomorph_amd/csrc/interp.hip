@@ -581,7 +581,7 @@ static int interp_backward_impl(R *d_I, R *d_u, const R *go, const R *I, const R
         return fail_invalid("interp_backward_fused: u_mode must be 0, 1 or 2 (2 needs as many channels as dimensions)");
     if (umode && !need_u) return fail_invalid("interp_backward_fused: u_mode != 0 needs need_u");
     Geom g;
-    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz)) return fail_invalid("interp_backward: bad extent");
+    if (nc < 0 || !make_geom(g, dim, nn, nx, ny, nz, kBlock, true)) return fail_invalid("interp_backward: bad extent");
     hipStream_t s = (hipStream_t)stream;
     const size_t nI = (size_t)(bc ? 1 : nn) * nc * g.nvox;
     const size_t nu = (size_t)nn * dim * g.nvox;
@@ -618,7 +618,7 @@ template <typename R>
 static int hessdiag_impl(R *out, const R *u, double dt, int64_t nI, int64_t nn, int64_t nc, int64_t nx, int64_t ny,
                          void *stream) {
     Geom g;
-    if (nc < 0 || nI < 0 || !make_geom(g, 2, nn, nx, ny, 1))
+    if (nc < 0 || nI < 0 || !make_geom(g, 2, nn, nx, ny, 1, kBlock, true))
         return fail_invalid("interp_hessian_diagonal_image: bad extent");
     hipStream_t s = (hipStream_t)stream;
     size_t no = (size_t)nI * nc * g.nvox;

@@ -552,6 +552,13 @@ def affine_interp_backward(grad_out, I, A, T, need_I, need_A, need_T):
     return [d_I, d_A, d_T]
 
 
+def _overlaps(a, b):
+    """Do the byte ranges of two contiguous tensors intersect?  (a partially overlapping view counts: the kernel
+    gathers from its inputs while it writes `out`)"""
+    a0, b0 = a.data_ptr(), b.data_ptr()
+    return a.numel() > 0 and b.numel() > 0 and a0 < b0 + b.numel() * b.element_size() and b0 < a0 + a.numel() * a.element_size()
+
+
 def compose(u, v, ds=1.0, dt=1.0, out=None):
     """Fused deform.compose (deform.py:53-55): ds*u + dt*interp(v, u, dt=ds) in one kernel.
     Not part of the reference's extension surface; u and v are (N, d, *spatial) vector fields.  `out`: a contiguous
@@ -569,7 +576,7 @@ def compose(u, v, ds=1.0, dt=1.0, out=None):
     else:
         _check_input(out, "out")
         _same(u, out)
-        if out.shape != u.shape or out.data_ptr() in (u.data_ptr(), v.data_ptr()):
+        if out.shape != u.shape or _overlaps(out, u) or _overlaps(out, v):
             raise RuntimeError("compose: out must have the shape of u and must not alias an input")
     _call("lago_compose", u, _ptr(out), _ptr(u), _ptr(v), float(ds), float(dt), dim, u.size(0), nx, ny, nz)
     return out

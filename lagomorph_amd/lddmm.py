@@ -118,15 +118,16 @@ def _shoot(metric, m0, phiinv, dt, num_steps, v0, keep, out=None):
     return phi, steps, first
 
 
-# A forward-only shoot (no gradient wanted) of at least 2 * EXPMAP_STREAMS batch items can be cut into EXPMAP_STREAMS
+# A forward-only shoot (no gradient wanted) of at least 2 * EXPMAP_STREAMS batch items is cut into EXPMAP_STREAMS
 # contiguous sub-batches that run on HIP streams of their own: batch items are independent, and the tail of one part's
 # kernel (the last workgroups of a launch leave most CUs idle) then overlaps with the head of another part's next
-# kernel.  Measured (tools/ab_streams.py, round 4, profiles/r04_stream_split.md): 22.28 -> 21.66 ms at 32 x 128^3,
-# 5.84 -> 5.55 at 8 x 128^3, same bits; capping the gather kernels to one workgroup per CU so that the other part's
-# FFT passes co-reside costs 30 %.  OFF by default (1): with two parts in flight a kernel's launch
-# duration is no longer the time it needs by itself, and the benchmark's per-kernel roofline is measured on the
-# default path; `lagomorph_amd.lddmm.EXPMAP_STREAMS = 2` switches it on (bench.py reports it beside the headline).
-EXPMAP_STREAMS = 1
+# kernel.  Measured (tools/ab_streams.py, profiles/r04_stream_split.md): 22.28 -> 21.66 ms at 32 x 128^3, 5.84 -> 5.55
+# at 8 x 128^3; the driver's round-4 run 21.32 -> 21.14 ms; same bits (tests/test_gpu_lddmm_step.py:
+# test_expmap_stream_split_same_bits).  ON by default since round 5 (2 parts, i.e. batches of 4 and more; smaller ones
+# and every shoot that keeps its steps for a backward pass run on the caller's stream alone); `EXPMAP_STREAMS = 1`
+# switches it off -- bench.py does so for the pass it takes its per-kernel roofline from, because with two parts in
+# flight a launch's duration is no longer the time the kernel needs by itself.
+EXPMAP_STREAMS = 2
 _side_streams = {}
 
 

@@ -340,6 +340,44 @@ def test_affine_interp(ext, dtype, sp, nn, nc, bc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp,nn,nc,bc,kind", [((65, 70, 72), 4, 1, False, "random"), ((64, 64, 130), 2, 2, True, "random"),
+                                              ((33, 129, 127), 2, 1, False, "rotation"), ((128, 128, 64), 1, 1, False, "far")])
+def test_affine_forward_several_voxels_per_lane(ext, dtype, sp, nn, nc, bc, kind):
+    """affine_fwd3_multi_kernel (round 5: launches of 2^20 voxels and more give a lane one voxel of each of four
+    consecutive 256-voxel slabs): bit for bit against the oracle -- ragged last workgroups (volumes that are no
+    multiple of 1024 voxels), broadcast image, two channels, a rotation, and a map that sends most samples out of range."""
+    rng = np.random.default_rng(hash((sp, nn, nc)) % 2**31)
+    I = rnd(rng, ((1 if bc else nn), nc) + sp, dtype)
+    if kind == "rotation":
+        c, s_ = np.cos(0.35), np.sin(0.35)
+        A = np.tile(np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]), (nn, 1, 1)).astype(I.dtype)
+        T = (0.7 * rng.standard_normal((nn, 3))).astype(I.dtype)
+    elif kind == "far":
+        A = (2.5 * np.eye(3)[None] + 0.3 * rng.standard_normal((nn, 3, 3))).astype(I.dtype)
+        T = (40.0 * rng.standard_normal((nn, 3))).astype(I.dtype)
+    else:
+        A = (np.eye(3)[None] + 0.1 * rng.standard_normal((nn, 3, 3))).astype(I.dtype)
+        T = (1.5 * rng.standard_normal((nn, 3))).astype(I.dtype)
+    assert int(np.prod(sp)) * nn >= 1 << 20   # the multi-voxel kernel's threshold (affine.hip: affine_forward_impl)
+    assert_bits(ext.affine_interp_forward(dev(I), dev(A), dev(T)), orc.affine_interp_forward(I, A, T), "affine forward (multi)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp,out,nn,nc", [((20, 24, 28), (40, 48, 56), 3, 3), ((40, 48, 56), (20, 24, 28), 1, 5),
+                                          ((8, 8, 8), (6, 5, 1030), 1, 2), ((8, 8, 8), (6, 5, 1024), 2, 1)])
+def test_regrid_forward_planes_in_the_grid(ext, dtype, sp, out, nn, nc):
+    """regrid_fwd3_planes_kernel (round 5: plane groups in blockIdx.y, the reference's running sum hz += Sz evaluated
+    once per workgroup into an LDS table): bit for bit against the oracle -- plane counts that are no multiple of the
+    group size, rows at and beyond the table's 1024 entries (the latter stay on the per-lane kernel)."""
+    rng = np.random.default_rng(hash((sp, out)) % 2**31)
+    I = rnd(rng, (nn, nc) + sp, dtype)
+    origin = [(s - 1) * 0.5 + 0.3 for s in sp]
+    spacing = [(a - 1) / (b - 1) if b > 1 else 1.0 for a, b in zip(sp, out)]
+    assert_bits(ext.regrid_forward(dev(I), list(out), origin, spacing), orc.regrid_forward(I, list(out), origin, spacing),
+                "regrid forward (planes)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp,out", [((4, 5, 6), (5, 7, 9)), ((6, 6, 6), (3, 3, 3)), ((4, 5), (9, 4)), ((2, 2, 2), (3, 3, 70))])
 def test_regrid(ext, dtype, sp, out):
     rng = np.random.default_rng(hash((sp, out)) % 2**31)
@@ -949,6 +987,46 @@ def test_regrid_backward_every_form(ext, dtype, sp, out, scale):
     finally:
         ext.REGRID_BACKWARD_SEPARABLE = 1
     assert_close(got0, want, dtype, "regrid backward (global atomics)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("origin,spacing,sep", [
+    ([2.0e9, 3.0, 4.0], [1.0, 0.5, 0.5], False),     # |origin| >= 1e9: beyond the separable passes' checks
+    ([3.0, 3.0, 4.0], [2.0e6, 0.5, 0.5], False),     # spacing >= 1e6
+    ([3.0, 3.0, 4.0], [1e-9, 0.5, 0.5], None),       # a spacing so small that float32 rounding moves a sample by many cells (float64: still separable)
+    ([3.0, 3.0, 4.0], [1e-3, 0.5, 0.5], True),       # small but well inside: wider candidate window, still separable
+    ([3.0, 3.0, 4.0], [0.5, -0.5, 0.5], False)])     # a non-positive spacing (the Python side already routes it)
+def test_regrid_backward_separable_entry_accepts_what_the_reference_accepts(ext, dtype, origin, spacing, sep):
+    """lago_regrid_backward_sep used to FAIL on inputs outside its checks although lago_regrid_backward (and
+    the reference, cuda/affine.cu:802-855) serve them; now the entry point itself falls back to the splat.  Called with
+    the workspace the separable form would need, so that the C entry -- not the Python predicate -- takes the decision."""
+    rng = np.random.default_rng(31)
+    sp, out = (6, 8, 20), (9, 10, 33)
+    go = rnd(rng, (2, 2) + out, dtype)
+    want = orc.regrid_backward(go, sp, out, origin, spacing)
+    before = ext.path_launches()
+    got = ext.regrid_backward(dev(go), sp, out, origin, spacing)
+    torch.cuda.synchronize()
+    after = ext.path_launches()
+    splat_ran = any(after[k] != before[k] for k in ("splat_tiled", "splat_global"))
+    if sep is None:
+        sep = dtype == torch.float64
+    if all(x > 0 for x in spacing):
+        assert splat_ran == (not sep), (origin, spacing, {k: after[k] - before[k] for k in after})
+    assert_close(got, want, dtype, "regrid backward (separable entry, fallback)")
+
+
+def test_compose_rejects_partially_overlapping_out(ext):
+    """`out` overlapping an input only partly (a shifted view of one buffer) passed the pointer-equality
+    check; the kernel would gather from what it is overwriting."""
+    buf = torch.zeros((3, 3, 8, 8, 8), device="cuda")
+    u = torch.randn((2, 3, 8, 8, 8), device="cuda")
+    with pytest.raises(RuntimeError, match="alias"):
+        ext.compose(u, buf[:-1], 1.0, 1.0, out=buf[1:])
+    with pytest.raises(RuntimeError, match="alias"):
+        ext.compose(buf[1:], u, 1.0, 1.0, out=buf[:-1])
+    sep = torch.empty_like(u)
+    assert ext.compose(u, buf[:-1], 1.0, 1.0, out=sep) is sep
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

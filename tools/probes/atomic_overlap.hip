@@ -28,7 +28,7 @@ __device__ __forceinline__ void stream_tile(float* __restrict__ out, const float
         keep += v4;
     }
 }
-template <bool ATOMIC>
+template <int FL>  // 0 atomic, 1 plain store, 2 plain load + add + store (what a colour-phased flush issues)
 __device__ __forceinline__ void flush_tile(float* __restrict__ dI, int n, int bx, int by, float val) {
     const size_t nv = (size_t)S * S * S;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,23 +37,60 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ dI, int n, int bx
         const int gx = min(bx * TX + lx, S - 1), gy = min(by * TY + ly, S - 1);
         float* grow = dI + (size_t)n * nv + ((size_t)gx * S + gy) * S;
         for (int z = lane; z < S; z += 64) {
-            if (ATOMIC) unsafeAtomicAdd(grow + z, val);
-            else grow[z] = val;
+            if (FL == 0) unsafeAtomicAdd(grow + z, val);
+            else if (FL == 1) grow[z] = val;
+            else grow[z] = __builtin_nontemporal_load(grow + z) + val;
         }
     }
 }
-template <int MODE>  // 0 stream, 1 atomic, 2 store, 3 phased, 4 split
+// round 5: the colour-phased flush.  MODE 5: flush only, read-modify-write; 6: stream, then RMW flush
+// (all tiles in ONE launch: races, timing only -- the bound of any colouring); 7: stream, then plain stores (bound of a
+// flush into private slabs).  COLOUR launches (kc): the tiles of one (bx & 1, by & 1) colour per launch, four launches
+// -- windows of one colour are disjoint, the kernel boundary orders the colours: a flush that is correct without atomics.
+template <int MODE>  // 0 stream, 1 atomic, 2 store, 3 phased, 4 split, 5 rmw, 6 phased rmw, 7 phased store
 __global__ __launch_bounds__(NT) void k(float* dI, float* out, const float* in) {
     extern __shared__ double win[];
     int b = blockIdx.x;
-    bool do_stream = MODE == 0 || MODE == 3, do_flush = MODE == 1 || MODE == 2 || MODE == 3;
+    bool do_stream = MODE == 0 || MODE == 3 || MODE == 6 || MODE == 7, do_flush = MODE != 0 && MODE != 4;
     if (MODE == 4) { do_stream = (b & 1) == 0; do_flush = !do_stream; b >>= 1; }
     const int n = b / (NTX * NTY), r = b % (NTX * NTY), bx = r / NTY, by = r % NTY;
     float keep = 0.f;
     if (do_stream) stream_tile(out, in, n, bx, by, keep);
-    if (MODE == 3) __syncthreads();
-    if (do_flush) { if (MODE == 2) flush_tile<false>(dI, n, bx, by, 1.f + keep * 1e-30f); else flush_tile<true>(dI, n, bx, by, 1.f + keep * 1e-30f); }
+    if (MODE == 3 || MODE >= 6) __syncthreads();
+    if (do_flush) {
+        if (MODE == 2 || MODE == 7) flush_tile<1>(dI, n, bx, by, 1.f + keep * 1e-30f);
+        else if (MODE == 5 || MODE == 6) flush_tile<2>(dI, n, bx, by, 1.f + keep * 1e-30f);
+        else flush_tile<0>(dI, n, bx, by, 1.f + keep * 1e-30f);
+    }
     if (keep == 1.2345e30f) win[0] = 1.0;
+}
+// one colour of tiles per launch: colour = (cx, cy), tiles bx = 2 i + cx, by = 2 j + cy.  FL as in flush_tile; STREAM: with the operands
+template <int FL, bool STREAM>
+__global__ __launch_bounds__(NT) void kc(float* dI, float* out, const float* in, int cx, int cy, int ncx, int ncy) {
+    extern __shared__ double win[];
+    const int b = blockIdx.x;
+    const int n = b / (ncx * ncy), r = b % (ncx * ncy), bx = 2 * (r / ncy) + cx, by = 2 * (r % ncy) + cy;
+    float keep = 0.f;
+    if (STREAM) { stream_tile(out, in, n, bx, by, keep); __syncthreads(); }
+    flush_tile<FL>(dI, n, bx, by, 1.f + keep * 1e-30f);
+    if (keep == 1.2345e30f) win[0] = 1.0;
+}
+template <int FL, bool STREAM> float runc(float* dI, float* out, const float* in, size_t smem, int* blocks_out) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kc<FL, STREAM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    auto all = [&]() {
+        for (int cx = 0; cx < 2; ++cx) for (int cy = 0; cy < 2; ++cy) {
+            const int ncx = (NTX - cx + 1) / 2, ncy = (NTY - cy + 1) / 2;
+            kc<FL, STREAM><<<B * ncx * ncy, NT, smem>>>(dI, out, in, cx, cy, ncx, ncy);
+            if (blocks_out) blocks_out[cx * 2 + cy] = B * ncx * ncy;
+        }
+    };
+    for (int i = 0; i < 3; ++i) all();
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    for (int i = 0; i < 10; ++i) all();
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / 10 * 1e3f;
 }
 // persistent forms: G workgroups walk the tiles (tile = blockIdx.x, += G).  PM 0: every wave streams its tile, then flushes it,
 // no barrier anywhere (waves drift apart: loads, stores and atomics of different tiles in flight together); PM 1: waves
@@ -126,6 +163,15 @@ int main() {
         printf("LDS %3zu KB per workgroup (%d per CU): stream %.1f us (%.2f TB/s)  atomic flush %.1f us (%.2f TB/s)  store flush %.1f us\n"
                "    phased %.1f us   split %.1f us   [sum %.1f, max %.1f]\n",
                smem / 1024, (int)(160 * 1024 / smem), ts, streamMB / ts, ta, flushMB / ta, tp, t3, t4, ts + ta, ts > ta ? ts : ta);
+    }
+    for (size_t smem : {(size_t)80 * 1024, (size_t)40 * 1024}) {
+        const float t5 = run<5>(dI, out, in, smem), t6 = run<6>(dI, out, in, smem), t7 = run<7>(dI, out, in, smem);
+        int nb[4];
+        const float c0 = runc<0, true>(dI, out, in, smem, nb), c2 = runc<2, true>(dI, out, in, smem, nb), c1 = runc<1, true>(dI, out, in, smem, nb);
+        const float f2 = runc<2, false>(dI, out, in, smem, nb);
+        printf("LDS %3zu KB: rmw flush only %.1f us (%.2f TB/s of cells)   one launch: stream + rmw %.1f us, stream + store %.1f us\n"
+               "    four colour launches (%d/%d/%d/%d workgroups): stream + atomic %.1f us, stream + rmw %.1f us, stream + store %.1f us, rmw flush only %.1f us\n",
+               smem / 1024, t5, flushMB / t5, t6, t7, nb[0], nb[1], nb[2], nb[3], c0, c2, c1, f2);
     }
     for (int grid : {256, 512, 128}) {
         printf("persistent, %d workgroups of 1024: stream only %.1f us  flush only %.1f us  every wave stream+flush %.1f us  waves split 8/8 %.1f us\n",
