@@ -147,6 +147,13 @@ int lago_set_tuning(const lago_tuning *t);
 #define LAGO_PATH_SPLAT_AFFINE_BOX 12 /* affine_interp_backward's image splat by target boxes */
 #define LAGO_PATH_FLUID_GENERIC 13 /* lago_fluid_metric: generic hand-written FFT passes (any extent, both precisions) */
 long long lago_path_launches(int path);
+/* Launch direction (lago_tuning.launch_order): launches so far that walked their workgroups in DESCENDING order.  Kernels
+ * whose results do not depend on the block order alternate (a consumer starts on what the Infinity Cache still holds of
+ * its producer's output); every launch that feeds a scatter-add (interp_backward, interp_hessian_diagonal_image,
+ * affine_interp_backward, regrid_backward) walks ascending and leaves the alternation alone, so that the arrival order
+ * of its float atomics -- the last bits of d_I, d_A, d_T -- never depends on the calls made before it.  Telemetry for
+ * tests/test_gpu_dispatch.py::test_scatter_direction_is_history_free. */
+long long lago_reversed_launches(void);
 
 
 #define LAGO_DECLARE(REAL, SUF)                                                                                      \

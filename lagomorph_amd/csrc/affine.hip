@@ -12,6 +12,7 @@
 // shuffles (64 lanes), combines its 4 waves through LDS and issues one float
 // atomic per matrix entry, so the launch fills all 256 CUs.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "common.hpp"
 
@@ -36,7 +37,7 @@ __device__ __forceinline__ R half_extent(int n) {  // `.5*static_cast<Real>(n-1)
 
 // ------------------------------------------------------------------ affine forward
 
-template <typename R, int DIM, bool BC>
+template <typename R, int DIM, bool BC, int NTS = LAGO_NT_AFFINE_ST>
 __global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out, const R *__restrict__ I,
                                                             const R *__restrict__ A, const R *__restrict__ T,
                                                             int nc, Geom g) {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out,
         const R hz = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
         Lerp3<R> L;
         L.setup(hx, hy, hz, g.nx, g.ny, g.nz);
-        for (int c = 0; c < nc; ++c) st_pol<LAGO_NT_AFFINE_ST>(&on[(size_t)c * nv], L.value(In + (size_t)c * nv));
+        for (int c = 0; c < nc; ++c) st_pol<NTS>(&on[(size_t)c * nv], L.value(In + (size_t)c * nv));
     } else {
         const R ox = half_extent<R>(g.ny), oy = half_extent<R>(g.nz);
         const R fi = (R)v.j - ox, fj = (R)v.k - oy;
@@ -63,57 +64,7 @@ __global__ __launch_bounds__(kBlock) void affine_fwd_kernel(R *__restrict__ out,
         const R hy = lg_fma(An[2], fi, An[3] * fj) + Tn[1] + oy;
         Lerp2<R> L;
         L.setup(hx, hy, g.ny, g.nz);
-        for (int c = 0; c < nc; ++c) st_pol<LAGO_NT_AFFINE_ST>(&on[(size_t)c * nv], L.value(In + (size_t)c * nv));
-    }
-}
-
-// 3D, several voxels per lane (round 5).  The kernel above gives a lane ONE voxel: four pair gathers, one lerp, one
-// 4-byte store, then the wave retires -- 65 536 workgroups of one dependent memory round trip each at 8 x 128^3
-// (52 us = 0.32 of HBM peak, profiles/r05_affine_regrid_forward.md).  Here a lane owns voxel tid of each of VPT
-// consecutive 256-voxel slabs of one batch item: the positions of all its voxels first, then per channel every gather
-// of the VPT voxels in flight together.  Same expressions per voxel: bit-identical.
-#ifndef LAGO_AFFINE_VPT
-#define LAGO_AFFINE_VPT 4
-#endif
-template <typename R, bool BC, int VPT>
-__global__ __launch_bounds__(kBlock) void affine_fwd3_multi_kernel(R *__restrict__ out, const R *__restrict__ I,
-                                                                   const R *__restrict__ A, const R *__restrict__ T,
-                                                                   int nc, Geom g) {
-    const uint32_t L = block_order(blockIdx.x, g.nblocks, g.rev);
-    const uint32_t n = g.dnbx.div(L);
-    const uint32_t s0 = (L - n * g.nbx) * (uint32_t)(kBlock * VPT) + threadIdx.x;
-    const size_t nv = g.nvox;
-    const R *An = A + (size_t)n * 9;
-    const R *Tn = T + (size_t)n * 3;
-    const R *In = BC ? I : I + (size_t)n * nc * nv;
-    R *on = out + (size_t)n * nc * nv;
-    const R ox = half_extent<R>(g.nx), oy = half_extent<R>(g.ny), oz = half_extent<R>(g.nz);
-    const R a0 = An[0], a1 = An[1], a2 = An[2], a3 = An[3], a4 = An[4], a5 = An[5], a6 = An[6], a7 = An[7], a8 = An[8];
-    const R t0 = Tn[0], t1 = Tn[1], t2 = Tn[2];
-    Lerp3<R> Lq[VPT];
-    bool ok[VPT];
-#pragma unroll
-    for (int e = 0; e < VPT; ++e) {
-        const uint32_t sv = s0 + (uint32_t)(e * kBlock);
-        ok[e] = sv < g.nvox;
-        const uint32_t sl = ok[e] ? sv : 0u;
-        const uint32_t ii = g.dyz.div(sl);
-        const uint32_t rr = sl - ii * (uint32_t)(g.ny * g.nz);
-        const uint32_t jj = g.dz.div(rr);
-        const R fi = (R)(int)ii - ox, fj = (R)(int)jj - oy, fk = (R)(int)(rr - jj * (uint32_t)g.nz) - oz;
-        const R hx = lg_fma(a2, fk, lg_fma(a0, fi, a1 * fj)) + t0 + ox;   // cuda/affine.cu:42-61
-        const R hy = lg_fma(a5, fk, lg_fma(a3, fi, a4 * fj)) + t1 + oy;
-        const R hz = lg_fma(a8, fk, lg_fma(a6, fi, a7 * fj)) + t2 + oz;
-        Lq[e].setup(hx, hy, hz, g.nx, g.ny, g.nz);
-    }
-    for (int c = 0; c < nc; ++c) {
-        const R *Ic = In + (size_t)c * nv;
-        R val[VPT];
-#pragma unroll
-        for (int e = 0; e < VPT; ++e) val[e] = Lq[e].value(Ic);
-#pragma unroll
-        for (int e = 0; e < VPT; ++e)
-            if (ok[e]) st_pol<LAGO_NT_AFFINE_ST>(&on[(size_t)c * nv + s0 + (uint32_t)(e * kBlock)], val[e]);
+        for (int c = 0; c < nc; ++c) st_pol<NTS>(&on[(size_t)c * nv], L.value(In + (size_t)c * nv));
     }
 }
 
@@ -431,7 +382,7 @@ struct RegridParams {
 };
 
 // Output-grid geometry in g; input extents in rp.
-template <typename R, int DIM>
+template <typename R, int DIM, int NTS = LAGO_NT_AFFINE_ST>
 __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out, const R *__restrict__ I,
                                                             int nq, Geom g, RegridParams rp) {
     const Vox v = locate(g);  // v.n unused: (n, c) planes are looped here
@@ -450,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out,
         for (int k = 0; k < v.k; ++k) hz += Sz;
         Lerp3<R> L;
         L.setup(hx, hy, hz, rp.nx, rp.ny, rp.nz);
-        for (int q = 0; q < nq; ++q) st_pol<LAGO_NT_AFFINE_ST>(&out[(size_t)q * Nv + v.s], L.value(I + (size_t)q * nvin));
+        for (int q = 0; q < nq; ++q) st_pol<NTS>(&out[(size_t)q * Nv + v.s], L.value(I + (size_t)q * nvin));
     } else {
         const R Ox = (R)rp.O[0], Oy = (R)rp.O[1];
         const R Sx = (R)rp.S[0], Sy = (R)rp.S[1];
@@ -459,47 +410,8 @@ __global__ __launch_bounds__(kBlock) void regrid_fwd_kernel(R *__restrict__ out,
         const R hy = lg_fma((R)v.k - oy, Sy, Oy);
         Lerp2<R> L;
         L.setup(hx, hy, rp.ny, rp.nz);
-        for (int q = 0; q < nq; ++q) st_pol<LAGO_NT_AFFINE_ST>(&out[(size_t)q * Nv + v.s], L.value(I + (size_t)q * nvin));
+        for (int q = 0; q < nq; ++q) st_pol<NTS>(&out[(size_t)q * Nv + v.s], L.value(I + (size_t)q * nvin));
     }
-}
-
-// 3D, planes in the grid (round 5).  The kernel above loops over ALL nn * nc planes inside one thread -- 24 dependent
-// gather / store round trips per wave at 8 x 3 planes, and only Nv / 256 workgroups (101 us for 64^3 -> 128^3 = 0.28
-// of HBM peak) -- and every lane finds its hz by up to nz sequential adds.  Here blockIdx.y picks a group of QPT planes
-// whose gathers are all in flight together, and the reference's running sum `hz += Sz` (cuda/affine.cu:669-675) is
-// evaluated ONCE per workgroup, by one lane into an LDS table of nz entries -- the same sequentially rounded values.
-#ifndef LAGO_REGRID_QPT
-#define LAGO_REGRID_QPT 4
-#endif
-constexpr int kRegridTab = 1024;   // longest output row the table form serves
-template <typename R, int QPT>
-__global__ __launch_bounds__(kBlock) void regrid_fwd3_planes_kernel(R *__restrict__ out, const R *__restrict__ I,
-                                                                    int nq, Geom g, RegridParams rp) {
-    __shared__ R hzt[kRegridTab];
-    const R Sz = (R)rp.S[2];
-    if (threadIdx.x == 0) {
-        R hz = lg_fma(-half_extent<R>(g.nz), Sz, (R)rp.O[2]);
-        for (int k = 0; k < g.nz; ++k) {
-            hzt[k] = hz;
-            hz += Sz;
-        }
-    }
-    __syncthreads();
-    const Vox v = locate(g);  // (one "batch item": the planes are blockIdx.y's)
-    if (!v.valid) return;
-    const size_t Nv = g.nvox;
-    const size_t nvin = (size_t)rp.nx * rp.ny * rp.nz;
-    const R hx = lg_fma((R)v.i - half_extent<R>(g.nx), (R)rp.S[0], (R)rp.O[0]);
-    const R hy = lg_fma((R)v.j - half_extent<R>(g.ny), (R)rp.S[1], (R)rp.O[1]);
-    Lerp3<R> L;
-    L.setup(hx, hy, hzt[v.k], rp.nx, rp.ny, rp.nz);
-    const int q0 = (int)blockIdx.y * QPT;
-    R val[QPT];
-#pragma unroll
-    for (int e = 0; e < QPT; ++e) val[e] = L.value(I + (size_t)min(q0 + e, nq - 1) * nvin);
-#pragma unroll
-    for (int e = 0; e < QPT; ++e)
-        if (q0 + e < nq) st_pol<LAGO_NT_AFFINE_ST>(&out[(size_t)(q0 + e) * Nv + v.s], val[e]);
 }
 
 template <typename R, int DIM>
@@ -738,17 +650,15 @@ static int affine_forward_impl(R *out, const R *I, const R *A, const R *T, int d
     if (g.nblocks == 0 || nc == 0) return LAGO_OK;
     if (!out || !I || !A || !T) return fail_invalid("affine_interp_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    // large 3D launches: several voxels per lane (same bits); small ones keep one voxel per lane -- more workgroups
-    if (dim == 3 && (int64_t)g.nvox * nn >= (1ll << 20)) {
-        Geom gm;
-        if (make_geom(gm, 3, nn, nx, ny, nz, kBlock * LAGO_AFFINE_VPT)) {
-            if (bc) hipLaunchKernelGGL((affine_fwd3_multi_kernel<R, true, LAGO_AFFINE_VPT>), dim3(gm.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, gm);
-            else hipLaunchKernelGGL((affine_fwd3_multi_kernel<R, false, LAGO_AFFINE_VPT>), dim3(gm.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, gm);
-            return finish_launch(s, "affine_interp_forward");
-        }
-    }
-#define LAUNCH(D, B) \
-    hipLaunchKernelGGL((affine_fwd_kernel<R, D, B>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, g)
+    // Output stores non-temporal once input + output exceed the Infinity Cache (8 x 3 x 128^3: 209 -> 140 us; C = 1,
+    // 134 MB in all: no difference).  The kernel is bound by the rate of its four pair gathers per output value, like
+    // every gather kernel of the library (profiles/r05_affine_regrid_forward.md): several voxels per lane changed nothing.
+    const bool big = (double)(nn + (bc ? 1 : nn)) * nc * g.nvox * sizeof(R) > 256.0 * 1024 * 1024;
+#define LAUNCH(D, B)                                                                                                     \
+    do {                                                                                                                 \
+        if (big) hipLaunchKernelGGL((affine_fwd_kernel<R, D, B, 1>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, g); \
+        else hipLaunchKernelGGL((affine_fwd_kernel<R, D, B, 0>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, A, T, (int)nc, g);     \
+    } while (0)
     if (dim == 3) {
         if (bc) LAUNCH(3, true); else LAUNCH(3, false);
     } else {
@@ -851,14 +761,15 @@ static int regrid_forward_impl(R *out, const R *I, int dim, int64_t nn, int64_t 
     if (g.nblocks == 0 || nn * nc == 0) return LAGO_OK;
     if (!out || !I) return fail_invalid("regrid_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t groups = (nn * nc + LAGO_REGRID_QPT - 1) / LAGO_REGRID_QPT;
-    if (dim == 3 && g.nz <= kRegridTab && groups <= 65535)
-        hipLaunchKernelGGL((regrid_fwd3_planes_kernel<R, LAGO_REGRID_QPT>), dim3(g.nblocks, (uint32_t)groups), dim3(kBlock), 0, s, out,
-                           I, (int)(nn * nc), g, rp);
-    else if (dim == 3)
-        hipLaunchKernelGGL((regrid_fwd_kernel<R, 3>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp);
-    else
-        hipLaunchKernelGGL((regrid_fwd_kernel<R, 2>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp);
+    // (non-temporal stores once input + output exceed the Infinity Cache: 80^3 -> 160^3 at 8 x 3 planes 260 -> 190 us)
+    const bool big = ((double)nn * nc * ((double)g.nvox + (double)rp.nx * rp.ny * rp.nz)) * sizeof(R) > 256.0 * 1024 * 1024;
+#define LAUNCH(D)                                                                                                        \
+    do {                                                                                                                 \
+        if (big) hipLaunchKernelGGL((regrid_fwd_kernel<R, D, 1>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp); \
+        else hipLaunchKernelGGL((regrid_fwd_kernel<R, D, 0>), dim3(g.nblocks), dim3(kBlock), 0, s, out, I, (int)(nn * nc), g, rp);     \
+    } while (0)
+    if (dim == 3) LAUNCH(3); else LAUNCH(2);
+#undef LAUNCH
     return finish_launch(s, "regrid_forward");
 }
 

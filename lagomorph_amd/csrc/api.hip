@@ -12,6 +12,7 @@ std::atomic<int> g_interp_vec{1};
 std::atomic<long long> g_path_launches[LP_COUNT];
 std::atomic<int> g_launch_alt{1};
 std::atomic<unsigned> g_launch_seq{0};
+std::atomic<long long> g_reversed_launches{0};
 static thread_local char g_err[512] = "";
 
 int fail_invalid(const char *fmt, ...) {
@@ -107,6 +108,7 @@ int lago_get_debug(void) { return lago::g_debug; }
 int lago_abi_version(void) { return LAGO_ABI_VERSION; }
 const char *lago_version(void) { return "lagomorph_hip 0.1 (gfx950, HIP)"; }
 const char *lago_last_error(void) { return lago::g_err; }
+long long lago_reversed_launches(void) { return lago::g_reversed_launches.load(); }
 long long lago_path_launches(int path) {
     return path >= 0 && path < lago::LP_COUNT ? lago::g_path_launches[path].load() : -1;
 }

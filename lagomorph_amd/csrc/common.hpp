@@ -53,7 +53,12 @@ struct KnobArray {  // array-valued setting: read and written as a whole under a
 // only: the block -> data mapping is a bijection either way.
 extern std::atomic<int> g_launch_alt;        // 1 (default): alternate; 0: always ascending
 extern std::atomic<unsigned> g_launch_seq;
-inline int next_direction() { return g_launch_alt ? (int)(g_launch_seq.fetch_add(1) & 1u) : 0; }
+extern std::atomic<long long> g_reversed_launches;   // telemetry: lago_reversed_launches()
+inline int next_direction() {
+    const int rev = g_launch_alt ? (int)(g_launch_seq.fetch_add(1) & 1u) : 0;
+    if (rev) g_reversed_launches.fetch_add(1, std::memory_order_relaxed);
+    return rev;
+}
 extern std::atomic<int> g_splat_mode;
 extern std::atomic<int> g_interp_vec;  // 1: use the vectorised 3D kernels when shapes allow (default)
 // Which implementation a call was dispatched to (lago_path_launches; ids = LAGO_PATH_* of the header).  Telemetry only:

@@ -1264,6 +1264,7 @@ int regrid_splat_lds(R *d_I, const R *go, int64_t nplanes, const Geom &g, const 
     int nt;
     if (g.nz < 2 || gs.nz < 2) return 1;
     if (!make_tiles(tg, g, gs, nplanes, S, smem, nt)) return 1;
+    note_path(LP_SPLAT_TILED);
     PosArgs pa{};
     for (int d = 0; d < 3; ++d) {
         pa.O[d] = O[d];

@@ -256,6 +256,15 @@ PATHS = ("gather_window", "stencil_tile", "vector_gather", "splat_shear", "splat
          "fluid_lds", "fluid_2d", "fluid_xpass", "fluid_rocfft", "splat_2d", "splat_affine_box", "fluid_generic")  # LAGO_PATH_* of include/lagomorph_hip.h, in order
 
 
+_lib.lago_reversed_launches.restype = ctypes.c_longlong
+_lib.lago_reversed_launches.argtypes = []
+
+
+def reversed_launches():
+    """Launches so far that walked their workgroups in descending order (include/lagomorph_hip.h)."""
+    return int(_lib.lago_reversed_launches())
+
+
 def path_launches(name=None):
     """Launches so far per implementation path (a dict), or of one path by name."""
     if name is not None:

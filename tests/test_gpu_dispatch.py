@@ -124,13 +124,15 @@ def test_float64_and_2d_take_the_general_kernels(lm):
 
 def test_scatter_direction_is_history_free(lm):
     """VERDICT r4 item 6.  Launches alternate their block order (common.hpp: next_direction) from a process-wide
-    counter; a scatter-add rounds its float atomics in arrival order, so until round 4 the last bits of d_I depended on
-    the PARITY of the number of library calls made before it -- any calls, rejected ones included.  Scatter launches now
-    always walk ascending and leave the counter alone.  Checked two ways: (1) with integer-valued data every sum is
-    exact, so the bits cannot depend on anything -- a control that the harness compares the right things; (2) with real
-    data, the same call after 0, 1, 2 and 3 unrelated launches (and a rejected call) gives ONE set of bits in at least
-    all-but-one of the trials (a reversed block order reverses the arrival order at every cell that three or more tiles
-    add to; atomic arrival order itself is not guaranteed by the hardware, hence "all but one" rather than "all")."""
+    counter; a scatter-add rounds its float atomics in arrival order, so until round 4 the block order of a splat -- and
+    with it the last bits of d_I, d_A, d_T -- followed the PARITY of the number of library calls made before it, rejected
+    ones included.  Scatter launches now always walk ascending and leave the counter alone.  Bit equality of two runs
+    cannot show that: float atomics arrive in a different order on every run of the SAME launch (observed: 0 of 5
+    repeats of one call reproduce its bits), so the mechanism itself is asserted through `lago_reversed_launches`:
+    (1) no scatter-add entry point ever launches in descending order, whatever came before it (valid and rejected
+    calls); (2) it does not advance the alternation either: order-independent kernels keep alternating strictly across
+    any number of interleaved scatter calls; (3) with integer-valued data, where every sum is exact, the bits agree --
+    a control that the calls compare like with like."""
     shim = lm.lagomorph_ext
     sp = (40, 36, 128)
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -138,29 +140,52 @@ def test_scatter_direction_is_history_free(lm):
     sm = torch.nn.functional.avg_pool3d(u, 5, stride=1, padding=2)   # smooth enough for the LDS windows to hold it
     go = torch.randn((2, 1) + sp, device="cuda", generator=g)
     I = torch.randn((2, 1) + sp, device="cuda", generator=g)
+    go3 = torch.randn((2, 3) + sp, device="cuda", generator=g)
     w = torch.randn((1, 3, 8, 8, 8), device="cuda", generator=g)
+    A = (torch.eye(3, device="cuda").repeat(2, 1, 1) * 1.05).contiguous()
+    T = torch.full((2, 3), 0.3, device="cuda")
+    u2 = 0.5 * torch.randn((2, 2, 128, 128), device="cuda", generator=g)
+    I2 = torch.randn((2, 1, 128, 128), device="cuda", generator=g)
 
     def unrelated(k):
         for _ in range(k):
-            shim.jacobian_times_vectorfield_forward(w, w, True, False)   # one make_geom each
+            shim.jacobian_times_vectorfield_forward(w, w, True, False)   # one alternating launch each
         if k:
             with pytest.raises(RuntimeError):
                 shim.interp_forward(w, torch.zeros((1, 3, 8, 8, 9), device="cuda"), 1.0)   # rejected after make_geom
 
-    # (1) exact arithmetic
+    scatters = [
+        lambda: shim.interp_backward(go, I, sm, 1.0, True, True),                 # sheared-window splat
+        lambda: shim.interp_backward(go3, go3, sm, -0.3, True, True),             # its multi-channel form
+        lambda: shim.interp_backward(go, I, 30.0 * u, 1.0, True, False),          # rough field: strays, global atomics
+        lambda: shim.interp_backward(I2, I2, u2, 1.0, True, True),                # 2D LDS splat
+        lambda: shim.affine_interp_backward(go, I, A, T, True, True, True),       # target boxes + the d_A / d_T reduction
+        lambda: shim.regrid_backward(go3, [20, 18, 64], list(sp), [9.5, 8.5, 31.5], [19 / 39, 17 / 35, 63 / 127]),
+        lambda: shim.interp_hessian_diagonal_image(I2, u2, 1.0),
+    ]
+    shim.REGRID_BACKWARD_SEPARABLE = 0    # (the separable form has no atomics; the splat form is the one at stake)
+    try:
+        for k in (0, 1, 2, 3):
+            unrelated(k)
+            before = shim.reversed_launches()
+            for fn in scatters:
+                fn()
+            assert shim.reversed_launches() == before, f"a scatter-add launched in descending order after {k} unrelated calls"
+        # (2) strict alternation of an order-independent kernel across interleaved scatter calls
+        seen = []
+        for i in range(6):
+            before = shim.reversed_launches()
+            shim.jacobian_times_vectorfield_forward(w, w, True, False)
+            seen.append(shim.reversed_launches() - before)
+            for fn in scatters[: i % 3]:
+                fn()
+        assert seen in ([0, 1, 0, 1, 0, 1], [1, 0, 1, 0, 1, 0]), seen
+    finally:
+        shim.REGRID_BACKWARD_SEPARABLE = 1
+    # (3) exact arithmetic: bits cannot depend on anything
     ui = torch.round(sm)
     goi = torch.round(4 * go)
     ref_bits = shim.interp_backward(goi, I, ui, 1.0, True, False)[0]
     for k in (1, 2, 3):
         unrelated(k)
         assert torch.equal(shim.interp_backward(goi, I, ui, 1.0, True, False)[0], ref_bits)
-    # (2) real data, several call histories
-    for fn in (lambda: shim.interp_backward(go, I, sm, 1.0, True, True)[0],
-               lambda: shim.affine_interp_backward(go, I, torch.eye(3, device="cuda").repeat(2, 1, 1) * 1.05,
-                                                   torch.full((2, 3), 0.3, device="cuda"), True, True, True)[0]):
-        outs = []
-        for k in (0, 1, 2, 3, 1, 0):
-            unrelated(k)
-            outs.append(fn())
-        same = sum(torch.equal(o, outs[0]) for o in outs[1:])
-        assert same >= len(outs) - 2, f"{same} of {len(outs) - 1} histories reproduced the first call's bits"

@@ -342,10 +342,10 @@ def test_affine_interp(ext, dtype, sp, nn, nc, bc):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp,nn,nc,bc,kind", [((65, 70, 72), 4, 1, False, "random"), ((64, 64, 130), 2, 2, True, "random"),
                                               ((33, 129, 127), 2, 1, False, "rotation"), ((128, 128, 64), 1, 1, False, "far")])
-def test_affine_forward_several_voxels_per_lane(ext, dtype, sp, nn, nc, bc, kind):
-    """affine_fwd3_multi_kernel (round 5: launches of 2^20 voxels and more give a lane one voxel of each of four
-    consecutive 256-voxel slabs): bit for bit against the oracle -- ragged last workgroups (volumes that are no
-    multiple of 1024 voxels), broadcast image, two channels, a rotation, and a map that sends most samples out of range."""
+def test_affine_forward_megavoxel_volumes(ext, dtype, sp, nn, nc, bc, kind):
+    """affine_interp_forward on volumes of a million voxels and more (the other affine cases are tiny), bit for bit
+    against the oracle: ragged last workgroups, broadcast image, two channels, a rotation, and a map that sends most
+    samples out of range (the clamp)."""
     rng = np.random.default_rng(hash((sp, nn, nc)) % 2**31)
     I = rnd(rng, ((1 if bc else nn), nc) + sp, dtype)
     if kind == "rotation":
@@ -358,23 +358,21 @@ def test_affine_forward_several_voxels_per_lane(ext, dtype, sp, nn, nc, bc, kind
     else:
         A = (np.eye(3)[None] + 0.1 * rng.standard_normal((nn, 3, 3))).astype(I.dtype)
         T = (1.5 * rng.standard_normal((nn, 3))).astype(I.dtype)
-    assert int(np.prod(sp)) * nn >= 1 << 20   # the multi-voxel kernel's threshold (affine.hip: affine_forward_impl)
-    assert_bits(ext.affine_interp_forward(dev(I), dev(A), dev(T)), orc.affine_interp_forward(I, A, T), "affine forward (multi)")
+    assert_bits(ext.affine_interp_forward(dev(I), dev(A), dev(T)), orc.affine_interp_forward(I, A, T), "affine forward (large)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("sp,out,nn,nc", [((20, 24, 28), (40, 48, 56), 3, 3), ((40, 48, 56), (20, 24, 28), 1, 5),
                                           ((8, 8, 8), (6, 5, 1030), 1, 2), ((8, 8, 8), (6, 5, 1024), 2, 1)])
-def test_regrid_forward_planes_in_the_grid(ext, dtype, sp, out, nn, nc):
-    """regrid_fwd3_planes_kernel (round 5: plane groups in blockIdx.y, the reference's running sum hz += Sz evaluated
-    once per workgroup into an LDS table): bit for bit against the oracle -- plane counts that are no multiple of the
-    group size, rows at and beyond the table's 1024 entries (the latter stay on the per-lane kernel)."""
+def test_regrid_forward_many_planes_and_long_rows(ext, dtype, sp, out, nn, nc):
+    """regrid_forward with several (n, c) planes and output rows of a thousand voxels (the reference's running sum
+    hz += Sz over the whole row, cuda/affine.cu:669-675), bit for bit against the oracle."""
     rng = np.random.default_rng(hash((sp, out)) % 2**31)
     I = rnd(rng, (nn, nc) + sp, dtype)
     origin = [(s - 1) * 0.5 + 0.3 for s in sp]
     spacing = [(a - 1) / (b - 1) if b > 1 else 1.0 for a, b in zip(sp, out)]
     assert_bits(ext.regrid_forward(dev(I), list(out), origin, spacing), orc.regrid_forward(I, list(out), origin, spacing),
-                "regrid forward (planes)")
+                "regrid forward (many planes)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -991,7 +989,8 @@ def test_regrid_backward_every_form(ext, dtype, sp, out, scale):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("origin,spacing,sep", [
-    ([2.0e9, 3.0, 4.0], [1.0, 0.5, 0.5], False),     # |origin| >= 1e9: beyond the separable passes' checks
+    ([1.0e9, 3.0, 4.0], [1.0, 0.5, 0.5], False),     # |origin| >= 1e9: beyond the separable passes' checks (below the 2^30
+                                                     # at which positions saturate and the weights stop being meaningful)
     ([3.0, 3.0, 4.0], [2.0e6, 0.5, 0.5], False),     # spacing >= 1e6
     ([3.0, 3.0, 4.0], [1e-9, 0.5, 0.5], None),       # a spacing so small that float32 rounding moves a sample by many cells (float64: still separable)
     ([3.0, 3.0, 4.0], [1e-3, 0.5, 0.5], True),       # small but well inside: wider candidate window, still separable
