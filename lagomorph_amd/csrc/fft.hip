@@ -37,9 +37,7 @@ bool fluid_xpass_supported(int64_t nx);
 // fft3.hip
 bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz);
 int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
-                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s, const float *phi = nullptr,
-                        double ds = 0.0, double dt = 0.0);
-bool zy_compose_supported(int64_t ny, int64_t nz);
+                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s);
 int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int64_t nx, int64_t ny, int64_t nzc,
                        double scale, hipStream_t s);
 bool fluid2d_supported(int64_t h, int64_t w);
@@ -540,28 +538,6 @@ int lago_fft_plan_state(int *plans, int *verified) {
     if (plans) *plans = (int)lago::g_plans.size();
     if (verified) *verified = nv;
     return 0;
-}
-/* out = ds * v + dt * interp(phi, v, ds), v = irfft(L^(+-2) rfft(m)): the fluid metric with deform.compose as the epilogue
- * of its last pass (float32, 3D, the shapes of the three-pass form with 64^2 / 96^2 / 128^2 planes; lut_generation != 0). */
-int lago_fluid_metric_compose_f32(float *out, const float *m, const float *phi, float *work, int64_t lut_generation,
-                                  int inverse, const float *cosX, const float *sinX, const float *cosY,
-                                  const float *sinY, const float *cosZ, const float *sinZ, double alpha, double beta,
-                                  double gamma, int64_t nn, int64_t nx, int64_t ny, int64_t nz, double ds, double dt,
-                                  void *stream) {
-    using namespace lago;
-    if (nn < 0 || nx < 1 || ny < 1 || nz < 1 || nn * 3 >= (1ll << 31) || nx * ny * nz >= (1ll << 29))
-        return fail_invalid("fluid_metric_compose: bad extent");
-    if (nn == 0) return LAGO_OK;
-    if (!out || !m || !phi || !work) return fail_invalid("fluid_metric_compose: null pointer");
-    if (lut_generation == 0 || !fluid_native_supported(nx, ny, nz) || !zy_compose_supported(ny, nz) || nz < 2 ||
-        (((uintptr_t)out | (uintptr_t)m | (uintptr_t)work) & 15) != 0)
-        return fail_invalid("fluid_metric_compose: shape not supported by the fused form");
-    CoefRef tab;
-    int rc = get_coef(tab, lut_generation, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nx, ny, nz, 1,
-                      (hipStream_t)stream);
-    if (rc != LAGO_OK) return rc;
-    return fluid_metric_native(out, m, work, tab->d, inverse, nn, nx, ny, nz, 1.0 / ((double)nx * (double)ny * (double)nz),
-                               (hipStream_t)stream, phi, ds, dt);
 }
 #define LAGO_DEFINE(REAL, SUF)                                                                                     \
     int lago_fluid_metric##SUF(REAL *out, const REAL *m, REAL *work, int64_t lut_generation, int inverse,         \

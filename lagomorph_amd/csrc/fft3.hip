@@ -64,84 +64,6 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_kernel(fl::
     }
 }
 
-// ---- zy inverse with `compose` as its epilogue (round 5, VERDICT r4 item 2: measured as a FUSION) ---------------------
-// out = ds * v + dt * interp(phi, v, ds) with v = the inverse transform's output, i.e. deform.compose_disp_vel of the
-// Euler step (lddmm.py:39-44, deform.py:53-62) without v's round trip through HBM (12 B/voxel written by
-// zy_inverse_kernel, 12 B/voxel read by the compose kernel) and without the second launch.  A workgroup owns one x
-// plane of one batch item and transforms its THREE component planes one after the other; each thread keeps the real
-// values it would have stored (KV float4 per component: rows of four consecutive z) in registers, and once all three
-// components of a voxel are known it gathers phi there (Lerp3: pair gathers through the vector L1 -- a plane-shaped
-// tile has no LDS window worth its halo) and stores the composed displacement.  Expressions as in
-// fused.hip: compose3_unroll_kernel, so the bits are those of the two-kernel sequence.
-// 1024 threads: 3 x KV = 12 float4 of velocity per thread leave room for the transform's own registers; at 512 threads
-// (24 float4 = 96 registers) the kernel would spill or lose its second workgroup per CU either way.
-template <int NY, int NZ, bool UNIT>
-__global__ __launch_bounds__(1024) void zy_inverse_compose_kernel(fl::ZYArgs a, float *__restrict__ out,
-                                                                 const float *__restrict__ phi, double ds, double dt,
-                                                                 int nx) {
-    using K = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T, 1024>;
-    extern __shared__ __align__(16) unsigned char lago_smem[];
-    float2 *P = reinterpret_cast<float2 *>(lago_smem), *tw = P + K::NY * K::PZ;
-    const uint32_t w = a.rev ? a.total - 1u - blockIdx.x : blockIdx.x;   // (batch item, x plane)
-    const uint32_t n = w / (uint32_t)nx, x = w - n * (uint32_t)nx;
-    const int tid = threadIdx.x;
-    float4 vel[3][K::KV];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const size_t p = ((size_t)n * 3 + c) * nx + x;
-        const float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
-#pragma unroll
-        for (int ph = 0; ph < K::NPH_INV - 1; ++ph) {   // every phase but the store
-            K::inv_phase(ph, tid, nullptr, mainp, nyqp, P, tw);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int k = 0; k < K::KV; ++k) {
-            if (tid + k * 1024 >= K::F4) continue;
-            const int e = (tid + k * 1024) * 2, y = e / K::NZH, j = e % K::NZH;
-            const float2 lo = P[y * K::PZ + j], hi = P[y * K::PZ + j + 1];
-            vel[c][k] = make_float4(lo.x, lo.y, hi.x, hi.y);
-        }
-        __syncthreads();
-    }
-    const size_t nv = (size_t)nx * NY * NZ;
-    const float *pn = phi + (size_t)n * 3 * nv;
-    float *on = out + (size_t)n * 3 * nv;
-    const float dsr = (float)ds, dtr = (float)dt;
-#pragma unroll
-    for (int k = 0; k < K::KV; ++k) {
-        if (tid + k * 1024 >= K::F4) continue;
-        const int e = (tid + k * 1024) * 2, y = e / K::NZH, z0 = (e % K::NZH) * 2;
-        const float ux[4] = {vel[0][k].x, vel[0][k].y, vel[0][k].z, vel[0][k].w};
-        const float uy[4] = {vel[1][k].x, vel[1][k].y, vel[1][k].z, vel[1][k].w};
-        const float uz[4] = {vel[2][k].x, vel[2][k].y, vel[2][k].z, vel[2][k].w};
-        const size_t sv = ((size_t)x * NY + y) * NZ + z0;
-        float o[3][4];
-        // (two voxels at a time: four Lerp3 states beside the velocity registers spill)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            Lerp3<float, false> L[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                L[q].setup(sample_pos_t<float, UNIT>((int)x, ds, ux[2 * h + q]), sample_pos_t<float, UNIT>(y, ds, uy[2 * h + q]),
-                           sample_pos_t<float, UNIT>(z0 + 2 * h + q, ds, uz[2 * h + q]), nx, NY, NZ);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float *uc = c == 0 ? ux : (c == 1 ? uy : uz);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float aa = dsr * uc[2 * h + q];
-                    const float bb = dtr * L[q].value(pn + (size_t)c * nv);
-                    o[c][2 * h + q] = aa + bb;
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            stg4<1>(reinterpret_cast<float4 *>(on + (size_t)c * nv + sv), make_float4(o[c][0], o[c][1], o[c][2], o[c][3]));
-    }
-}
-
 // Planes whose LDS image leaves room for ONE workgroup per CU only (160 x 160: 104 KB) have nobody to hide their
 // global loads behind: a grid of one persistent workgroup per CU walks the planes and requests plane p + grid into
 // registers (7 float4 per thread) while it transforms plane p.  Two details of that loop, both measured
@@ -587,33 +509,8 @@ std::atomic<int> g_native_stage_mask{7};
 
 // out = irfftn(operator(rfftn(m))) * scale.  tab: split-layout coefficient table (fluid_coef_launch
 // with split = 1).  work: nn*3*nx*ny*(nz/2+1) complex.
-// shapes the fused inverse + compose kernel is instantiated for (float4 rows: nz % 4 == 0; planes up to 80 KB)
-bool zy_compose_supported(int64_t ny, int64_t nz) { return (ny == 128 && nz == 128) || (ny == 64 && nz == 64) || (ny == 96 && nz == 96); }
-template <int NY, int NZ>
-static hipError_t zy_compose_launch(const fl::ZYArgs &a, float *out, const float *phi, double ds, double dt, int nx, uint32_t planes_xn,
-                                    hipStream_t s) {
-    using K = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T, 1024>;
-    fl::ZYArgs b = a;
-    b.total = planes_xn;
-    const bool unit = ds == 1.0 || ds == -1.0;
-    if (unit) {
-        auto k = zy_inverse_compose_kernel<NY, NZ, true>;
-        hipError_t e = allow_smem(k, K::SMEM);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(planes_xn), dim3(1024), K::SMEM, s, b, out, phi, ds, dt, nx);
-    } else {
-        auto k = zy_inverse_compose_kernel<NY, NZ, false>;
-        hipError_t e = allow_smem(k, K::SMEM);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(planes_xn), dim3(1024), K::SMEM, s, b, out, phi, ds, dt, nx);
-    }
-    return hipSuccess;
-}
-
-// phi != nullptr: the third pass is zy_inverse_compose_kernel, out = ds * v + dt * interp(phi, v, ds) (zy_compose_supported shapes)
 int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
-                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s, const float *phi, double ds,
-                        double dt) {
+                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s) {
     const int64_t nzh = nz / 2, planes = nn * 3 * nx;
     const int64_t items = ny * (nzh / 16) + ny / 16;
     if (planes >= (1ll << 31) || nn * items >= (1ll << 31)) return fail_invalid("fluid_metric: batch too large");
@@ -653,15 +550,6 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     if (stages & 2) e = xpass2_dispatch(nx, xa, inverse != 0, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (x pass)");
     za.rev = next_direction();
-    if (phi) {
-        if (nn * nx >= (1ll << 31)) return fail_invalid("fluid_metric: batch too large");
-        if (ny == 128 && nz == 128) e = zy_compose_launch<128, 128>(za, out, phi, ds, dt, (int)nx, (uint32_t)(nn * nx), s);
-        else if (ny == 64 && nz == 64) e = zy_compose_launch<64, 64>(za, out, phi, ds, dt, (int)nx, (uint32_t)(nn * nx), s);
-        else if (ny == 96 && nz == 96) e = zy_compose_launch<96, 96>(za, out, phi, ds, dt, (int)nx, (uint32_t)(nn * nx), s);
-        else return fail_invalid("fluid_metric_compose: plane shape not instantiated");
-        if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy inverse + compose)");
-        return finish_launch(s, "fluid_metric_compose");
-    }
     if (stages & 4) e = zy_dispatch(ny, nz, za, true, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy inverse)");
     return finish_launch(s, "fluid_metric");

@@ -511,40 +511,6 @@ def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma, lut_generati
     return out
 
 
-def fluid_metric_compose(mv, phi, inverse, cosluts, sinluts, alpha, beta, gamma, lut_generation, ds, dt):
-    """compose(v, phi, ds, dt) with v = fluid_metric(mv, ...), as ONE sequence of three FFT passes whose last kernel
-    gathers phi and writes ds * v + dt * interp(phi, v, ds) (csrc/fft3.hip: zy_inverse_compose_kernel) -- v never goes
-    to HBM.  float32 3D fields with 64^2 / 96^2 / 128^2 planes; raises for other inputs.  Same bits as the two calls.
-    Round-5 experiment (profiles/r05_compose_epilogue.md): slower than the two kernels, not used by lddmm.py."""
-    if not hasattr(_lib, "lago_fluid_metric_compose_f32"):
-        raise RuntimeError("this library build has no lago_fluid_metric_compose_f32")
-    _check_input(mv, "mv")
-    _check_input(phi, "phi")
-    _same(mv, phi)
-    dim, nx, ny, nz = _spatial(mv)
-    if dim != 3 or mv.dtype != torch.float32 or mv.shape != phi.shape or mv.size(1) != 3:
-        raise RuntimeError("fluid_metric_compose: float32 3D vector fields of one shape")
-    csh = list(mv.shape[2:])
-    csh[-1] = csh[-1] // 2 + 1
-    luts = []
-    for d in range(3):
-        for t in (cosluts[d], sinluts[d]):
-            if t.dtype != mv.dtype or not t.is_cuda or t.device != mv.device or t.numel() != csh[d]:
-                raise RuntimeError("fluid_metric_compose: bad LUT")
-            luts.append(t.contiguous())
-    out = torch.empty_like(mv)
-    work = torch.empty((mv.size(0), 3, *csh, 2), dtype=mv.dtype, device=mv.device)
-    f = _lib.lago_fluid_metric_compose_f32
-    f.restype = _int
-    f.argtypes = [_vp, _vp, _vp, _vp, _i64, _int] + [_vp] * 6 + [ctypes.c_double] * 3 + [_i64] * 4 + [ctypes.c_double] * 2 + [_vp]
-    rc = f(_ptr(out), _ptr(mv), _ptr(phi), _ptr(work), int(lut_generation), int(bool(inverse)), *[_ptr(t) for t in luts],
-           float(alpha), float(beta), float(gamma), mv.size(0), nx, ny, nz, float(ds), float(dt),
-           torch.cuda.current_stream(mv.device).cuda_stream)
-    if rc != 0:
-        raise RuntimeError(_lib.lago_last_error().decode("utf-8", "replace"))
-    return out
-
-
 def affine_interp_forward(I, A, T):
     """extension.cpp:109-118 -> cuda/affine.cu:114-169.  The reference falls back to
     cpu/affine.cpp for CPU tensors; this build is HIP-only and raises instead."""
