@@ -19,10 +19,14 @@ Also on the same JSON line:
                    -> interp -> loss -> backward through every operator -> momentum update, then ONE RCCL
                    all-reduce of the atlas gradient and the image update) on 160^3 subjects, global
                    minibatch 32 split N ways; voxels/s, ms per step, the all-reduce time, rank count.
-  roofline      -- the dominant hand-written kernel of the timed region: algorithmic bytes / mean launch
-                   time measured live with HIP events on the launch stream; PMC traffic from profiles/.
+  roofline      -- the dominant hand-written kernel of the workload: algorithmic bytes / mean launch time measured
+                   live with HIP events on the launch stream, in a SINGLE-STREAM pass of the same shoots that follows
+                   the timed region in this process (the timed region runs the product's default, two sub-batches on two
+                   HIP streams, where a launch's duration is not the kernel's own time); PMC traffic from profiles/.
   cpu_baseline  -- the CPU oracle (C port, OpenMP) on bounded samples of the same workloads, timed on
-                   this host (rank 0, N = 1 only): the expmap sample plus per-operator figures.
+                   this host (rank 0, N = 1 only): the expmap sample plus per-operator figures; and
+                   reference_cpu_path: the reference's OWN CPU code (extension/cpu/affine.cpp, oracle/_ref) timed
+                   beside the HIP kernel that replaces it, BASELINE configs[0] included.
   interp_splat, fluid, other_ops -- BASELINE configs[1] / configs[2] micro-measurements (N = 1 only).
 """
 import argparse
@@ -143,7 +147,7 @@ def micro_interp_splat(ext, dev, size, batch=8):
         r["pair_Gvoxel_per_s"] = V / pair / 1e6
         res[label] = r
     # HBM bytes per launch of the two kernels from the PMC passes over tools/run_micro.py (same workload, same batch)
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_traffic_micro.json", "r03_traffic_micro.json", "r02_traffic_micro.json"))
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_traffic_micro.json", "r04_traffic_micro.json", "r03_traffic_micro.json", "r02_traffic_micro.json"))
                   if os.path.exists(q)), "")
     if tpath and size == 128 and batch == 8:
         t = json.load(open(tpath))
@@ -579,6 +583,10 @@ def parse_args():
                     help="skip the two untimed comparison shoots (all steps through the general kernels; stream split): "
                          "the profile runs use it, so that a kernel's average in the rocprofv3 summary is over the "
                          "launches of the timed workload only")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="lddmm.EXPMAP_STREAMS for the timed region (0 = the product's default, 2).  The profile runs pass 1: "
+                         "every launch of the trace / PMC passes is then a whole-batch launch on one stream, the launch the "
+                         "roofline object describes")
     ap.add_argument("--atlas-size", type=int, default=160)
     ap.add_argument("--atlas-batch", type=int, default=32, help="subjects per atlas update over ALL GPUs")
     ap.add_argument("--atlas-steps", type=int, default=4)
@@ -657,6 +665,8 @@ def main():
         names = ["interp_forward", "jacobian_times_vectorfield_forward", "fluid_operator", "fluid_metric", "compose",
                  "Ad_star"]
         from lagomorph_amd import lddmm as _lddmm
+        if args.streams > 0:
+            _lddmm.EXPMAP_STREAMS = args.streams
         default_streams = _lddmm.EXPMAP_STREAMS
         # TIMED REGION: the product's default path -- a forward-only shoot of 4+ batch items is cut into two sub-batches
         # on HIP streams of their own (lddmm.EXPMAP_STREAMS = 2, bit-identical to one stream).  HIP events of the
@@ -781,7 +791,7 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
             # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
             traffic, tsrc = None, None
-            for tname in ("r04_traffic_expmap.json", "r03_traffic_expmap.json", "r02_traffic_expmap.json", "r01_traffic.json"):
+            for tname in ("r05_traffic_expmap.json", "r04_traffic_expmap.json", "r03_traffic_expmap.json", "r02_traffic_expmap.json", "r01_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and B == 32 and S == 128:
                     for name, rec in json.load(open(tpath)).items():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end check on the GPU box: full GPU suite (with the observed-error reports), smoke(), bench at three batch sizes.
 cd "$(dirname "$0")/.."
-tag=${LAGO_ROUND_TAG:-r04}
+tag=${LAGO_ROUND_TAG:-r05}
 mkdir -p gpurun_out
 LAGO_TOL_REPORT=gpurun_out/${tag}_tolerances.json LAGO_TOL_REPORT_GOLDEN=gpurun_out/${tag}_tolerances_golden.json python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest.log 2>&1; echo "pytest exit $?"
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${tag}_smoke.log 2>&1; echo "smoke exit $?"
