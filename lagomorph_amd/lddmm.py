@@ -257,12 +257,16 @@ def _fused_step_ok(I, m, img, metric, integration_steps):
 
 
 def _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_weight, learning_rate_pose,
-                      momentum_preconditioning):
+                      momentum_preconditioning, whole=None, after_image_backward=None):
     """`lddmm_step` with the momentum side written out by hand: the shoot and its reverse sweep (`_shoot`,
     `_shoot_reverse`), the regulariser <sharp(m), m> and its gradient, and the descent step, with every elementwise
     sum in one pass (`lagomorph_ext.lincomb`).  Autograd is kept for the image side -- interp of the atlas, the
     regrid of multiscale momenta, the loss -- so that I.grad and its hooks (the atlas builder's all-reduce) behave
-    as in the plain form.  Same formulas; sums in a different order (rounding only)."""
+    as in the plain form.  Same formulas; sums in a different order (rounding only).
+    `whole` = (numel, items) of the WHOLE minibatch when (m, img) is a sub-batch of it (`_lddmm_step_split`): the
+    normalisers of the loss are the minibatch's (lddmm.py:308-313), so the parts' losses and gradients simply add.
+    `after_image_backward`: called once I.grad holds this call's splat (the split records a stream event there)."""
+    numel, items = (img.numel(), img.shape[0]) if whole is None else whole
     regrid_momenta = tuple(m.shape[2:]) != tuple(I.shape[2:])
     dt = 1.0 / integration_steps
     with torch.no_grad():
@@ -271,10 +275,12 @@ def _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_we
         h, steps, _ = _shoot(metric, m, None, dt, integration_steps, v, True)
     h.requires_grad_(True)
     hh = regrid(h, shape=I.shape[2:]) if regrid_momenta else h
-    img_term = torch.nn.functional.mse_loss(deform.interp(I, hh), img, reduction="sum") / img.numel()
+    img_term = torch.nn.functional.mse_loss(deform.interp(I, hh), img, reduction="sum") / numel
     img_term.backward()
+    if after_image_backward is not None:
+        after_image_backward()
     with torch.no_grad():
-        c = reg_weight / img.numel()
+        c = reg_weight / numel
         if regrid_momenta:  # account for downscaling in averaging (lddmm.py:311-312)
             c = c * (I.numel() / v[0, 0, ...].numel())
         reg_term = c * torch.dot(v.reshape(-1), m.reshape(-1))
@@ -286,7 +292,7 @@ def _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_we
         d_v = lagomorph_ext.lincomb([(-dt, G), (c, m)], out=G if own else None)
         d_mK = metric.sharp(d_v)
         del d_v, G
-        norm_factor = img.shape[0] / dataset_size
+        norm_factor = items / dataset_size
         terms = [(1.0, d_mK), (c, v)] + ([(1.0, d_m0)] if d_m0 is not None else [])
         if momentum_preconditioning:
             p = metric.flat(lagomorph_ext.lincomb(terms, out=d_mK))
@@ -295,6 +301,60 @@ def _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_we
             lr = learning_rate_pose
             lagomorph_ext.lincomb([(1.0, m)] + [(-lr * a, x) for a, x in terms], out=m)
         return m, (loss * norm_factor), (reg_term * norm_factor)
+
+
+# The matching step of a minibatch of at least 2 * LDDMM_STEP_STREAMS subjects is cut into LDDMM_STEP_STREAMS contiguous
+# sub-batches that run -- forward, backward, momentum update -- on HIP streams of their own, like the forward shoot
+# (EXPMAP_STREAMS above): subjects are independent up to the two sums over the minibatch, the loss and the atlas
+# gradient.  Each part splats into an atlas gradient of its own (a private leaf view of I), records an event when that
+# splat has run, and the caller's stream adds the parts and hands the sum to I through autograd -- I.grad accumulates and
+# its hooks (the atlas builder's asynchronous all-reduce) fire as in the one-stream form, still while the parts'
+# reverse sweeps run.  Same formulas and normalisers; the two sums are taken in a different order (rounding only).
+# 1 switches it off.
+LDDMM_STEP_STREAMS = 2
+
+
+def _lddmm_step_split(I, m, img, metric, dataset_size, integration_steps, reg_weight, learning_rate_pose,
+                      momentum_preconditioning):
+    """`_lddmm_step_fused` over sub-batches on side streams; None when the split does not apply."""
+    parts = LDDMM_STEP_STREAMS
+    B = m.size(0)
+    if parts < 2 or B < 2 * parts or img.size(0) != B:
+        return None
+    main = torch.cuda.current_stream(m.device)
+    streams = _streams_for(m.device, parts)
+    bounds = [B * i // parts for i in range(parts + 1)]
+    whole = (img.numel(), B)
+    metric.initialize_luts(shape=m.shape, dtype=m.dtype, device=m.device)   # (made once, on the main stream)
+    want_I = I.requires_grad
+    leaves, events, res = [], [], []
+    for i, s in enumerate(streams):
+        s.wait_stream(main)   # the inputs are the main stream's
+        sl = slice(bounds[i], bounds[i + 1])
+        with torch.cuda.stream(s):
+            Ik = I.detach().requires_grad_(want_I)   # a leaf of its own: the parts' splats do not race on I.grad
+            ev = torch.cuda.Event()
+            res.append(_lddmm_step_fused(Ik, m[sl], img[sl], metric, dataset_size, integration_steps, reg_weight,
+                                         learning_rate_pose, momentum_preconditioning, whole=whole,
+                                         after_image_backward=ev.record))
+            leaves.append(Ik)
+            events.append(ev)
+    if want_I:
+        # as soon as every part's splat has run (the parts continue with their reverse sweeps): the minibatch's atlas
+        # gradient, accumulated into I.grad through autograd so that post-accumulate hooks fire
+        for ev in events:
+            main.wait_event(ev)
+        g = leaves[0].grad
+        for Ik in leaves[1:]:
+            g = g + Ik.grad
+        torch.autograd.backward(I, g)
+    for s in streams:
+        main.wait_stream(s)
+    loss, reg = res[0][1], res[0][2]
+    for r in res[1:]:
+        loss = loss + r[1]
+        reg = reg + r[2]
+    return m.detach(), loss, reg
 
 
 def lddmm_step(I, m, img, metric, dataset_size, integration_steps=5, reg_weight=1e2, learning_rate_pose=2e2,
@@ -306,6 +366,10 @@ def lddmm_step(I, m, img, metric, dataset_size, integration_steps=5, reg_weight=
     Returns (m, loss, reg_term) with loss/reg already scaled by B / dataset_size, all on device
     (no host synchronisation)."""
     if _fused_step_ok(I, m, img, metric, integration_steps):
+        out = _lddmm_step_split(I, m, img, metric, dataset_size, integration_steps, reg_weight, learning_rate_pose,
+                                momentum_preconditioning)
+        if out is not None:
+            return out
         return _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_weight, learning_rate_pose,
                                  momentum_preconditioning)
     m.requires_grad_(True)

@@ -347,3 +347,101 @@ def test_expmap_stream_split_same_bits(sp, B, from_identity):
         assert torch.equal(t, one)
     g = lm.expmap(met, m0.clone().requires_grad_(True), num_steps=4, phiinv=p0)
     assert torch.equal(g.detach(), one)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("sp,msp,B,parts,precond,want_I", [
+    ((20, 24, 28), (20, 24, 28), 5, 2, False, True),     # uneven halves
+    ((20, 24, 28), (10, 12, 16), 4, 2, False, True),     # multiscale momenta (regrid inside every part)
+    ((40, 36), (40, 36), 7, 3, True, True),              # 2D, three parts, preconditioning
+    ((14, 12, 40), (14, 12, 40), 4, 2, False, False)])   # atlas gradient not wanted (lddmm_steps > 1: all but the last)
+def test_lddmm_step_stream_split_equals_one_stream(sp, msp, B, parts, precond, want_I, dtype, tol):
+    """`lddmm.LDDMM_STEP_STREAMS` (default 2): the matching step of a minibatch cut into sub-batches that run forward,
+    backward and momentum update on HIP streams of their own, each splatting into an atlas gradient of its own, the sums
+    over the minibatch (loss, regulariser, atlas gradient) taken on the caller's stream.  Same formulas and normalisers as
+    the one-stream step: loss, regulariser, updated momenta and atlas gradient agree at north_star's bound (observed 1e-7:
+    the order of two sums), I.grad ACCUMULATES onto what it held, its post-accumulate hooks fire exactly once per step
+    (the atlas builder's all-reduce hangs on that), and momenta are updated in place."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import lddmm
+
+    rng = np.random.default_rng(91)
+    d = len(sp)
+    base = torch.from_numpy(smooth_np(rng, (1, 1) + sp, 1.5)).to(dtype).cuda()
+    base = base / base.std()
+    imgs = (base + 0.2 * torch.from_numpy(smooth_np(rng, (B, 1) + sp, 1.0)).to(dtype).cuda()).contiguous()
+    m = scale_momenta(lm, torch.from_numpy(smooth_np(rng, (B, d) + msp, 1.5)).to(dtype).cuda(), 1.5).contiguous()
+    # what I.grad holds before the step: random in float64 (true accumulation), zeros in float32 (the step's gradient is
+    # ~1e-4 of a unit prior: subtracting the prior again would cost the comparison its digits)
+    prior = torch.from_numpy(rng.standard_normal((1, 1) + sp)).to(dtype).cuda()
+    if dtype == torch.float32:
+        prior.zero_()
+    default = lddmm.LDDMM_STEP_STREAMS
+    assert default == 2
+    res = {}
+    try:
+        for p in (1, parts):
+            lddmm.LDDMM_STEP_STREAMS = p
+            I = base.clone().requires_grad_(want_I)
+            fired = []
+            if want_I:
+                I.grad = prior.clone()
+                I.register_post_accumulate_grad_hook(lambda t: fired.append(t.grad.clone()))
+            mm = m.clone()
+            out, loss, reg = lm.lddmm_step(I, mm, imgs, lm.FluidMetric([0.1, 0.0, 0.01]), 3 * B, integration_steps=3,
+                                           reg_weight=1e-2, learning_rate_pose=1e-3, momentum_preconditioning=precond)
+            torch.cuda.synchronize()
+            assert out.data_ptr() == mm.data_ptr() and not out.requires_grad   # updated in place
+            if want_I:
+                assert len(fired) == 1 and torch.equal(fired[0], I.grad)
+            else:
+                assert I.grad is None
+            res[p] = (loss, reg, out, (I.grad - prior) if want_I else None)
+    finally:
+        lddmm.LDDMM_STEP_STREAMS = default
+    for i, name in enumerate(("loss", "reg", "m", "I.grad")):
+        a, b = res[parts][i], res[1][i]
+        if a is None:
+            continue
+        err = float((a.double() - b.double()).abs().max() / b.double().abs().max())
+        assert err <= tol, (name, err)
+    assert float((res[parts][2] - m).abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+def test_atlas_builder_with_split_minibatches_equals_oracle_backend(dtype, tol):
+    """Two epochs of LDDMMAtlasBuilder with minibatches LARGE enough for the stream split of `lddmm_step` (10 subjects in
+    minibatches of 5 and 5: parts of 2 + 3 subjects on two HIP streams; lddmm_steps = 2, so both the step that wants the
+    atlas gradient and the one that does not), against the same run on the oracle backend (one stream by nature) AND
+    against the one-stream HIP run: atlas, momenta, per-iteration losses."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import lddmm
+
+    sp = (16, 18, 20)
+    rng = np.random.default_rng(13)
+    data = torch.from_numpy(smooth_np(rng, (1, 1) + sp, 1.5) + 0.3 * smooth_np(rng, (10, 1) + sp, 1.0)).to(dtype)
+    kw = dict(batch_size=5, lddmm_steps=2, lddmm_integration_steps=2, reg_weight=1e-1, learning_rate_pose=2e-6,
+              learning_rate_image=5e-2)
+    with oracle_backend() as lmo:
+        bc = lmo.LDDMMAtlasBuilder(data, **kw)
+        bc.run(num_epochs=2)
+    runs = {}
+    default = lddmm.LDDMM_STEP_STREAMS
+    try:
+        for parts in (2, 1):
+            lddmm.LDDMM_STEP_STREAMS = parts
+            bg = lm.LDDMMAtlasBuilder(data.cuda(), **kw)
+            bg.run(num_epochs=2)
+            runs[parts] = bg
+    finally:
+        lddmm.LDDMM_STEP_STREAMS = default
+
+    def rel(a, b):
+        return float((a.cpu().double() - b.cpu().double()).abs().max() / b.cpu().double().abs().max())
+
+    for name, ref in (("oracle backend", bc), ("one stream", runs[1])):
+        bg = runs[2]
+        errs = {"atlas": rel(bg.I.detach(), ref.I.detach()),
+                "momenta": max(rel(a, b) for a, b in zip(bg.ms, ref.ms)),
+                "iter_losses": max(abs(a - b) / abs(b) for a, b in zip(bg.iter_losses, ref.iter_losses))}
+        assert max(errs.values()) <= tol, (name, errs)
