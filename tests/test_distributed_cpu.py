@@ -115,13 +115,13 @@ def test_two_rank_atlas_equals_sequential_emulation(tmp_path, oracle_ext, sp):
     assert calls == [(nv, 0, 0), (nv, 1, 1), (2, 0, 0), (nv, 1, 1), (2, 0, 0)], calls
 
 
-def _run_ragged(rank, world, port, sp, out):
+def _run_ragged(rank, world, port, sp, out, n=5):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lm = _patch_oracle()
-        data = _dataset(5, sp)   # 5 subjects over 2 ranks: the sampler pads to 6, one subject is seen twice
+        data = _dataset(n, sp)   # 5 subjects over 2 ranks: the sampler pads to 6, one subject is seen twice
         b = lm.LDDMMAtlasBuilder.from_dataset(data, world_size=world, rank=rank, batch_size=2, lddmm_integration_steps=2,
                                               reg_weight=1e-1, learning_rate_pose=1e-2, learning_rate_image=1e-1)
         I = b.run(num_epochs=2)
@@ -149,42 +149,45 @@ def test_shard_indices_are_the_distributed_samplers():
     assert lm.shard_indices(5, 2, 1, shuffle=False) == [1, 3, 0]
 
 
-def test_two_rank_atlas_with_a_padded_shard(tmp_path, oracle_ext):
-    """5 subjects on 2 ranks through `LDDMMAtlasBuilder.from_dataset`: both ranks hold 3 subjects (2 minibatches), run
-    the same number of iterations (no rank waits at a collective that the other never reaches), end with the same
-    atlas, and the result equals a sequential emulation over the same padded assignment."""
+@pytest.mark.parametrize("world,n", [(2, 5), (4, 9)])
+def test_n_rank_atlas_with_a_padded_shard(tmp_path, oracle_ext, world, n):
+    """5 subjects on 2 ranks (9 on 4) through `LDDMMAtlasBuilder.from_dataset`: every rank holds 3 subjects (2
+    minibatches: the sampler pads the assignment, some subjects are seen by two ranks), runs the same number of iterations
+    (no rank waits at a collective that another never reaches), all end with the same atlas, and the result equals a
+    sequential emulation over the same padded assignment."""
     import lagomorph_amd as lm
 
     sp = (6, 6, 6)
     out = str(tmp_path / "ragged")
-    mp.spawn(_run_ragged, args=(2, _free_port(), sp, out), nprocs=2, join=True)
-    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
-    assert np.array_equal(r0["I"], r1["I"]) and int(r0["nb"]) == int(r1["nb"]) == 2
-    assert list(r0["idx"]) == lm.shard_indices(5, 2, 0) and list(r1["idx"]) == lm.shard_indices(5, 2, 1)
-    # sequential emulation: per iteration both ranks step on their own minibatch against the same atlas, the
+    mp.spawn(_run_ragged, args=(world, _free_port(), sp, out, n), nprocs=world, join=True)
+    rs = [np.load(out + f".{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(rs[0]["I"], rs[r]["I"]) and int(rs[r]["nb"]) == 2
+        assert list(rs[r]["idx"]) == lm.shard_indices(n, world, r)
+    # sequential emulation: per iteration every rank steps on its own minibatch against the same atlas, the
     # gradients are summed and divided by image_iters * world_size (lddmm.py:292-297), one SGD step
-    data = _dataset(5, sp)
-    shards = [data[torch.as_tensor(lm.shard_indices(5, 2, r))] for r in range(2)]
+    data = _dataset(n, sp)
+    shards = [data[torch.as_tensor(lm.shard_indices(n, world, r))] for r in range(world)]
     metric = lm.FluidMetric([0.1, 0, 0.01])
-    mean = sum(lm.lddmm.streaming_batch_average(s, 2) for s in shards).unsqueeze(0) / 2
+    mean = sum(lm.lddmm.streaming_batch_average(s, 2) for s in shards).unsqueeze(0) / world
     I = mean.clone()
-    ms = [[torch.zeros((b, 3) + sp, dtype=data.dtype) for b in (2, 1)] for _ in range(2)]
+    ms = [[torch.zeros((b, 3) + sp, dtype=data.dtype) for b in (2, 1)] for _ in range(world)]
     losses = []
     for _ in range(2):
         tot = 0.0
         for it, (lo, hi) in enumerate(((0, 2), (2, 3))):
             grads = []
-            for r in range(2):
+            for r in range(world):
                 Ir = I.clone().requires_grad_(True)
-                ms[r][it], loss, _ = lm.lddmm_step(Ir, ms[r][it], shards[r][lo:hi], metric, 5, integration_steps=2,
+                ms[r][it], loss, _ = lm.lddmm_step(Ir, ms[r][it], shards[r][lo:hi], metric, n, integration_steps=2,
                                                    reg_weight=1e-1, learning_rate_pose=1e-2)
                 grads.append(Ir.grad)
                 tot += float(loss)
-            I = I - 1e-1 * (grads[0] + grads[1]) / 2
+            I = I - 1e-1 * sum(grads) / world
         losses.append(tot)
-    assert np.allclose(r0["I"], I.numpy(), rtol=1e-10, atol=1e-12)
-    assert np.allclose(r0["loss"], losses, rtol=1e-10)
-    assert np.allclose(r1["ms"], torch.cat(ms[1]).numpy(), rtol=1e-10, atol=1e-12)
+    assert np.allclose(rs[0]["I"], I.numpy(), rtol=1e-10, atol=1e-12)
+    assert np.allclose(rs[0]["loss"], losses, rtol=1e-10)
+    assert np.allclose(rs[world - 1]["ms"], torch.cat(ms[world - 1]).numpy(), rtol=1e-10, atol=1e-12)
 
 
 def _run_affine(rank, world, port, sp, out):
