@@ -303,15 +303,18 @@ def _lddmm_step_fused(I, m, img, metric, dataset_size, integration_steps, reg_we
         return m, (loss * norm_factor), (reg_term * norm_factor)
 
 
-# The matching step of a minibatch of at least 2 * LDDMM_STEP_STREAMS subjects is cut into LDDMM_STEP_STREAMS contiguous
-# sub-batches that run -- forward, backward, momentum update -- on HIP streams of their own, like the forward shoot
-# (EXPMAP_STREAMS above): subjects are independent up to the two sums over the minibatch, the loss and the atlas
-# gradient.  Each part splats into an atlas gradient of its own (a private leaf view of I), records an event when that
-# splat has run, and the caller's stream adds the parts and hands the sum to I through autograd -- I.grad accumulates and
-# its hooks (the atlas builder's asynchronous all-reduce) fire as in the one-stream form, still while the parts'
-# reverse sweeps run.  Same formulas and normalisers; the two sums are taken in a different order (rounding only).
-# 1 switches it off.
-LDDMM_STEP_STREAMS = 2
+# LDDMM_STEP_STREAMS = k >= 2 (an OPTION; default 1 = off): the matching step of a minibatch of at least 2 k subjects is
+# cut into k contiguous sub-batches that run -- forward, backward, momentum update -- on HIP streams of their own, like
+# the forward shoot (EXPMAP_STREAMS above): subjects are independent up to the two sums over the minibatch, the loss and
+# the atlas gradient.  Each part splats into an atlas gradient of its own (a private leaf view of I), records an event
+# when that splat has run, and the caller's stream adds the parts and hands the sum to I through autograd -- I.grad
+# accumulates and its hooks (the atlas builder's asynchronous all-reduce) fire as in the one-stream form, still while the
+# parts' reverse sweeps run.  Same formulas and normalisers; the two sums are taken in a different order (rounding only).
+# Why it is off (profiles/r05_stream_split.md): a lone `lddmm_step` called back to back gains 4-6 % at 4-8 subjects
+# (tools/ab_step_streams.py), but inside LDDMMAtlasBuilder's loop -- a different minibatch every iteration, the image
+# update in between -- the same split measures -1 ... -2.5 % at 4 subjects, +1 ... +3 % at 8 and +-1 % at 32 per GPU
+# (tools/ab_atlas_streams.py): not a robust win where it would matter.
+LDDMM_STEP_STREAMS = 1
 
 
 def _lddmm_step_split(I, m, img, metric, dataset_size, integration_steps, reg_weight, learning_rate_pose,
