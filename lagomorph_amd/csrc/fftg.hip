@@ -527,8 +527,8 @@ bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz, size_t
 }
 
 // ---- Bluestein tables: FFT_M of the conjugate chirp, per (N, sign, precision, device); computed on first use by one
-// workgroup and kept (at most a few hundred KB each, at most kBluMax tables: a full cache is emptied before the next
-// insertion) until lago_fluid_cache_clear() releases them.  The first use synchronises the stream once (another stream
+// workgroup and kept (at most a few hundred KB each, at most kBluMax tables: a full cache takes no more, further
+// lengths run their direct-DFT stages) until lago_fluid_cache_clear() releases them.  The first use synchronises the stream once (another stream
 // may be the next user); while THIS stream is being captured a missing table is not built and the direct-DFT stages
 // serve that call; the allocation itself runs with the thread's capture mode relaxed, so that a global-mode capture in
 // progress on another thread is not invalidated by it.
@@ -568,7 +568,9 @@ static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     const size_t cb = 2 * sizeof(R);
     void *d = nullptr;
-    if (g_blu->size() >= kBluMax) blu_release_locked();
+    // a full cache takes no further tables (the direct-DFT stages serve that length): freeing here could pull a table
+    // from under another thread that has looked it up and not launched yet; lago_fluid_cache_clear() empties the cache
+    if (g_blu->size() >= kBluMax) return nullptr;
     {
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
         const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
