@@ -43,6 +43,12 @@ def _built():
     lbuild = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lbuild)
     lbuild.build()
+    # LAGO_TEST_DEBUG=1: the whole session in the library's debug mode (every launch followed by a stream synchronisation,
+    # kernel faults returned by the call that caused them) -- a slow one-off sanity run, not the default
+    if os.environ.get("LAGO_TEST_DEBUG") == "1" and _has_gpu():
+        import lagomorph_amd
+
+        lagomorph_amd.set_debug_mode(True)
 
 
 @pytest.fixture
