@@ -807,6 +807,13 @@ def main():
                 "bytes_per_launch": bytes_per_launch, "mean_launch_ms": k["mean_ms"], "launches": k["launches"],
                 "measured_in": "the single-stream pass that follows the timed region in this process (config.single_stream): "
                                "HIP events on the launch stream around each of its launches",
+                # the same kernel inside the timed region itself: with the two-stream default each launch covers one
+                # sub-batch and runs BESIDE the other stream's kernels, so its duration is an upper bound of its own time
+                "timed_region": None if op not in ksum_timed else {
+                    "mean_launch_ms": ksum_timed[op]["mean_ms"], "launches": ksum_timed[op]["launches"],
+                    "bytes_per_launch": bytes_per_launch / (default_streams if split_active else 1),
+                    "frac": bytes_per_launch / (default_streams if split_active else 1) / (ksum_timed[op]["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "streams": default_streams if split_active else 1},
                 "others": {n: {"mean_launch_ms": present[n]["mean_ms"],
                                "frac": 36.0 * V / (present[n]["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                            for n in present if n != op},
