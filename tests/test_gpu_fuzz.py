@@ -1,0 +1,25 @@
+"""GPU: a short randomised parity sweep (tools/fuzz_parity.py): random 2D / 3D shapes incl. thin and ragged ones, both
+dtypes, batch / channel counts, broadcast images, displacements from sub-voxel to far out of range (smooth, rough,
+integer-valued), unit and non-unit steps -- interp forward / d_u, the four Jacobian products, compose, Ad_star, affine
+forward and regrid forward BIT FOR BIT against the oracle, the scatter-adds (d_I, d_A, d_T, regrid backward) at
+north_star's bound or, where thousands of float32 terms pile onto one border cell, by the float64 yardstick.  The long
+form (`python tools/fuzz_parity.py 150 <seed>`: ~9 000 cases per run) found no mismatch in 26 722 cases."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_cases_against_the_oracle(seed):
+    import fuzz_parity
+
+    try:
+        n, worst, yard = fuzz_parity.run(budget=12.0, seed=seed)
+    except SystemExit as e:   # the tool reports a mismatch this way
+        pytest.fail(str(e))
+    assert n >= 100, n
+    assert all(v <= 1.0 for v in worst.values()), worst

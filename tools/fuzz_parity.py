@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: random shapes (thin, ragged, 2D and 3D), dtypes, batch / channel counts,
+displacement scales (sub-voxel to far out of range) through the bit-exact operators against the CPU oracle, and the
+scatter-adds at north_star's bound.  Runs for `seconds` (default 120), prints the first mismatch or a count.
+usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import lagomorph_amd as lm
+from oracle import lago_oracle as orc
+
+ext = lm.lagomorph_ext
+
+
+def run(budget=120.0, seed=0):
+    """Returns (cases, worst error per scatter-add in units of its bound, cases decided by the float64 yardstick); raises
+    SystemExit with a description at the first mismatch."""
+    global n
+    rng = np.random.default_rng(seed)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    host = lambda t: t.detach().cpu().numpy()
+    t0, n, worst = time.time(), 0, {}
+
+
+    yard = {}
+
+
+    def close(name, got, want, tol, truth=None):
+        """|got - want| <= tol * max|want|; where that fails and `truth` (a callable returning the float64 oracle's result)
+        is given, the float64 yardstick of tests/test_gpu_lddmm_step.py decides: a scatter-add of thousands of float32 terms
+        onto one border cell differs between two summation orders by more than 1e-5 although both are as accurate as float32
+        allows -- HIP must then be no further from float64 than 1.5 x the float32 oracle is."""
+        want = np.asarray(want, dtype=np.float64)
+        g = host(got).astype(np.float64)
+        err = float(np.abs(g - want).max()) if want.size else 0.0
+        sc = max(float(np.abs(want).max()) if want.size else 0.0, 1e-30)
+        if err > tol * sc and truth is not None:
+            t = np.asarray(truth(), dtype=np.float64)
+            e_hip, e_orc = float(np.abs(g - t).max()) / sc, float(np.abs(want - t).max()) / sc
+            yard[name] = yard.get(name, 0) + 1
+            if e_hip <= max(tol, 1.5 * e_orc):
+                return
+            raise SystemExit(f"MISMATCH {name}: HIP vs float64 {e_hip:.3g}, float32 oracle vs float64 {e_orc:.3g} (case {n})")
+        worst[name] = max(worst.get(name, 0.0), err / (tol * sc))
+        if err > tol * sc:
+            raise SystemExit(f"MISMATCH {name}: err {err:.3g} scale {sc:.3g} (case {n})")
+
+
+    def bits(name, got, want):
+        if not np.array_equal(host(got), want):
+            raise SystemExit(f"BIT MISMATCH {name} (case {n}): max diff {np.abs(host(got) - want).max():.3g}")
+
+
+    while time.time() - t0 < budget:
+        n += 1
+        d = int(rng.choice([2, 3, 3]))
+        sp = tuple(int(x) for x in rng.choice([2, 3, 5, 8, 17, 33, 64, 70], size=d))
+        if rng.random() < 0.15:
+            sp = sp[:-1] + (int(rng.choice([128, 160, 200])),)
+        N, C = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        dt_np = np.float32 if rng.random() < 0.7 else np.float64
+        tol = 1e-5 if dt_np == np.float32 else 1e-12
+        amp = float(rng.choice([0.3, 1.5, 6.0, 40.0]))
+        bc = bool(rng.random() < 0.3)
+        I = rng.standard_normal(((1 if bc else N), C) + sp).astype(dt_np)
+        u = (amp * rng.standard_normal((N, d) + sp)).astype(dt_np)
+        if rng.random() < 0.5:   # smooth-ish displacement: exercises the LDS windows
+            from scipy.ndimage import uniform_filter
+            u = uniform_filter(u, size=[1, 1] + [3] * d, mode="nearest").astype(dt_np)
+        if rng.random() < 0.2:
+            u = np.round(u).astype(dt_np)
+        go = rng.standard_normal((N, C) + sp).astype(dt_np)
+        dtv = float(rng.choice([1.0, -1.0, 0.37, -0.1]))
+        bits("interp_forward", ext.interp_forward(dev(I), dev(u), dtv), orc.interp_forward(I, u, dtv))
+        dI, du = ext.interp_backward(dev(go), dev(I), dev(u), dtv, True, True)
+        oI, ou = orc.interp_backward(go, I, u, dtv, True, True)
+        bits("interp_backward d_u", du, ou)
+        f8 = lambda a: a.astype(np.float64)
+        close("interp_backward d_I", dI, oI, tol, truth=lambda: orc.interp_backward(f8(go), f8(I), f8(u), dtv, True, True)[0])
+        if min(sp) >= 2:
+            v = rng.standard_normal((N, d) + sp).astype(dt_np)
+            w = rng.standard_normal((N, d) + sp).astype(dt_np)
+            for disp, tr in ((True, False), (False, True)):
+                bits("jtv_forward", ext.jacobian_times_vectorfield_forward(dev(v), dev(w), disp, tr),
+                     orc.jacobian_times_vectorfield_forward(v, w, disp, tr))
+            bits("jtv_adjoint_forward", ext.jacobian_times_vectorfield_adjoint_forward(dev(v), dev(w)),
+                 orc.jacobian_times_vectorfield_adjoint_forward(v, w))
+            uu = u[:, :d]
+            k = dt_np   # deform.py:53-55 with torch's rounding: scalars rounded to the tensor dtype, three roundings
+            bits("compose", ext.compose(dev(uu), dev(v), dtv, -0.3), k(dtv) * uu + k(-0.3) * orc.interp_forward(v, uu, dtv))
+            if True:   # (2D and 3D)
+                want = orc.jacobian_times_vectorfield_forward(uu, orc.interp_forward(w, uu, 1.0), True, False)
+                bits("Ad_star", ext.Ad_star(dev(uu), dev(w)), want)
+        A = (np.eye(d)[None] + 0.3 * rng.standard_normal((N, d, d))).astype(dt_np)
+        T = (2.0 * rng.standard_normal((N, d))).astype(dt_np)
+        bits("affine_interp_forward", ext.affine_interp_forward(dev(I), dev(A), dev(T)), orc.affine_interp_forward(I, A, T))
+        gI, gA, gT = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, True, True)
+        oI, oA, oT = orc.affine_interp_backward(go, I, A, T, True, True, True)
+        tr = lambda k: (lambda: orc.affine_interp_backward(f8(go), f8(I), f8(A), f8(T), True, True, True)[k])
+        close("affine d_I", gI, oI, tol, tr(0)); close("affine d_A", gA, oA, tol, tr(1)); close("affine d_T", gT, oT, tol, tr(2))
+        out = tuple(int(x) for x in rng.choice([2, 3, 7, 16, 40], size=d))
+        origin = [float((s - 1) * 0.5 + rng.normal()) for s in sp]
+        spacing = [float((a - 1) / max(b - 1, 1) * rng.choice([1.0, 0.7, 1.6])) or 1.0 for a, b in zip(sp, out)]
+        Ic = rng.standard_normal((N, C) + sp).astype(dt_np)
+        bits("regrid_forward", ext.regrid_forward(dev(Ic), list(out), origin, spacing), orc.regrid_forward(Ic, list(out), origin, spacing))
+        gb = rng.standard_normal((N, C) + out).astype(dt_np)
+        close("regrid_backward", ext.regrid_backward(dev(gb), list(sp), list(out), origin, spacing),
+              orc.regrid_backward(gb, list(sp), list(out), origin, spacing), tol,
+              truth=lambda: orc.regrid_backward(f8(gb), list(sp), list(out), origin, spacing))
+    return n, worst, yard
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    n, worst, yard = run(budget, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f"{n} random cases in {budget:.0f} s, no mismatch; largest error in units of the bound: " +
+          ", ".join(f"{k} {v:.3g}" for k, v in sorted(worst.items())) + f"; decided by the float64 yardstick: {yard}")
