@@ -1,9 +1,10 @@
 """GPU: a short randomised parity sweep (tools/fuzz_parity.py): random 2D / 3D shapes incl. thin and ragged ones, both
 dtypes, batch / channel counts, broadcast images, displacements from sub-voxel to far out of range (smooth, rough,
-integer-valued), unit and non-unit steps -- interp forward / d_u, the four Jacobian products, compose, Ad_star, affine
-forward and regrid forward BIT FOR BIT against the oracle, the scatter-adds (d_I, d_A, d_T, regrid backward) at
-north_star's bound or, where thousands of float32 terms pile onto one border cell, by the float64 yardstick.  The long
-form (`python tools/fuzz_parity.py 150 <seed>`: ~9 000 cases per run) found no mismatch in 26 722 cases."""
+integer-valued), unit and non-unit steps -- interp forward / d_u, the Jacobian products and their backward forms, compose,
+Ad_star, affine forward and regrid forward BIT FOR BIT against the oracle, the fluid metric on random extents and the
+scatter-adds (d_I, d_A, d_T, regrid backward) at north_star's bound or, where thousands of float32 terms pile onto one
+border cell, by the float64 yardstick.  The long form (`python tools/fuzz_parity.py 150 <seed>`: 6 000 - 9 000 cases per
+run) found no mismatch in 58 630 cases over nine seeds."""
 import os
 import sys
 

@@ -96,6 +96,24 @@ def run(budget=120.0, seed=0):
             if True:   # (2D and 3D)
                 want = orc.jacobian_times_vectorfield_forward(uu, orc.interp_forward(w, uu, 1.0), True, False)
                 bits("Ad_star", ext.Ad_star(dev(uu), dev(w)), want)
+            gv = rng.standard_normal((N, d) + sp).astype(dt_np)
+            for disp, tr in ((True, False), (False, True), (True, True)):
+                a, b = ext.jacobian_times_vectorfield_backward(dev(gv), dev(v), dev(w), disp, tr, True, True)
+                oa, ob = orc.jacobian_times_vectorfield_backward(gv, v, w, disp, tr)
+                bits("jtv_backward d_v", a, oa)
+                bits("jtv_backward d_w", b, ob)
+            a, b = ext.jacobian_times_vectorfield_adjoint_backward(dev(gv), dev(v), dev(w), True, True)
+            oa, ob = orc.jacobian_times_vectorfield_adjoint_backward(gv, v, w)
+            bits("jtv_adjoint_backward d_v", a, oa)
+            bits("jtv_adjoint_backward d_w", b, ob)
+            if n % 4 == 0:   # the fluid metric on a random shape: tuned passes, the fused 2D kernel or the generic FFT passes
+                fs = tuple(int(x) for x in rng.choice([4, 6, 8, 9, 10, 12, 14, 15, 16, 22, 25, 26, 31, 32, 34, 58, 64], size=d))
+                mm = rng.standard_normal((N, d) + fs).astype(dt_np)
+                pr = [0.1, float(rng.choice([0.0, 0.05])), float(rng.choice([0.01, 0.3]))]
+                met = lm.FluidMetric(pr)
+                ft = 1e-5 if dt_np == np.float32 else 1e-11
+                close("sharp", met.sharp(dev(mm)), orc.fluid_metric_apply(mm, pr, True), ft)
+                close("flat", met.flat(dev(mm)), orc.fluid_metric_apply(mm, pr, False), ft)
         A = (np.eye(d)[None] + 0.3 * rng.standard_normal((N, d, d))).astype(dt_np)
         T = (2.0 * rng.standard_normal((N, d))).astype(dt_np)
         bits("affine_interp_forward", ext.affine_interp_forward(dev(I), dev(A), dev(T)), orc.affine_interp_forward(I, A, T))
