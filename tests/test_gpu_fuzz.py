@@ -4,7 +4,7 @@ integer-valued), unit and non-unit steps -- interp forward / d_u, the Jacobian p
 Ad_star, affine forward and regrid forward BIT FOR BIT against the oracle, the fluid metric on random extents and the
 scatter-adds (d_I, d_A, d_T, regrid backward) at north_star's bound or, where thousands of float32 terms pile onto one
 border cell, by the float64 yardstick.  The long form (`python tools/fuzz_parity.py 150 <seed>`: 6 000 - 9 000 cases per
-run) found no mismatch in 58 630 cases over nine seeds."""
+run; `LAGO_FUZZ_BIG=1` for volumes of up to 2 M voxels) found no mismatch in 61 700 cases over twelve seeds."""
 import os
 import sys
 
