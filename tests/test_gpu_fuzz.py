@@ -24,3 +24,17 @@ def test_random_cases_against_the_oracle(seed):
         pytest.fail(str(e))
     assert n >= 100, n
     assert all(v <= 1.0 for v in worst.values()), worst
+
+
+def test_random_matching_steps_against_the_oracle_backend():
+    """tools/fuzz_step.py, short form: random `lddmm_step` problems (2D / 3D, multiscale momenta, 1-4 integration steps,
+    preconditioning, 1-6 subjects, the stream-split option, both dtypes) through HIP against the oracle backend.  The
+    long form ran 4 545 steps without a mismatch (profiles/r05_fuzz.md, incl. the four cell-face events it explains)."""
+    import fuzz_step
+
+    try:
+        n, worst, yard = fuzz_step.run(budget=15.0, seed=7)
+    except SystemExit as e:
+        pytest.fail(str(e))
+    assert n >= 20, n
+    assert all(v <= 1.0 for v in worst.values()), worst
