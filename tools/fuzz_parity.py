@@ -16,6 +16,8 @@ from oracle import lago_oracle as orc
 
 ext = lm.lagomorph_ext
 BIG = os.environ.get("LAGO_FUZZ_BIG") == "1"
+TUNE = os.environ.get("LAGO_FUZZ_TUNE", "1") == "1"
+CASE = {}
 if BIG:
     orc.set_threads(min(32, os.cpu_count() or 1))
 
@@ -31,38 +33,41 @@ def run(budget=120.0, seed=0):
 
 
     yard = {}
-    ratio = [0.0]
 
-    def close(name, got, want, tol, truth=None):
-        """|got - want| <= tol * max|want|; where that fails and `truth` (a callable returning the float64 oracle's result)
-        is given, the float64 yardstick of tests/test_gpu_lddmm_step.py decides: a scatter-add of thousands of float32 terms
-        onto one border cell differs between two summation orders by more than 1e-5 although both are as accurate as float32
-        allows -- HIP must then be no further from float64 than 2 x the float32 oracle is (the reference's own atomics add
-        in arbitrary order too)."""
+    def close(name, got, want, tol, truth=None, sabs=None, nterms=None):
+        """|got - want| <= tol * max|want|.  Where that fails for a float32 scatter-add or reduction, two float32 sums of
+        the same n terms in different orders are being compared, and what float32 allows is the summation bound
+        eps * sum|terms| of the element in question, not a fraction of the largest result (a border cell onto which a
+        thousand clamped samples pile up; a d_T that cancels from terms a thousand times its size): with `truth` (the
+        float64 oracle's result), `sabs` (sum of |terms| per element, or a bound of it) and `nterms` (how many terms an
+        element sums, an estimate) HIP must be within (4 + 2 sqrt(n)) eps sum|terms| of the float64 result everywhere --
+        the random-walk size of n float32 additions (strays of a rough field reach their cell one atomic at a time).
+        The reference's own atomics add in arbitrary order too."""
         want = np.asarray(want, dtype=np.float64)
         g = host(got).astype(np.float64)
         err = float(np.abs(g - want).max()) if want.size else 0.0
         sc = max(float(np.abs(want).max()) if want.size else 0.0, 1e-30)
-        if err > tol * sc and truth is not None:
+        if err > tol * sc and truth is not None and g.dtype is not None and tol > 1e-8:
             t = np.asarray(truth(), dtype=np.float64)
-            e_hip, e_orc = float(np.abs(g - t).max()) / sc, float(np.abs(want - t).max()) / sc
+            S = np.asarray(sabs(), dtype=np.float64)
+            nt = np.asarray(nterms(), dtype=np.float64) if nterms is not None else np.ones_like(S)
+            excess = float(np.max(np.abs(g - t) - np.maximum((4.0 + 2.0 * np.sqrt(np.maximum(nt, 0.0))) * 1.2e-7 * S, tol * sc)))
             yard[name] = yard.get(name, 0) + 1
-            ratio[0] = max(ratio[0], e_hip / max(e_orc, 1e-300))
-            if e_hip <= max(tol, 2.0 * e_orc):   # (two float32 sums of n terms in different orders: worst ratio seen 1.50)
+            if excess <= 0.0:
                 return
-            raise SystemExit(f"MISMATCH {name}: HIP vs float64 {e_hip:.3g}, float32 oracle vs float64 {e_orc:.3g} (case {n})")
+            if os.environ.get("LAGO_FUZZ_DUMP"):
+                np.savez(os.environ["LAGO_FUZZ_DUMP"], name=name, hip=g, orc32=want, f64=t, **{k: v for k, v in CASE.items()})
+            raise SystemExit(f"MISMATCH {name}: HIP beyond the float32 summation bound by {excess:.3g} (case {n})")
         worst[name] = max(worst.get(name, 0.0), err / (tol * sc))
         if err > tol * sc:
             raise SystemExit(f"MISMATCH {name}: err {err:.3g} scale {sc:.3g} (case {n})")
-
 
     def bits(name, got, want):
         if not np.array_equal(host(got), want):
             raise SystemExit(f"BIT MISMATCH {name} (case {n}): max diff {np.abs(host(got) - want).max():.3g}")
 
 
-    while time.time() - t0 < budget:
-        n += 1
+    def one_case():
         d = int(rng.choice([2, 3, 3]))
         sp = tuple(int(x) for x in rng.choice([2, 3, 5, 8, 17, 33, 64, 70], size=d))
         if rng.random() < 0.15:
@@ -86,12 +91,15 @@ def run(budget=120.0, seed=0):
             u = np.round(u).astype(dt_np)
         go = rng.standard_normal((N, C) + sp).astype(dt_np)
         dtv = float(rng.choice([1.0, -1.0, 0.37, -0.1]))
+        CASE.clear(); CASE.update(I=I, u=u, go=go, dtv=dtv)
         bits("interp_forward", ext.interp_forward(dev(I), dev(u), dtv), orc.interp_forward(I, u, dtv))
         dI, du = ext.interp_backward(dev(go), dev(I), dev(u), dtv, True, True)
         oI, ou = orc.interp_backward(go, I, u, dtv, True, True)
         bits("interp_backward d_u", du, ou)
         f8 = lambda a: a.astype(np.float64)
-        close("interp_backward d_I", dI, oI, tol, truth=lambda: orc.interp_backward(f8(go), f8(I), f8(u), dtv, True, True)[0])
+        close("interp_backward d_I", dI, oI, tol, truth=lambda: orc.interp_backward(f8(go), f8(I), f8(u), dtv, True, True)[0],
+              sabs=lambda: orc.interp_backward(np.abs(f8(go)), f8(I), f8(u), dtv, True, True)[0],
+              nterms=lambda: 8.0 * orc.interp_backward(np.ones_like(f8(go)), f8(I), f8(u), dtv, True, True)[0] + 8.0)
         if min(sp) >= 2:
             v = rng.standard_normal((N, d) + sp).astype(dt_np)
             w = rng.standard_normal((N, d) + sp).astype(dt_np)
@@ -122,15 +130,27 @@ def run(budget=120.0, seed=0):
                 pr = [0.1, float(rng.choice([0.0, 0.05])), float(rng.choice([0.01, 0.3]))]
                 met = lm.FluidMetric(pr)
                 ft = 1e-5 if dt_np == np.float32 else 1e-11
-                close("sharp", met.sharp(dev(mm)), orc.fluid_metric_apply(mm, pr, True), ft)
-                close("flat", met.flat(dev(mm)), orc.fluid_metric_apply(mm, pr, False), ft)
+                try:
+                    close("sharp", met.sharp(dev(mm)), orc.fluid_metric_apply(mm, pr, True), ft)
+                    close("flat", met.flat(dev(mm)), orc.fluid_metric_apply(mm, pr, False), ft)
+                except RuntimeError as e:   # fluid_mode < 3 may select rocFFT, whose guard fails LOUDLY on a wrong transform
+                    if "rocFFT returned a WRONG" not in str(e):
+                        raise
+                    yard["rocFFT wrong, call failed loudly"] = yard.get("rocFFT wrong, call failed loudly", 0) + 1
         A = (np.eye(d)[None] + 0.3 * rng.standard_normal((N, d, d))).astype(dt_np)
         T = (2.0 * rng.standard_normal((N, d))).astype(dt_np)
+        CASE.update(A=A, T=T)
         bits("affine_interp_forward", ext.affine_interp_forward(dev(I), dev(A), dev(T)), orc.affine_interp_forward(I, A, T))
         gI, gA, gT = ext.affine_interp_backward(dev(go), dev(I), dev(A), dev(T), True, True, True)
         oI, oA, oT = orc.affine_interp_backward(go, I, A, T, True, True, True)
         tr = lambda k: (lambda: orc.affine_interp_backward(f8(go), f8(I), f8(A), f8(T), True, True, True)[k])
-        close("affine d_I", gI, oI, tol, tr(0)); close("affine d_A", gA, oA, tol, tr(1)); close("affine d_T", gT, oT, tol, tr(2))
+        # sum |terms|: d_I -- the splat of |go|; d_T / d_A -- |go| |grad I| (|x - o|) summed over the image: bounded by
+        # sum|go| * 2 max|I| (* the largest half extent)
+        sT = float(np.abs(go).sum()) * 2.0 * float(np.abs(I).max())
+        close("affine d_I", gI, oI, tol, tr(0), sabs=lambda: orc.affine_interp_backward(np.abs(f8(go)), f8(I), f8(A), f8(T), True, True, True)[0],
+              nterms=lambda: 8.0 * orc.affine_interp_backward(np.ones_like(f8(go)), f8(I), f8(A), f8(T), True, True, True)[0] + 8.0)
+        close("affine d_A", gA, oA, tol, tr(1), sabs=lambda: np.full(oA.shape, sT * 0.5 * max(sp)), nterms=lambda: np.full(oA.shape, float(go[0].size)))
+        close("affine d_T", gT, oT, tol, tr(2), sabs=lambda: np.full(oT.shape, sT), nterms=lambda: np.full(oT.shape, float(go[0].size)))
         out = tuple(int(x) for x in rng.choice([2, 3, 7, 16, 40], size=d))
         origin = [float((s - 1) * 0.5 + rng.normal()) for s in sp]
         spacing = [float((a - 1) / max(b - 1, 1) * rng.choice([1.0, 0.7, 1.6])) or 1.0 for a, b in zip(sp, out)]
@@ -139,8 +159,31 @@ def run(budget=120.0, seed=0):
         gb = rng.standard_normal((N, C) + out).astype(dt_np)
         close("regrid_backward", ext.regrid_backward(dev(gb), list(sp), list(out), origin, spacing),
               orc.regrid_backward(gb, list(sp), list(out), origin, spacing), tol,
-              truth=lambda: orc.regrid_backward(f8(gb), list(sp), list(out), origin, spacing))
-    yard["worst HIP / oracle error ratio"] = round(ratio[0], 3)
+              truth=lambda: orc.regrid_backward(f8(gb), list(sp), list(out), origin, spacing),
+              sabs=lambda: orc.regrid_backward(np.abs(f8(gb)), list(sp), list(out), origin, spacing),
+              nterms=lambda: 8.0 * orc.regrid_backward(np.ones_like(f8(gb)), list(sp), list(out), origin, spacing) + 8.0)
+
+    while time.time() - t0 < budget:
+        n += 1
+        # every third case under a random combination of the library's sibling implementations (lago_tuning and the
+        # shim's switches: speed only, never results -- which is what this checks)
+        knobs = None
+        if TUNE and n % 3 == 0:
+            knobs = dict(gw=int(rng.integers(0, 2)), st=int(rng.integers(0, 2)), vk=int(rng.integers(0, 2)), sm=int(rng.integers(0, 2)),
+                         fm=int(rng.integers(0, 4)), mc=int(rng.integers(0, 3)), sep=int(rng.integers(0, 2)), box=int(rng.integers(0, 2)),
+                         lo=int(rng.integers(0, 2)))
+            ext.set_gather_window(knobs["gw"]); ext.set_stencil_tile(knobs["st"]); ext.set_vector_kernels(knobs["vk"])
+            ext.set_splat_mode(knobs["sm"]); ext.set_fluid_mode(knobs["fm"]); ext.set_splat_shear_mc(knobs["mc"])
+            ext.REGRID_BACKWARD_SEPARABLE = knobs["sep"]; ext.tune(affine_box=knobs["box"]); ext.set_launch_order(knobs["lo"])
+        try:
+            one_case()
+        except SystemExit as e:
+            raise SystemExit(f"{e} [tuning {knobs}]")
+        finally:
+            if knobs is not None:
+                ext.set_gather_window(1); ext.set_stencil_tile(1); ext.set_vector_kernels(1); ext.set_splat_mode(1)
+                ext.set_fluid_mode(3); ext.set_splat_shear_mc(2); ext.REGRID_BACKWARD_SEPARABLE = 1; ext.tune(affine_box=1)
+                ext.set_launch_order(1)
     return n, worst, yard
 
 
