@@ -19,6 +19,13 @@ import lagomorph_amd as lm
 from lagomorph_amd import lddmm
 from test_gpu_lddmm_step import oracle_backend, smooth_np
 
+BIG = os.environ.get("LAGO_FUZZ_BIG") == "1"
+if BIG:
+    from oracle import lago_oracle as _orc
+
+    _orc.set_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
 
 def run(budget=120.0, seed=0):
     rng = np.random.default_rng(seed)
@@ -27,6 +34,10 @@ def run(budget=120.0, seed=0):
         n += 1
         d = int(rng.choice([2, 3, 3]))
         sp = tuple(int(x) for x in rng.choice([6, 8, 10, 12, 16, 20, 24], size=d))
+        if BIG:   # LAGO_FUZZ_BIG=1: volumes on which the tile / window / tuned-FFT fast paths of the step engage
+            sp = tuple(int(x) for x in rng.choice([32, 40, 48, 64, 96], size=d))
+            if d == 3 and np.prod(sp) > 300_000:
+                sp = (int(min(sp[0], 32)), int(min(sp[1], 48)), sp[2])
         multi = rng.random() < 0.3
         msp = tuple(max(4, s // 2 + int(rng.integers(0, 3))) for s in sp) if multi else sp
         B = int(rng.integers(1, 7))
