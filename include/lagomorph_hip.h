@@ -314,6 +314,18 @@ int lago_fluid_metric_f64(double *out, const double *m, double *work, int64_t lu
                           const double *cosX, const double *sinX, const double *cosY, const double *sinY,
                           const double *cosZ, const double *sinZ, double alpha, double beta, double gamma, int dim,
                           int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream);
+/* out = out_scale * (the field lago_fluid_metric returns): the factor multiplies the finished value in the field's
+ * precision, i.e. the bits of a separate `out *= out_scale` pass, without that pass where the last kernel can take the
+ * factor (the tuned 3D passes, the fused 2D kernel); one in-place pass inside the call otherwise.  For the Euler step
+ * from the identity, phi_1 = -dt * sharp(m0) (lddmm.py:39-44 with a zero displacement; lagomorph_amd/lddmm.py). */
+int lago_fluid_metric_scaled_f32(float *out, const float *m, float *work, int64_t lut_generation, int inverse,
+                                 const float *cosX, const float *sinX, const float *cosY, const float *sinY,
+                                 const float *cosZ, const float *sinZ, double alpha, double beta, double gamma, int dim,
+                                 int64_t nn, int64_t nx, int64_t ny, int64_t nz, double out_scale, void *stream);
+int lago_fluid_metric_scaled_f64(double *out, const double *m, double *work, int64_t lut_generation, int inverse,
+                                 const double *cosX, const double *sinX, const double *cosY, const double *sinY,
+                                 const double *cosZ, const double *sinZ, double alpha, double beta, double gamma, int dim,
+                                 int64_t nn, int64_t nx, int64_t ny, int64_t nz, double out_scale, void *stream);
 /* Drops every cached coefficient table (buffers still read by enqueued kernels are freed after them). */
 void lago_fluid_cache_clear(void);
 int lago_fluid_cache_entries(void);

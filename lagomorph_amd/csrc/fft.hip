@@ -37,13 +37,13 @@ bool fluid_xpass_supported(int64_t nx);
 // fft3.hip
 bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz);
 int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
-                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s);
+                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s, float oscale);
 int fluid_xpass_launch(float *F, const float *tab, int inverse, int64_t nn, int64_t nx, int64_t ny, int64_t nzc,
                        double scale, hipStream_t s);
 bool fluid2d_supported(int64_t h, int64_t w);
 int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, const float *sinX, const float *cosY,
                     const float *sinY, double alpha, double beta, double gamma, int64_t nn, int64_t h, int64_t w,
-                    hipStream_t s);
+                    hipStream_t s, float oscale);
 // fftg.hip
 bool fluid_generic_supported(int dim, int64_t nx, int64_t ny, int64_t nz, size_t esize);
 void bluestein_cache_clear();   // fftg.hip
@@ -442,10 +442,41 @@ static int fluid_metric_xpass(float *out, const float *m, float *work, int64_t g
     return finish_launch(s, "fluid_metric");
 }
 
+// out *= f, in place: the trailing pass of lago_fluid_metric_scaled on the paths whose last kernel has no factor of its own
+template <typename R>
+__global__ __launch_bounds__(256) void scale_inplace_kernel(R *__restrict__ x, size_t n, R f) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= f;
+}
+
+template <typename R>
+static int fluid_metric_unscaled(R *out, const R *m, R *work, int64_t gen, int inverse, const R *cosX, const R *sinX,
+                                 const R *cosY, const R *sinY, const R *cosZ, const R *sinZ, double alpha, double beta,
+                                 double gamma, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream,
+                                 R oscale, bool &scaled);
+
+// out = oscale * irfftn(operator(rfftn(m))): the factor multiplies the finished value (the bits of `out * oscale` in the
+// field's precision) -- inside the last kernel of the tuned 3D passes and of the fused 2D kernel, as one more pass on
+// the other paths
 template <typename R>
 static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inverse, const R *cosX, const R *sinX, const R *cosY,
                              const R *sinY, const R *cosZ, const R *sinZ, double alpha, double beta, double gamma,
-                             int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {
+                             int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream, double out_scale) {
+    const R f = (R)out_scale;
+    bool scaled = false;
+    int rc = fluid_metric_unscaled<R>(out, m, work, gen, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim,
+                                      nn, nx, ny, nz, stream, f, scaled);
+    if (rc != LAGO_OK || scaled || f == (R)1 || nn == 0) return rc;
+    const size_t n = (size_t)nn * dim * nx * ny * (dim == 2 ? 1 : nz);
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(scale_inplace_kernel<R>, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, n, f);
+    return finish_launch((hipStream_t)stream, "fluid_metric (scale)");
+}
+
+template <typename R>
+static int fluid_metric_unscaled(R *out, const R *m, R *work, int64_t gen, int inverse, const R *cosX, const R *sinX,
+                                 const R *cosY, const R *sinY, const R *cosZ, const R *sinZ, double alpha, double beta,
+                                 double gamma, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream,
+                                 R oscale, bool &scaled) {
     if (dim != 2 && dim != 3) return fail_invalid("Only two- and three-dimensional fluid metric is supported");
     if (dim == 2) nz = 1;
     if (nn < 0 || nx < 1 || ny < 1 || nz < 1 || nn * dim >= (1ll << 31) || nx * ny * nz >= (1ll << 29))
@@ -456,8 +487,10 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
     if (sizeof(R) == 4 && dim == 2 && g_fluid_xpass >= 2 && fluid2d_supported(nx, ny) && nn < (1ll << 31) &&
         (((uintptr_t)out | (uintptr_t)m) & 15) == 0) {
         note_path(LP_FLUID_2D);
+        scaled = true;
         return fluid_metric_2d((float *)out, (const float *)m, inverse, (const float *)cosX, (const float *)sinX,
-                               (const float *)cosY, (const float *)sinY, alpha, beta, gamma, nn, nx, ny, (hipStream_t)stream);
+                               (const float *)cosY, (const float *)sinY, alpha, beta, gamma, nn, nx, ny, (hipStream_t)stream,
+                               (float)oscale);
     }
     // the table-based fast paths need a LUT generation to key their cached coefficient table on
     if (gen != 0 && sizeof(R) == 4 && dim == 3 && g_fluid_xpass >= 2 && fluid_native_supported(nx, ny, nz) &&
@@ -468,8 +501,9 @@ static int fluid_metric_impl(R *out, const R *m, R *work, int64_t gen, int inver
                           nz, 1, (hipStream_t)stream);
         if (rc != LAGO_OK) return rc;
         note_path(LP_FLUID_LDS);
+        scaled = true;
         return fluid_metric_native((float *)out, (const float *)m, (float *)work, tab->d, inverse, nn, nx, ny, nz,
-                                   1.0 / ((double)nx * (double)ny * (double)nz), (hipStream_t)stream);
+                                   1.0 / ((double)nx * (double)ny * (double)nz), (hipStream_t)stream, (float)oscale);
     }
     if (g_fluid_xpass >= 3 && fluid_generic_supported(dim, nx, ny, nz, sizeof(R))) {
         note_path(LP_FLUID_GENERIC);
@@ -545,7 +579,15 @@ int lago_fft_plan_state(int *plans, int *verified) {
                                const REAL *cosZ, const REAL *sinZ, double alpha, double beta, double gamma,       \
                                int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz, void *stream) {           \
         return lago::fluid_metric_impl<REAL>(out, m, work, lut_generation, inverse, cosX, sinX, cosY, sinY, cosZ, \
-                                             sinZ, alpha, beta, gamma, dim, nn, nx, ny, nz, stream);              \
+                                             sinZ, alpha, beta, gamma, dim, nn, nx, ny, nz, stream, 1.0);         \
+    }                                                                                                              \
+    int lago_fluid_metric_scaled##SUF(REAL *out, const REAL *m, REAL *work, int64_t lut_generation, int inverse,  \
+                                      const REAL *cosX, const REAL *sinX, const REAL *cosY, const REAL *sinY,     \
+                                      const REAL *cosZ, const REAL *sinZ, double alpha, double beta,              \
+                                      double gamma, int dim, int64_t nn, int64_t nx, int64_t ny, int64_t nz,      \
+                                      double out_scale, void *stream) {                                           \
+        return lago::fluid_metric_impl<REAL>(out, m, work, lut_generation, inverse, cosX, sinX, cosY, sinY, cosZ, \
+                                             sinZ, alpha, beta, gamma, dim, nn, nx, ny, nz, stream, out_scale);   \
     }
 LAGO_DEFINE(float, _f32)
 LAGO_DEFINE(double, _f64)

@@ -59,7 +59,7 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_kernel(fl::
     const float2 *mainp = a.main_ + p * (size_t)(K::NY * K::NZH), *nyqp = a.nyq + p * (size_t)K::NY;
 #pragma unroll
     for (int ph = 0; ph < K::NPH_INV; ++ph) {
-        K::inv_phase(ph, threadIdx.x, out, mainp, nyqp, P, tw);
+        K::inv_phase(ph, threadIdx.x, out, mainp, nyqp, P, tw, a.oscale);
         if (ph + 1 < K::NPH_INV) __syncthreads();
     }
 }
@@ -142,7 +142,7 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
 #pragma unroll
                 for (int k = 0; k < K::KVX; ++k) settle(v[k]);
             }
-            K::inv_phase(ph, threadIdx.x, out, nullptr, nullptr, P, tw);
+            K::inv_phase(ph, threadIdx.x, out, nullptr, nullptr, P, tw, a.oscale);
             __syncthreads();
         }
     }
@@ -171,7 +171,8 @@ template <int NY, int NZ, bool INV>
 __global__ __launch_bounds__((ZYK2D<NY, NZ>::THREADS)) void fluid2d_kernel(float *__restrict__ out, const float *__restrict__ m,
                                                                        const float *__restrict__ cosX, const float *__restrict__ sinX,
                                                                        const float *__restrict__ cosY, const float *__restrict__ sinY,
-                                                                       double alpha, double beta, double gamma, float scale) {
+                                                                       double alpha, double beta, double gamma, float scale,
+                                                                       float oscale) {
     using K = ZYK2D<NY, NZ>;
     using SY = typename SzOf<NY>::T;
     using SZH = typename SzOf<NZ / 2>::T;
@@ -238,8 +239,8 @@ __global__ __launch_bounds__((ZYK2D<NY, NZ>::THREADS)) void fluid2d_kernel(float
     __syncthreads();
 #pragma unroll
     for (int ph = 1; ph < K::NPH_INV; ++ph) {
-        K::inv_phase(ph, threadIdx.x, out0, nullptr, nullptr, P0, tw);
-        K::inv_phase(ph, threadIdx.x, out1, nullptr, nullptr, P1, tw);
+        K::inv_phase(ph, threadIdx.x, out0, nullptr, nullptr, P0, tw, oscale);
+        K::inv_phase(ph, threadIdx.x, out1, nullptr, nullptr, P1, tw, oscale);
         if (ph + 1 < K::NPH_INV) __syncthreads();
     }
 }
@@ -261,7 +262,7 @@ bool fluid2d_supported(int64_t h, int64_t w) {
 template <int NY, int NZ>
 static hipError_t fluid2d_launch(float *out, const float *m, int inverse, const float *cosX, const float *sinX,
                                  const float *cosY, const float *sinY, double alpha, double beta, double gamma,
-                                 int64_t nn, hipStream_t s) {
+                                 int64_t nn, hipStream_t s, float oscale) {
     using K = ZYK2D<NY, NZ>;
     constexpr size_t smem = (size_t)(2 * NY * K::PZ + K::LTW) * sizeof(float2);
     static_assert(smem <= 160 * 1024, "two planes do not fit the LDS");
@@ -270,22 +271,22 @@ static hipError_t fluid2d_launch(float *out, const float *m, int inverse, const 
         auto k = fluid2d_kernel<NY, NZ, true>;
         hipError_t e = allow_smem(k, smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((uint32_t)nn), dim3(K::THREADS), smem, s, out, m, cosX, sinX, cosY, sinY, alpha, beta, gamma, scale);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nn), dim3(K::THREADS), smem, s, out, m, cosX, sinX, cosY, sinY, alpha, beta, gamma, scale, oscale);
     } else {
         auto k = fluid2d_kernel<NY, NZ, false>;
         hipError_t e = allow_smem(k, smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((uint32_t)nn), dim3(K::THREADS), smem, s, out, m, cosX, sinX, cosY, sinY, alpha, beta, gamma, scale);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nn), dim3(K::THREADS), smem, s, out, m, cosX, sinX, cosY, sinY, alpha, beta, gamma, scale, oscale);
     }
     return hipSuccess;
 }
 
 int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, const float *sinX, const float *cosY,
                     const float *sinY, double alpha, double beta, double gamma, int64_t nn, int64_t h, int64_t w,
-                    hipStream_t s) {
+                    hipStream_t s, float oscale) {
     hipError_t e = hipErrorInvalidValue;
 #define X(H, W) \
-    if (h == H && w == W) e = fluid2d_launch<H, W>(out, m, inverse, cosX, sinX, cosY, sinY, alpha, beta, gamma, nn, s);
+    if (h == H && w == W) e = fluid2d_launch<H, W>(out, m, inverse, cosX, sinX, cosY, sinY, alpha, beta, gamma, nn, s, oscale);
     LAGO_2D_SHAPES(X)
 #undef X
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (2D)");
@@ -510,7 +511,7 @@ std::atomic<int> g_native_stage_mask{7};
 // out = irfftn(operator(rfftn(m))) * scale.  tab: split-layout coefficient table (fluid_coef_launch
 // with split = 1).  work: nn*3*nx*ny*(nz/2+1) complex.
 int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
-                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s) {
+                        int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s, float oscale) {
     const int64_t nzh = nz / 2, planes = nn * 3 * nx;
     const int64_t items = ny * (nzh / 16) + ny / 16;
     if (planes >= (1ll << 31) || nn * items >= (1ll << 31)) return fail_invalid("fluid_metric: batch too large");
@@ -520,6 +521,7 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     za.main_ = reinterpret_cast<float2 *>(work);
     za.nyq = za.main_ + (size_t)planes * ny * nzh;
     za.total = (uint32_t)planes;
+    za.oscale = oscale;   // (read by the inverse zy pass only)
     fl::XArgs xa;
     xa.main_ = za.main_;
     xa.nyq = za.nyq;

@@ -524,6 +524,7 @@ struct ZYArgs {
     float2 *main_, *nyq;
     uint32_t total;
     int rev;           // launch direction (common.hpp): planes descending
+    float oscale = 1.0f;   // inverse: factor on every stored value (lago_fluid_metric_scaled)
 };
 
 // threads per plane: 1024 for the planes that are alone on their CU (above 80 KB of LDS: the persistent kernels of
@@ -686,8 +687,9 @@ struct ZY {
     }
 
     // -- inverse: main[r][c], nyq[r] -> real plane (unnormalised: NY * NZ times the original)
+    // oscale: applied to the finished value in the store phase -- the bits a separate multiply of the stored plane gives
     LAGO_HD static void inv_phase(int ph, int tid, float *out, const float2 *mainp, const float2 *nyqp, float2 *P,
-                                  float2 *tw) {
+                                  float2 *tw, float oscale = 1.0f) {
         if (ph == 0) {
             fill_twiddles(tid, tw);
             float4 v[KVX];
@@ -725,7 +727,8 @@ struct ZY {
                 if (tid + k * NT >= F4) continue;
                 const int e = (tid + k * NT) * 2, y = e / NZH, j = e % NZH;
                 const float2 a = P[y * PZ + j], c = P[y * PZ + j + 1];
-                stg4<LAGO_NT_ZI_ST>(reinterpret_cast<float4 *>(out) + (tid + k * NT), make_float4(a.x, a.y, c.x, c.y));
+                stg4<LAGO_NT_ZI_ST>(reinterpret_cast<float4 *>(out) + (tid + k * NT),
+                                    make_float4(a.x * oscale, a.y * oscale, c.x * oscale, c.y * oscale));
             }
         }
     }

@@ -71,6 +71,8 @@ _SIGS = {
     "lago_ad_star": [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _vp],
     "lago_fluid_metric": [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64, _i64,
                           _i64, _i64, _vp],
+    "lago_fluid_metric_scaled": [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _i64,
+                                 _i64, _i64, _i64, _dbl, _vp],
 }
 _fn = {}
 for _name, _args in _SIGS.items():
@@ -480,11 +482,13 @@ def fft_plan_state():
     return a.value, b.value
 
 
-def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma, lut_generation=0):
+def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma, lut_generation=0, out_scale=1.0):
     """Whole FluidMetricOperator.forward (metric.py:11-19) in one call: irfft(L^(+-2) rfft(mv)).
     Not part of the reference's extension surface.  Returns a new tensor; mv is not modified.
     `lut_generation` names the CONTENTS of the LUTs (see include/lagomorph_hip.h): non-zero lets the
-    library cache its coefficient table under that number; 0 takes the table-free path."""
+    library cache its coefficient table under that number; 0 takes the table-free path.
+    `out_scale`: a factor on the result, applied to the finished value (the bits of `result * out_scale`) inside the
+    last kernel where that kernel can take it (lago_fluid_metric_scaled)."""
     _check_input(mv, "mv")
     dim, nx, ny, nz = _spatial(mv)
     if dim not in (2, 3):
@@ -506,6 +510,10 @@ def fluid_metric(mv, inverse, cosluts, sinluts, alpha, beta, gamma, lut_generati
     out = torch.empty_like(mv)
     work = torch.empty((mv.size(0), dim, *csh, 2), dtype=mv.dtype, device=mv.device)
     p = [_ptr(t) for t in luts] + [None] * (6 - 2 * dim)
+    if float(out_scale) != 1.0:
+        _call("lago_fluid_metric_scaled", mv, _ptr(out), _ptr(mv), _ptr(work), int(lut_generation), int(bool(inverse)), *p,
+              float(alpha), float(beta), float(gamma), dim, mv.size(0), nx, ny, nz, float(out_scale))
+        return out
     _call("lago_fluid_metric", mv, _ptr(out), _ptr(mv), _ptr(work), int(lut_generation), int(bool(inverse)), *p, float(alpha), float(beta),
           float(gamma), dim, mv.size(0), nx, ny, nz)
     return out

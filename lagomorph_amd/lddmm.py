@@ -186,8 +186,11 @@ def _first_step(metric, m0, dt, v0=None, mommask=None):
     through the Ad_star and compose kernels (up to the sign of exact zeros), for finite m0.  v0: sharp(m0) if the
     caller already has it."""
     m = m0 if mommask is None else m0 * mommask
-    v = metric.sharp(m) if (v0 is None or mommask is not None) else v0
-    return v * (-dt)
+    if v0 is None or mommask is not None:
+        if isinstance(metric, FluidMetric) and isinstance(dt, (int, float)):   # the factor rides in the operator's last kernel: same bits, one pass less
+            return metric.sharp(m, out_scale=-dt)
+        return metric.sharp(m) * (-dt)
+    return v0 * (-dt)
 
 
 def _fused_expmap_ok(metric, m0, phiinv, mommask, v0):
@@ -347,12 +350,17 @@ def _lddmm_step_split(I, m, img, metric, dataset_size, integration_steps, reg_we
         # gradient, accumulated into I.grad through autograd so that post-accumulate hooks fire
         for ev in events:
             main.wait_event(ev)
+        for Ik in leaves:   # (made on a side stream, read on this one: keep the allocator from handing the memory out
+            Ik.grad.record_stream(main)   # again before this stream's reads have run)
         g = leaves[0].grad
         for Ik in leaves[1:]:
             g = g + Ik.grad
         torch.autograd.backward(I, g)
     for s in streams:
         main.wait_stream(s)
+    for r in res:
+        r[1].record_stream(main)
+        r[2].record_stream(main)
     loss, reg = res[0][1], res[0][2]
     for r in res[1:]:
         loss = loss + r[1]

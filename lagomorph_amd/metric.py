@@ -23,18 +23,22 @@ def _irfft(Fx, spatial_dim, signal_sizes):
     return torch.fft.irfftn(torch.view_as_complex(Fx), s=tuple(signal_sizes), dim=dims, norm="ortho")
 
 
-def _apply(mv, inverse, luts, params):
-    """rFFT -> per-frequency operator -> inverse rFFT.  On the GPU this is one C-ABI call
+def _apply(mv, inverse, luts, params, out_scale=1.0):
+    """rFFT -> per-frequency operator -> inverse rFFT (times `out_scale`).  On the GPU this is one C-ABI call
     (hipFFT on caller buffers + csrc/metric.hip, 1/N folded into the kernel); the three-call
     form below is the reference's literal sequence and is what the extension surface exposes."""
     if USE_FUSED_FLUID and hasattr(lagomorph_ext, "fluid_metric"):
+        if out_scale != 1.0:
+            return lagomorph_ext.fluid_metric(mv.contiguous(), inverse, luts["cos"], luts["sin"], *params,
+                                              lut_generation=luts.get("gen", 0), out_scale=out_scale)
         return lagomorph_ext.fluid_metric(mv.contiguous(), inverse, luts["cos"], luts["sin"], *params,
                                           lut_generation=luts.get("gen", 0))
     sh = mv.shape
     spatial_dim = len(sh) - 2
     Fmv = _rfft(mv.contiguous(), spatial_dim)
     lagomorph_ext.fluid_operator(Fmv, inverse, luts["cos"], luts["sin"], *params)
-    return _irfft(Fmv, spatial_dim, sh[2:])
+    out = _irfft(Fmv, spatial_dim, sh[2:])
+    return out if out_scale == 1.0 else out * out_scale
 
 
 USE_FUSED_FLUID = True
@@ -45,15 +49,16 @@ class FluidMetricOperator(torch.autograd.Function):
     The operator is self-adjoint, so backward applies the same operator to the output gradient."""
 
     @staticmethod
-    def forward(ctx, params, luts, inverse, mv):
+    def forward(ctx, params, luts, inverse, mv, out_scale=1.0):
         ctx.params = params
         ctx.luts = luts
         ctx.inverse = inverse
-        return _apply(mv, inverse, luts, params)
+        ctx.out_scale = out_scale
+        return _apply(mv, inverse, luts, params, out_scale)
 
     @staticmethod
     def backward(ctx, outgrad):
-        return None, None, None, _apply(outgrad, ctx.inverse, ctx.luts, ctx.params)
+        return None, None, None, _apply(outgrad, ctx.inverse, ctx.luts, ctx.params, ctx.out_scale), None
 
 
 def fluid_luts(spatial_shape, dtype, device):
@@ -104,13 +109,16 @@ class FluidMetric(object):
             self._lut_cache[key] = fluid_luts(shape[2:], dtype, device)
         self.luts = self._lut_cache[key]
 
-    def operator(self, mv, inverse):
+    def operator(self, mv, inverse, out_scale=1.0):
         self.initialize_luts(shape=mv.shape, dtype=mv.dtype, device=mv.device)
+        if out_scale != 1.0:
+            return FluidMetricOperator.apply(self.params, self.luts, inverse, mv, float(out_scale))
         return FluidMetricOperator.apply(self.params, self.luts, inverse, mv)
 
-    def sharp(self, m):
-        """momentum -> velocity (apply the Green's function)."""
-        return self.operator(m, inverse=True)
+    def sharp(self, m, out_scale=1.0):
+        """momentum -> velocity (apply the Green's function).  `out_scale` (not in the reference): a factor on the
+        result, the bits of `sharp(m) * out_scale` without the extra pass (lago_fluid_metric_scaled)."""
+        return self.operator(m, inverse=True, out_scale=out_scale)
 
     def flat(self, m, out=None):
         """velocity -> momentum (apply the differential operator)."""

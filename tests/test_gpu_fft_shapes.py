@@ -27,3 +27,52 @@ def test_fft_passes_match_the_float64_path(shape):
         ref = f(m.double())
         err = float((out.double() - ref).abs().max() / ref.abs().max())
         assert err <= 2e-6, (shape, err)
+
+
+@pytest.mark.parametrize("sp,dtype,mode", [
+    ((128, 128, 128), torch.float32, 3), ((160, 160, 160), torch.float32, 3),   # tuned passes (persistent zy at 160)
+    ((64, 96, 128), torch.float32, 3), ((32, 32, 64), torch.float32, 3),
+    ((128, 128), torch.float32, 3), ((64, 256), torch.float32, 3),              # the fused 2D kernel
+    ((24, 20, 28), torch.float32, 3), ((100, 100), torch.float32, 3),           # generic passes
+    ((24, 20, 28), torch.float64, 3), ((30, 36), torch.float64, 3),
+    ((64, 40, 40), torch.float32, 1), ((24, 20, 28), torch.float32, 0), ((24, 20, 28), torch.float64, 0)])   # rocFFT forms
+def test_scaled_operator_has_the_bits_of_a_separate_multiply(sp, dtype, mode):
+    """`lago_fluid_metric_scaled`: out_scale * K(m) is the finished value times the factor -- bit for bit what
+    `K(m) * out_scale` gives, on every implementation of the operator (the factor rides in the last kernel of the
+    tuned 3D passes and of the 2D kernel; the other paths run one in-place pass), both directions, and through the
+    autograd node (the backward of s K is s K)."""
+    import lagomorph_amd as lm
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    m = torch.randn((3, len(sp)) + sp, device="cuda", dtype=dtype, generator=g)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    lm.lagomorph_ext.set_fluid_mode(mode)
+    try:
+        for s in (-0.1, 1.0 / 3.0, -1.0, 7.5):
+            v = met.sharp(m)
+            assert torch.equal(met.sharp(m, out_scale=s), v * s), (sp, dtype, mode, s)
+            f = met.operator(m, inverse=False)
+            assert torch.equal(met.operator(m, inverse=False, out_scale=s), f * s), (sp, dtype, mode, s)
+        assert torch.equal(met.sharp(m, out_scale=1.0), met.sharp(m))
+        mr = m.clone().requires_grad_(True)
+        go = torch.randn(m.shape, device="cuda", dtype=dtype, generator=g)
+        met.sharp(mr, out_scale=-0.25).backward(go)
+        assert torch.equal(mr.grad, met.sharp(go) * -0.25)
+    finally:
+        lm.lagomorph_ext.set_fluid_mode(3)
+
+
+def test_first_euler_step_uses_the_scaled_operator():
+    """`expmap` from the identity: phi_1 = -dt sharp(m0) comes out of ONE call of the operator (no multiply pass), with
+    the bits of the two-call form."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import lddmm
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    m = torch.randn((2, 3, 32, 32, 64), device="cuda", generator=g)
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    one = lddmm._first_step(met, m, 0.1)
+    assert torch.equal(one, met.sharp(m) * -0.1)
+    v0 = met.sharp(m)
+    assert torch.equal(lddmm._first_step(met, m, 0.1, v0=v0), one)
+    assert torch.equal(lm.expmap(met, m, num_steps=1), met.sharp(m) * -1.0)   # (dt = 1)
