@@ -255,3 +255,25 @@ def test_tuning_is_one_struct():
     finally:
         ext.tune(**d)
     assert ext.get_tuning() == d
+
+
+def test_operator_output_factor_on_the_host_form(oracle_ext):
+    """`FluidMetric.sharp(m, out_scale=s)` (the GPU form folds s into the operator's last kernel,
+    lago_fluid_metric_scaled): on the three-call host form it is `sharp(m) * s`, its backward s * sharp(grad), and the
+    first Euler step of `expmap` from the identity uses it (-dt sharp(m0))."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import lddmm
+
+    g = torch.Generator().manual_seed(3)
+    m = torch.randn((2, 3, 6, 8, 10), dtype=torch.float64, generator=g)
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    v = met.sharp(m)
+    assert torch.equal(met.sharp(m, out_scale=-0.25), v * -0.25)
+    assert torch.equal(met.sharp(m, out_scale=1.0), v)
+    mr = m.clone().requires_grad_(True)
+    go = torch.randn(m.shape, dtype=torch.float64, generator=g)
+    met.sharp(mr, out_scale=-0.25).backward(go)
+    assert torch.equal(mr.grad, met.sharp(go) * -0.25)
+    assert torch.equal(lddmm._first_step(met, m, 0.5), v * -0.5)
+    assert torch.equal(lddmm._first_step(met, m, 0.5, v0=v), v * -0.5)
+    assert torch.equal(lm.expmap(met, m, num_steps=1), v * -1.0)
