@@ -37,7 +37,7 @@ extern "C" {
 #define LAGO_ERR_INVALID (-1)
 #define LAGO_ERR_HIP (-2)
 
-#define LAGO_ABI_VERSION 4
+#define LAGO_ABI_VERSION 5
 
 /* ---- housekeeping --------------------------------------------------------- */
 

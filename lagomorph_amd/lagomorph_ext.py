@@ -23,7 +23,7 @@ import torch  # must be imported first: it loads the process's libamdhip64.so.7
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LAGO_HIP_LIBRARY selects another build of the same C ABI (tools/ use the -DLAGO_PROFILING build this way)
 LIB_PATH = os.environ.get("LAGO_HIP_LIBRARY") or os.path.join(_HERE, "_lib", "liblagomorph_hip.so")
-ABI_VERSION = 4  # LAGO_ABI_VERSION of include/lagomorph_hip.h this binding was written against
+ABI_VERSION = 5  # LAGO_ABI_VERSION of include/lagomorph_hip.h this binding was written against
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35, names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/lagomorph_hip.h but not exported: {missing}"
-    assert lib.lago_abi_version() == lagomorph_amd.lagomorph_ext.ABI_VERSION == 4
+    assert lib.lago_abi_version() == lagomorph_amd.lagomorph_ext.ABI_VERSION == 5
     lib.lago_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.lago_version()
 
