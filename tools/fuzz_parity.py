@@ -133,6 +133,9 @@ def run(budget=120.0, seed=0):
                 try:
                     close("sharp", met.sharp(dev(mm)), orc.fluid_metric_apply(mm, pr, True), ft)
                     close("flat", met.flat(dev(mm)), orc.fluid_metric_apply(mm, pr, False), ft)
+                    sc = float(rng.choice([-0.1, -0.5, 1.0 / 3.0, 2.5]))   # the operator with an output factor: the bits of a multiply
+                    if not torch.equal(met.sharp(dev(mm), out_scale=sc), met.sharp(dev(mm)) * sc):
+                        raise SystemExit(f"case {n}: sharp(out_scale={sc}) differs from sharp * {sc} at {fs} {dt_np}")
                 except RuntimeError as e:   # fluid_mode < 3 may select rocFFT, whose guard fails LOUDLY on a wrong transform
                     if "rocFFT returned a WRONG" not in str(e):
                         raise
