@@ -725,7 +725,7 @@ def main():
                 del hg, z
         finally:
             _lddmm.EXPMAP_STREAMS = default_streams
-        split_active = default_streams >= 2 and B >= 2 * default_streams
+        split_active = default_streams >= 2 and B // _lddmm.EXPMAP_MIN_ITEMS >= default_streams   # (lddmm._shoot_forward_split)
         del h
     elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
     if world > 1:

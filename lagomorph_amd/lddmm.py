@@ -118,16 +118,17 @@ def _shoot(metric, m0, phiinv, dt, num_steps, v0, keep, out=None):
     return phi, steps, first
 
 
-# A forward-only shoot (no gradient wanted) of at least 2 * EXPMAP_STREAMS batch items is cut into EXPMAP_STREAMS
-# contiguous sub-batches that run on HIP streams of their own: batch items are independent, and the tail of one part's
+# A forward-only shoot (no gradient wanted) of at least EXPMAP_MIN_ITEMS * EXPMAP_STREAMS batch items is cut into
+# EXPMAP_STREAMS contiguous sub-batches (fewer when the batch does not have that many items) that run on HIP streams of their own: batch items are independent, and the tail of one part's
 # kernel (the last workgroups of a launch leave most CUs idle) then overlaps with the head of another part's next
 # kernel.  Measured (tools/ab_streams.py, profiles/r04_stream_split.md): 22.28 -> 21.66 ms at 32 x 128^3, 5.84 -> 5.55
 # at 8 x 128^3; the driver's round-4 run 21.32 -> 21.14 ms; same bits (tests/test_gpu_lddmm_step.py:
-# test_expmap_stream_split_same_bits).  ON by default since round 5 (2 parts, i.e. batches of 4 and more; smaller ones
+# test_expmap_stream_split_same_bits).  ON by default since round 5 (2 parts, i.e. batches of 2 and more; single items
 # and every shoot that keeps its steps for a backward pass run on the caller's stream alone); `EXPMAP_STREAMS = 1`
 # switches it off -- bench.py does so for the pass it takes its per-kernel roofline from, because with two parts in
 # flight a launch's duration is no longer the time the kernel needs by itself.
 EXPMAP_STREAMS = 2
+EXPMAP_MIN_ITEMS = 1   # batch items a part must have (1: a batch of two shoots as 1 + 1: 1.61-1.71 -> 1.52-1.56 ms at 128^3)
 _side_streams = {}
 
 
@@ -142,7 +143,8 @@ def _shoot_forward_split(metric, m0, phiinv, dt, num_steps, v0):
     """`_shoot(..., keep=False)` over sub-batches on side streams; None when the split does not apply."""
     parts = EXPMAP_STREAMS
     B = m0.size(0)
-    if parts < 2 or B < 2 * parts or not m0.is_cuda or num_steps < 2:
+    parts = min(parts, B // EXPMAP_MIN_ITEMS)
+    if parts < 2 or not m0.is_cuda or num_steps < 2:
         return None
     m0 = m0.contiguous()
     phiinv = None if phiinv is None else phiinv.contiguous()

@@ -314,7 +314,7 @@ def test_lincomb(n, dtype):
         ext.lincomb([(1.0, xs[0]), (1.0, xs[1][:-1].contiguous())] if n > 1 else [])
 
 
-@pytest.mark.parametrize("sp,B", [((32, 32, 32), 5), ((24, 20, 28), 4), ((40, 36), 6)])
+@pytest.mark.parametrize("sp,B", [((32, 32, 32), 5), ((24, 20, 28), 4), ((40, 36), 6), ((32, 32, 64), 2), ((24, 20, 28), 3)])
 @pytest.mark.parametrize("from_identity", [True, False])
 def test_expmap_stream_split_same_bits(sp, B, from_identity):
     """`lddmm.EXPMAP_STREAMS = 2`: a forward-only shoot cut into two sub-batches on HIP streams of their own (uneven
@@ -338,7 +338,7 @@ def test_expmap_stream_split_same_bits(sp, B, from_identity):
             lddmm.EXPMAP_STREAMS = 2
             two = [lm.expmap(met, m0, num_steps=4, phiinv=p0) for _ in range(3)]
             lddmm.EXPMAP_STREAMS = 3
-            three = lm.expmap(met, m0, num_steps=4, phiinv=p0) if B >= 6 else one
+            three = lm.expmap(met, m0, num_steps=4, phiinv=p0)   # (as many parts as the batch has items, at most three)
         finally:
             lddmm.EXPMAP_STREAMS = default
     torch.cuda.synchronize()

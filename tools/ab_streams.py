@@ -18,13 +18,14 @@ dev = torch.device("cuda")
 torch.manual_seed(1234)
 met = lm.FluidMetric([0.1, 0.0, 0.01])
 default = lddmm.EXPMAP_STREAMS
+lddmm.EXPMAP_MIN_ITEMS = int(os.environ.get("MINPER", lddmm.EXPMAP_MIN_ITEMS))
 with torch.no_grad():
     m = gaussian_blur(torch.randn((B, 3, S, S, S), device=dev), 4.0)
     m *= 5.0 / met.sharp(m).abs().max()
     lddmm.EXPMAP_STREAMS = 1
     ref = lm.expmap(met, m, num_steps=10)
     for parts in (1, 2, 3, 4, 1, 2, 3, 4):
-        if B < 2 * parts:
+        if B < lddmm.EXPMAP_MIN_ITEMS * parts:
             continue
         lddmm.EXPMAP_STREAMS = parts
         for _ in range(4):
