@@ -111,9 +111,7 @@ class FluidMetric(object):
 
     def operator(self, mv, inverse, out_scale=1.0):
         self.initialize_luts(shape=mv.shape, dtype=mv.dtype, device=mv.device)
-        if out_scale != 1.0:
-            return FluidMetricOperator.apply(self.params, self.luts, inverse, mv, float(out_scale))
-        return FluidMetricOperator.apply(self.params, self.luts, inverse, mv)
+        return FluidMetricOperator.apply(self.params, self.luts, inverse, mv, float(out_scale))
 
     def sharp(self, m, out_scale=1.0):
         """momentum -> velocity (apply the Green's function).  `out_scale` (not in the reference): a factor on the
