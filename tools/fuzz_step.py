@@ -12,6 +12,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch
 
@@ -95,25 +96,34 @@ def run(budget=120.0, seed=0):
         if msg is not None:
             # The gradient of trilinear interpolation with respect to the sample position JUMPS at the faces of the
             # grid cells (include/interp.h:207-327 takes one-sided differences of the cell the floor selects).  A sample
-            # that sits on a face to within float32 rounding picks its cell by the last bit of a position that went
-            # through several FFTs: HIP float32, the oracle's float32 and float64 may land on different sides, and the
-            # one-voxel jump (smeared over a plane by the smoothing operator) exceeds any bound.  That is a property of
-            # the operator at a measure-zero set of inputs (typically a voxel where a displacement component crosses zero,
-            # so that the sample sits on its own grid point), not of an implementation: the same case with a smooth
-            # perturbation of 1e-3 of the momenta's size added must pass, three times out of three, or the mismatch is
-            # reported.
-            pert = [m + 1e-3 * float(m.abs().max()) * torch.from_numpy(smooth_np(rng, tuple(m.shape), 1.5)).to(dtype) for _ in range(3)]
-            again = [check(q.contiguous(), False) for q in pert]
-            if any(a is not None for a in again):
+            # that sits on a face to within float32 rounding -- typically a voxel where a displacement component
+            # crosses zero, so that x + h rounds to x in float32 and lies a hair below it in float64 -- picks its cell
+            # by the last bit of a position that went through several FFTs: HIP float32, the oracle's float32 and float64
+            # may land on different sides, and the one-voxel jump (smeared over a plane by the smoothing operator; the
+            # coarser the momentum grid, the larger its share) exceeds any bound.  A property of the operator on a
+            # measure-zero set of inputs, not of an implementation -- and one that can be PROVED per case
+            # (tools/debug_step_event.py): the float32 step is re-run with the position gradient of exactly the
+            # outlier voxels whose sample lies within 2 float32 ulps of a cell face taken from the float64 run; the
+            # case counts as a cell-face event iff there is no outlier voxel off a face and the patched step is within
+            # the bound.  Anything else is reported as a mismatch.
+            if os.environ.get("LAGO_FUZZ_DUMP_EVENTS"):   # every first-check failure, for tools/debug_step_event.py
+                np.savez(os.path.join(os.environ["LAGO_FUZZ_DUMP_EVENTS"], f"event_{seed}_{n}.npz"), base=base.numpy(), imgs=imgs.numpy(),
+                         m=m.numpy(), steps=steps, reg_weight=kw["reg_weight"], precond=precond, parts=parts, B=B)
+            ev = None
+            if dtype == torch.float32:
+                from debug_step_event import analyse
+
+                ev = analyse(base, imgs, m, B, kw)
+            if ev is None or ev["on_face"] == 0 or ev["off_face"] > 0 or max(ev["after"].values()) > tol:
                 if os.environ.get("LAGO_FUZZ_DUMP"):
                     np.savez(os.environ["LAGO_FUZZ_DUMP"], base=base.numpy(), imgs=imgs.numpy(), m=m.numpy(), steps=steps,
                              reg_weight=kw["reg_weight"], precond=precond, parts=parts, B=B)
-                raise SystemExit(f"MISMATCH {msg}; also after perturbation: {again}; case {n}: sp {sp} msp {msp} B {B} steps {steps} "
+                raise SystemExit(f"MISMATCH {msg}; cell-face analysis: {ev}; case {n}: sp {sp} msp {msp} B {B} steps {steps} "
                                  f"precond {precond} parts {parts} {dtype}")
-            flips.append((n, msg))
+            flips.append((n, msg, f"{ev['on_face']} on-face voxels; patched: {max(ev['after'].values()):.2e}"))
     yard = yard[0]
     if flips:
-        print(f"cell-face events (a sample within float32 rounding of a cell face; pass under a 1e-3 perturbation of the momenta): {len(flips)}: {flips[:4]}")
+        print(f"cell-face events (every outlier of the position gradient within 2 float32 ulps of a cell face; within the bound once those voxels take the float64 run's values): {len(flips)}: {flips[:4]}")
     return n, worst, yard
 
 
