@@ -16,9 +16,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# LAGO_ORACLE_BUILD: another build of the same sources (oracle/Makefile `asan`: AddressSanitizer + UBSan, `make -C oracle
+# check-asan` runs the CPU suite on it)
+_BUILD = os.environ.get("LAGO_ORACLE_BUILD") or os.path.join(_HERE, "_build")
 _LIB_PATHS = {
-    False: os.path.join(_HERE, "_build", "liblago_oracle.so"),        # documented FMA contraction (matches HIP)
-    True: os.path.join(_HERE, "_build", "liblago_oracle_strict.so"),  # unfused a*b+c (matches oracle/_ref)
+    False: os.path.join(_BUILD, "liblago_oracle.so"),        # documented FMA contraction (matches HIP)
+    True: os.path.join(_BUILD, "liblago_oracle_strict.so"),  # unfused a*b+c (matches oracle/_ref)
 }
 _libs = {}
 _strict = False
