@@ -5,7 +5,7 @@ Ad_star, affine forward and regrid forward BIT FOR BIT against the oracle, the f
 scatter-adds (d_I, d_A, d_T, regrid backward) at north_star's bound or, where thousands of float32 terms pile onto one
 border cell or cancel, by the float32 summation bound against the float64 oracle; every third case under a random
 combination of the library's sibling implementations.  The long form (`python tools/fuzz_parity.py 150 <seed>`: 6 000 - 9 000 cases per
-run; `LAGO_FUZZ_BIG=1` for volumes of up to 2 M voxels) found no mismatch in over 100 000 cases (profiles/r05_fuzz.md)."""
+run; `LAGO_FUZZ_BIG=1` for volumes of up to 2 M voxels) found no mismatch in over 109 000 cases (profiles/r05_fuzz.md)."""
 import os
 import sys
 
@@ -30,7 +30,7 @@ def test_random_cases_against_the_oracle(seed):
 def test_random_matching_steps_against_the_oracle_backend():
     """tools/fuzz_step.py, short form: random `lddmm_step` problems (2D / 3D, multiscale momenta, 1-4 integration steps,
     preconditioning, 1-6 subjects, the stream-split option, both dtypes) through HIP against the oracle backend.  The
-    long form ran 16 926 steps without a mismatch (profiles/r05_fuzz.md, incl. the thirteen cell-face events, each proved on its own case by tools/debug_step_event.py)."""
+    long form ran 19 226 steps without a mismatch (profiles/r05_fuzz.md, incl. the fourteen cell-face events, each proved on its own case by tools/debug_step_event.py)."""
     import fuzz_step
 
     try:
