@@ -145,6 +145,13 @@ def micro_interp_splat(ext, dev, size, batch=8):
         r["pair_GBps"] = 56.0 * V / pair / 1e6
         r["pair_frac_of_hbm_peak"] = r["pair_GBps"] / HBM_PEAK_GBPS
         r["pair_Gvoxel_per_s"] = V / pair / 1e6
+        if label == "smooth":   # north_star's target for this pair, stated on the line
+            r["target_frac"] = 0.60
+            r["met"] = bool(r["pair_frac_of_hbm_peak"] >= 0.60)
+            r["floor_of_scheme"] = 0.55
+            r["floor_source"] = "profiles/r05_colour_flush.md"
+            r["fwd_frac_of_hbm_peak"] = r["fwd_GBps"] / HBM_PEAK_GBPS
+            r["bwd_frac_of_hbm_peak"] = r["bwd_lds_GBps"] / HBM_PEAK_GBPS
         res[label] = r
     # HBM bytes per launch of the two kernels from the PMC passes over tools/run_micro.py (same workload, same batch)
     tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_traffic_micro.json", "r04_traffic_micro.json", "r03_traffic_micro.json", "r02_traffic_micro.json"))
@@ -275,11 +282,14 @@ def lddmm_step_alg_bytes_per_voxel(steps):
     return (steps - 1) * (144.8 + 192.8) + 84 + 16 + 28 + 8 + 12 + 2 * 72.8 + 24 + 36
 
 
-def atlas_leg(lm, dev, world, rank, args):
+def atlas_leg(lm, dev, world, rank, args, force_dist=False):
     """BASELINE configs[4]: the batched atlas step at `args.atlas_size`^3, global minibatch `args.atlas_batch`
     split over the ranks, one all-reduce of the atlas gradient per image update (image_update_freq = 0:
     every iteration, lddmm.py:287-298).  Timed exactly like the headline: barrier + synchronize on both sides,
-    max over ranks.  Learning rates are small so that every timed step sees a comparable state."""
+    max over ranks.  Learning rates are small so that every timed step sees a comparable state.
+    `force_dist` (N = 1 with a world-size-1 RCCL process group): the builder takes every branch of the N-rank code --
+    the asynchronous all-reduce from the gradient hook, the wait before the image update -- over RCCL on this one GPU."""
+    coll = world > 1 or force_dist
     S, GB = args.atlas_size, args.atlas_batch
     if GB % world:
         raise SystemExit(f"bench.py: --atlas-batch {GB} is not divisible by {world} ranks")
@@ -301,7 +311,7 @@ def atlas_leg(lm, dev, world, rank, args):
         del subj
     builder = lm.LDDMMAtlasBuilder(images, batch_size=B, lddmm_integration_steps=5, reg_weight=1e2,
                                    learning_rate_pose=1e-3, learning_rate_image=1e-2, world_size=world, rank=rank,
-                                   dataset_size=GB * iters)
+                                   dataset_size=GB * iters, force_collectives=force_dist)
     # momenta that shoot to ~3 voxels, so that the gathers and splats see a realistic displacement
     with torch.no_grad():
         for b in range(len(builder.ms)):
@@ -312,7 +322,7 @@ def atlas_leg(lm, dev, world, rank, args):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -324,13 +334,13 @@ def atlas_leg(lm, dev, world, rank, args):
         builder.iteration(b)
     sync()
     T = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
+    if coll:
         dist.all_reduce(T, op=dist.ReduceOp.MAX)
     T = T.item()
     # the same iterations again with the all-reduce BLOCKING behind the whole backward pass (the reference's placement,
     # lddmm.py:287-298) instead of asynchronous from the gradient hook: what the overlap hides shows as the difference
     T_block = None
-    if world > 1:
+    if coll:
         builder.overlap_allreduce = False
         sync()
         t0 = time.perf_counter()
@@ -341,9 +351,21 @@ def atlas_leg(lm, dev, world, rank, args):
         dist.all_reduce(Tb, op=dist.ReduceOp.MAX)
         T_block = Tb.item()
         builder.overlap_allreduce = True
+    # at one rank with forced collectives: the same iterations once more with the collectives switched off (the plain
+    # single-process builder), i.e. what the RCCL plumbing itself costs per step
+    T_plain = None
+    if force_dist and world == 1:
+        builder.collectives = False
+        sync()
+        t0 = time.perf_counter()
+        for b in range(args.atlas_warmup, iters):
+            builder.iteration(b)
+        torch.cuda.synchronize()
+        T_plain = time.perf_counter() - t0
+        builder.collectives = True
     # the collective on its own: a blocking all-reduce of one (1, 1, S, S, S) fp32 gradient
     ar_ms = None
-    if world > 1:
+    if coll:
         buf = torch.zeros((1, 1, S, S, S), device=dev)
         for _ in range(3):
             dist.all_reduce(buf)
@@ -368,16 +390,97 @@ def atlas_leg(lm, dev, world, rank, args):
                     f"gradient, image update), {S}^3 fp32, global minibatch {GB} = {B} per GPU x {world}, 5 integration "
                     f"steps (BASELINE configs[4])",
         "value": vox / T, "unit": "voxels/s", "ms_per_step": 1e3 * T / args.atlas_steps, "steps": args.atlas_steps,
-        "warmup": args.atlas_warmup, "n_ranks": world, "backend": dist.get_backend() if world > 1 else None,
+        "warmup": args.atlas_warmup, "n_ranks": world, "backend": dist.get_backend() if coll else None,
         "global_batch": GB, "per_gpu_batch": B, "scaling": "strong",
-        "collective": "RCCL all_reduce(SUM) of I.grad, %.1f MB fp32, issued from the backward pass" % (4 * S ** 3 / 1e6)
-                      if world > 1 else None,
+        "collective": ("%s all_reduce(SUM) of I.grad, %.1f MB fp32, issued asynchronously from the backward pass"
+                       % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(), 4 * S ** 3 / 1e6)) if coll else None,
+        "forced_collectives_at_world_size_1": bool(force_dist and world == 1),
+        "note": ("world size 1: every collective of the N-rank builder is issued through ProcessGroupNCCL (its own stream, "
+                 "work.wait() = stream wait); an in-place SUM over one rank moves no data, so allreduce_ms is the call's "
+                 "cost, not a bandwidth figure") if force_dist and world == 1 else None,
+        "ms_per_step_without_collectives": None if T_plain is None else 1e3 * T_plain / args.atlas_steps,
         "allreduce_ms": ar_ms,
         "ms_per_step_blocking_allreduce": None if T_block is None else 1e3 * T_block / args.atlas_steps,
         "allreduce_hidden_ms_per_step": None if T_block is None else 1e3 * (T_block - T) / args.atlas_steps,
         "alg_bytes_per_voxel": bpv, "achieved_GBps": gbps,
         "frac_of_hbm_peak": gbps / (HBM_PEAK_GBPS * world), "finite": finite,
     }
+
+
+def atlas_epoch_leg(lm, dev, world, rank, args, force_dist=False):
+    """BASELINE configs[4] as the workload it names: `args.epoch_subjects` (256) synthetic `args.atlas_size`^3 (160^3)
+    subjects resident in HBM with their momenta (4.2 GB + 12.6 GB at one rank), sharded over the ranks, global minibatch
+    `args.atlas_batch` (32), and one `LDDMMAtlasBuilder.epoch()` (lddmm.py:343-362): every minibatch's matching step and
+    image update (image_update_freq 0, lddmm.py:287-298), the forced end-of-epoch update (:359) and the reduction of the
+    per-iteration (loss, reg) history (:333-335).  One warm-up epoch, one timed epoch between synchronised barriers,
+    max over ranks."""
+    coll = world > 1 or force_dist
+    S, GB, NS = args.atlas_size, args.atlas_batch, args.epoch_subjects
+    if GB % world or NS % GB:
+        raise SystemExit(f"bench.py: --epoch-subjects {NS} / --atlas-batch {GB} do not split over {world} ranks")
+    B, nb = GB // world, NS // GB
+    torch.cuda.reset_peak_memory_stats(dev)
+    g = torch.Generator(device=dev).manual_seed(777)  # the template is the same on every rank
+    tmpl = gaussian_blur(torch.randn((1, 1, S, S, S), device=dev, generator=g), 3.0)
+    tmpl = tmpl / tmpl.std()
+    g = torch.Generator(device=dev).manual_seed(8765 + rank)
+    images = torch.empty((nb * B, 1, S, S, S), device=dev)
+    with torch.no_grad():
+        for b in range(nb):  # this rank's shard: template o (id + smooth u) + noise
+            u = gaussian_blur(torch.randn((B, 3, S, S, S), device=dev, generator=g), 8.0)
+            u *= 3.0 / u.abs().max()
+            images[b * B:(b + 1) * B] = lm.interp(tmpl, u) + 0.05 * torch.randn((B, 1, S, S, S), device=dev, generator=g)
+            del u
+    builder = lm.LDDMMAtlasBuilder(images, batch_size=B, lddmm_integration_steps=5, reg_weight=1e2,
+                                   learning_rate_pose=1e-3, learning_rate_image=1e-2, world_size=world, rank=rank,
+                                   dataset_size=NS, force_collectives=force_dist)
+    with torch.no_grad():  # momenta that shoot to ~3 voxels, so that the gathers and splats see a realistic displacement
+        for b in range(len(builder.ms)):
+            m = gaussian_blur(torch.randn(builder.ms[b].shape, device=dev, generator=g), 4.0)
+            m *= 3.0 / builder.metric.sharp(m).abs().max()
+            builder.ms[b] = m
+            del m
+    torch.cuda.empty_cache()
+
+    def sync():
+        torch.cuda.synchronize()
+        if coll:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    builder.image_optimizer.zero_grad()
+    builder.epoch()   # warm-up
+    sync()
+    t0 = time.perf_counter()
+    loss, reg = builder.epoch()
+    sync()
+    T = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if coll:
+        dist.all_reduce(T, op=dist.ReduceOp.MAX)
+    T = T.item()
+    peak = torch.cuda.max_memory_allocated(dev)
+    reserved = torch.cuda.max_memory_reserved(dev)
+    builder._flush_history()
+    finite = bool(torch.isfinite(builder.I).all().item()) and all(x == x for x in builder.iter_losses)
+    vox = NS * S ** 3
+    bpv = lddmm_step_alg_bytes_per_voxel(5)
+    gbps = bpv * vox / T / 1e9
+    out = {
+        "workload": f"LDDMMAtlasBuilder.epoch(): {NS} synthetic subjects of {S}^3 fp32 resident in HBM with their momenta, "
+                    f"global minibatch {GB} = {B} per GPU x {world}, {nb} minibatches per epoch, 5 integration steps, image "
+                    "update (with its all-reduce when there are collectives) after every minibatch, forced end-of-epoch "
+                    "update, history reduction (BASELINE configs[4], lagomorph/lddmm.py:343-362)",
+        "ms_per_epoch": 1e3 * T, "value": vox / T, "unit": "voxels/s", "subjects": NS, "minibatches": nb,
+        "ms_per_minibatch": 1e3 * T / nb, "n_ranks": world, "backend": dist.get_backend() if coll else None,
+        "forced_collectives_at_world_size_1": bool(force_dist and world == 1),
+        "alg_bytes_per_voxel": bpv, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / (HBM_PEAK_GBPS * world),
+        "resident_GB": {"images": images.numel() * 4 / 1e9, "momenta": sum(m.numel() for m in builder.ms) * 4 / 1e9},
+        "peak_allocated_GB": peak / 1e9, "peak_reserved_GB": reserved / 1e9,
+        "epoch_loss": float(loss), "epoch_reg_term": float(reg), "finite": finite, "scaling": "strong",
+    }
+    del builder, images
+    torch.cuda.empty_cache()
+    return out
 
 
 def reference_cpu_path(lm, dev, size):
@@ -591,6 +694,8 @@ def parse_args():
     ap.add_argument("--atlas-batch", type=int, default=32, help="subjects per atlas update over ALL GPUs")
     ap.add_argument("--atlas-steps", type=int, default=4)
     ap.add_argument("--atlas-warmup", type=int, default=1)
+    ap.add_argument("--epoch-subjects", type=int, default=256, help="subjects of the atlas_epoch leg over ALL GPUs (configs[4]: 256)")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the atlas_epoch leg")
     ap.add_argument("--cpu-sample-batch", type=int, default=16,
                     help="volumes in the all-cores CPU baseline sample (the one-thread sample is a quarter of it)")
     return ap.parse_args()
@@ -620,6 +725,53 @@ def spawn_workers(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+# At N = 1 the atlas legs run the N-rank code over a world-size-1 RCCL process group created in this process (VERDICT r5
+# item 1): init_process_group("nccl") as lagomorph/utils.py:161-166 does, every collective of LDDMMAtlasBuilder issued
+# through ProcessGroupNCCL.  LAGO_BENCH_FORCE_DIST=0 switches it off (the atlas legs then run without a process group).
+FORCE_DIST = os.environ.get("LAGO_BENCH_FORCE_DIST", "1") != "0"
+
+_RCCL_PROBE = r"""
+import socket, sys, torch, torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+t = torch.ones(1 << 20, device=dev)
+w = dist.all_reduce(t, async_op=True); w.wait()
+torch.cuda.synchronize()
+assert float(t.sum()) == float(1 << 20)
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+"""
+
+
+def rccl_world1_probe(timeout=180):
+    """Can a world-size-1 RCCL process group be created and used on this box?  Asked of a CHILD process with a time
+    limit, before this process touches the GPU: a communicator that hangs in its set-up then costs the atlas legs their
+    RCCL variant, not the whole benchmark line.  Returns (ok, detail)."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        r = subprocess.run([sys.executable, "-c", _RCCL_PROBE], capture_output=True, text=True, timeout=timeout, env=env)
+    except subprocess.TimeoutExpired:
+        return False, f"probe timed out after {timeout} s"
+    if r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout:
+        return True, "ok"
+    return False, (r.stderr or r.stdout).strip()[-400:]
+
+
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -633,6 +785,9 @@ def main():
                          "number of ranks")
     if args.batch % world:
         raise SystemExit(f"bench.py: --batch {args.batch} is not divisible by {world} ranks")
+    force_dist, force_dist_detail = False, None
+    if world == 1 and FORCE_DIST and not (args.no_atlas and args.no_epoch):
+        force_dist, force_dist_detail = rccl_world1_probe()   # (a child process; nothing here has touched the GPU yet)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     ensure_built(local_rank)
@@ -645,6 +800,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif force_dist:
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
+        except Exception as e:
+            force_dist, force_dist_detail = False, repr(e)
 
     import lagomorph_amd as lm
 
@@ -668,7 +828,7 @@ def main():
         if args.streams > 0:
             _lddmm.EXPMAP_STREAMS = args.streams
         default_streams = _lddmm.EXPMAP_STREAMS
-        # TIMED REGION: the product's default path -- a forward-only shoot of 4+ batch items is cut into two sub-batches
+        # TIMED REGION: the product's default path -- a forward-only shoot of 2+ batch items is cut into two sub-batches
         # on HIP streams of their own (lddmm.EXPMAP_STREAMS = 2, bit-identical to one stream).  HIP events of the
         # wrapped entry points are recorded on the stream each call is launched on; with two parts in flight they
         # measure a kernel BESIDE the other part's kernels (reported as breakdown_ms_per_step, not as a roofline).
@@ -753,7 +913,8 @@ def main():
                         "first Euler step is evaluated in closed form (-dt sharp(m0): the bits EPDiff_step returns); "
                         + (f"the product's default path: each rank's shoot runs as {default_streams} sub-batches on HIP "
                            "streams of their own (lddmm.EXPMAP_STREAMS, bit-identical)" if split_active else
-                           "one HIP stream (the sub-batch split needs 4+ items per rank)"),
+                           f"one HIP stream (the sub-batch split needs {max(2, 2 * _lddmm.EXPMAP_MIN_ITEMS)}+ items per rank "
+                           "and lddmm.EXPMAP_STREAMS >= 2)"),
             "streams": default_streams if split_active else 1,
             "single_stream": {"ms_per_step": 1e3 * t_single, "same_bits": single_bits,
                               "note": "the same shoots with lddmm.EXPMAP_STREAMS = 1, after the timed region: the pass "
@@ -768,12 +929,18 @@ def main():
     }
     del m
     torch.cuda.empty_cache()
-    atlas = None
+    atlas, epoch = None, None
     if not args.no_atlas:
-        atlas = atlas_leg(lm, dev, world, rank, args)
+        atlas = atlas_leg(lm, dev, world, rank, args, force_dist=force_dist)
+    if not args.no_epoch:
+        epoch = atlas_epoch_leg(lm, dev, world, rank, args, force_dist=force_dist)
     if rank == 0:
         if atlas is not None:
             result["atlas_step"] = atlas
+        if epoch is not None:
+            result["atlas_epoch"] = epoch
+        if world == 1:
+            result["rccl_world_size_1"] = {"requested": FORCE_DIST, "active": force_dist, "detail": force_dist_detail}
         # the dominant single kernel of the timed region (fluid_metric is three kernels and is reported
         # separately): all four candidates move 36 algorithmic bytes per voxel at C = 3
         cands = {
@@ -811,7 +978,7 @@ def main():
                 # sub-batch and runs BESIDE the other stream's kernels, so its duration is an upper bound of its own time
                 "timed_region": None if op not in ksum_timed else {
                     "mean_launch_ms": ksum_timed[op]["mean_ms"], "launches": ksum_timed[op]["launches"],
-                    "bytes_per_launch": bytes_per_launch / (default_streams if split_active else 1),
+                    "bytes_per_launch": bytes_per_launch / (default_streams if split_active else 1),   # (mean over the parts: exact for even per-rank batches)
                     "frac": bytes_per_launch / (default_streams if split_active else 1) / (ksum_timed[op]["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "streams": default_streams if split_active else 1},
                 "others": {n: {"mean_launch_ms": present[n]["mean_ms"],
@@ -844,7 +1011,7 @@ def main():
         if SHARE_GPU:
             result["debug_shared_gpu"] = "LAGO_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo -- a plumbing check, NOT a measurement"
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

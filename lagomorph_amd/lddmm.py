@@ -467,7 +467,7 @@ class LDDMMAtlasBuilder:
     def __init__(self, images, batch_size=8, lddmm_steps=1, lddmm_integration_steps=5, image_update_freq=0,
                  reg_weight=1e2, learning_rate_pose=2e2, learning_rate_image=1e4, metric=None, momentum_shape=None,
                  image_shape=None, momentum_preconditioning=False, I0=None, ms=None, world_size=1, rank=0,
-                 dataset_size=None, checkpoint_format=None, overlap_allreduce=True):
+                 dataset_size=None, checkpoint_format=None, overlap_allreduce=True, force_collectives=False):
         self.images = images  # this rank's shard: (n_local, 1, *sp) on the device
         self.batch_size = batch_size
         self.lddmm_steps = lddmm_steps
@@ -482,6 +482,11 @@ class LDDMMAtlasBuilder:
         self.rank = rank
         self.checkpoint_format = checkpoint_format
         self.overlap_allreduce = overlap_allreduce
+        # the collectives of lddmm.py:196-198,292-297,333-335 are issued when there is more than one rank -- or when
+        # `force_collectives` asks for them at world size 1 (a process group must exist): every branch of the N-rank
+        # code then runs, over RCCL, on a single GPU (tests/test_gpu_rccl_world1.py, bench.py's `atlas_step_rccl`)
+        self.collectives = world_size > 1 or bool(force_collectives)
+        self.grad_reduce_op = dist.ReduceOp.SUM   # lddmm.py:294 (the tests put a non-identity operator here at world size 1)
         n_local = images.shape[0]
         self.dataset_size = dataset_size if dataset_size is not None else n_local * world_size
         dim = images.dim() - 2
@@ -491,7 +496,7 @@ class LDDMMAtlasBuilder:
         with torch.no_grad():
             if I0 is None:
                 I0 = streaming_batch_average(images, batch_size).unsqueeze(0)
-                if world_size > 1:
+                if self.collectives:
                     dist.all_reduce(I0)
                     I0 /= world_size
             else:
@@ -543,8 +548,8 @@ class LDDMMAtlasBuilder:
 
     def _on_image_grad(self, param):
         """Runs inside the backward pass right after `I.grad` received the splat of this minibatch."""
-        if self._reduce_now and self.world_size > 1 and self._work is None:
-            self._work = dist.all_reduce(param.grad, async_op=True)
+        if self._reduce_now and self.collectives and self._work is None:
+            self._work = dist.all_reduce(param.grad, op=self.grad_reduce_op, async_op=True)
 
     def _will_update(self, last_of_epoch):
         # the decision update_base_image() is going to take after this iteration (lddmm.py:287-291)
@@ -555,12 +560,12 @@ class LDDMMAtlasBuilder:
         if (self.image_iters < self.image_update_freq and not force) or self.image_iters == 0:
             return
         with torch.no_grad():
-            if self.world_size > 1:
+            if self.collectives:
                 if self._work is not None:
                     self._work.wait()
                     self._work = None
                 else:
-                    dist.all_reduce(self.I.grad)
+                    dist.all_reduce(self.I.grad, op=self.grad_reduce_op)
             self.I.grad = self.I.grad / (self.image_iters * self.world_size)
             self.image_optimizer.step()
             self.image_optimizer.zero_grad()
@@ -600,7 +605,7 @@ class LDDMMAtlasBuilder:
             hist[b, 0] = loss
             hist[b, 1] = reg
         self.update_base_image(force=True)
-        if self.world_size > 1:
+        if self.collectives:
             dist.all_reduce(hist)
         self._pending_hist.append(hist[:nb])
         tot = hist[:nb].sum(dim=0)
