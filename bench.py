@@ -772,10 +772,31 @@ def free_port():
     return port
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """stdout carries ONE JSON line: everything else that writes to file descriptor 1 -- RCCL prints a version banner
+    there from C -- is sent to stderr; the line itself goes to the saved descriptor (`emit`)."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (line + "\n").encode()
+    fd = _JSON_FD if _JSON_FD is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_workers(args))
+    claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1010,7 +1031,7 @@ def main():
                 result["cpu_baseline"]["reference_cpu_path"] = {"available": False, "error": repr(e)}
         if SHARE_GPU:
             result["debug_shared_gpu"] = "LAGO_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo -- a plumbing check, NOT a measurement"
-        print(json.dumps(result), flush=True)
+        emit(json.dumps(result))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -7,9 +7,15 @@ history reduction.  What a single GPU can prove of SURVEY 8(e): ProcessGroupNCCL
 stream, wait = stream wait, allocator bookkeeping), which gloo's host-synchronous collectives never exercised.
 
 Two kinds of check:
-  * SUM at world size 1 is the identity, so the run must reproduce the non-distributed builder.  Float atomics make no two
-    runs of ONE builder agree bit for bit, so the yardstick is a repeat of the plain run: the collective
-    run may be no further from the plain run than three times that repeat (plus one ulp-scale floor); in float64 1e-12.
+  * SUM at world size 1 is the identity, so the run must reproduce the non-distributed builder: to 1e-11 in float64.
+    In float32 no two runs of ONE builder agree bit for bit (float atomics), and the spread is bimodal:
+    usually 6e-7, but about every other run of some configurations lands 4e-5 ... 1.5e-4 away, always by the same
+    amount, with or without the library's debug mode (a stream synchronisation after every launch) and never in float64
+    (profiles/r06_rccl_world1.md).  That is the algorithm, not a race: the gradient of trilinear interpolation jumps
+    at cell boundaries (include/interp.h:207-327 picks the cell by floor), and a sample whose displacement sits at half
+    an ulp of its coordinate is rounded onto the grid point or just below it depending on the last bit of the
+    displacement -- forward or backward difference for that voxel.  The float32 bound is therefore 2e-3 (a wrong or
+    missing reduction is 2e-2 ... 3.5e-2 away, see the control below); a repeat of the plain run is printed beside it.
   * an ordering check with a reduction that is NOT the identity: RCCL's pre-multiplied sum (factor 2) on the atlas
     gradient.  At one rank RCCL then launches a real device kernel on ITS stream; the atlas must equal the plain builder
     run with twice the image learning rate (scaling by 2 is exact in binary floating point).  A missing or misplaced
@@ -146,29 +152,29 @@ def test_world1_rccl_builder_reproduces_plain_builder(rccl_world1, dtype, freq, 
     yard, d = _dist(again, plain), _dist(coll, plain)
     print(f"world-1 RCCL builder {dtype} freq {freq} overlap {overlap} step_streams {step_streams}: "
           f"collective-vs-plain {d:.3e}, plain repeat {yard:.3e}")
-    floor = 1e-12 if dtype == torch.float64 else 2e-7
-    assert d <= max(3.0 * yard, floor), (d, yard)
+    assert d <= (1e-11 if dtype == torch.float64 else 2e-3), (d, yard)
     assert float((plain.ms[0]).abs().max()) > 0 and len(plain.iter_losses) == 6
 
 
 @pytest.mark.parametrize("step_streams", [1, 2])
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("freq", [0, 2])
-def test_world1_rccl_premul_sum_orders_collective_before_update(rccl_world1, freq, overlap, step_streams):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_world1_rccl_premul_sum_orders_collective_before_update(rccl_world1, dtype, freq, overlap, step_streams):
     """The atlas gradient goes through a reduction that doubles it (a device kernel on RCCL's stream at one rank): the run
     must equal the plain builder with twice the image learning rate, and must NOT equal the plain builder itself."""
     import lagomorph_amd as lm
 
     try:
         op = dist._make_nccl_premul_sum(2.0)
-        t = torch.ones(1 << 20, device="cuda")
+        t = torch.ones(1 << 20, device="cuda", dtype=dtype)
         dist.all_reduce(t, op=op)
         torch.cuda.synchronize()
         ok = float(t[0]) == 2.0 and float(t[-1]) == 2.0
     except Exception as e:   # not offered by this RCCL / torch build
         pytest.skip(f"pre-multiplied sum not available: {e!r}")
     assert ok, "RCCL premul-sum at one rank did not scale its buffer"
-    data = _dataset(12, 64, torch.float32, seed=9)
+    data = _dataset(12, 64 if dtype == torch.float32 else 40, dtype, seed=9)
     prev = lm.lddmm.LDDMM_STEP_STREAMS
     lm.lddmm.LDDMM_STEP_STREAMS = step_streams
     try:
@@ -179,10 +185,10 @@ def test_world1_rccl_premul_sum_orders_collective_before_update(rccl_world1, fre
     finally:
         lm.lddmm.LDDMM_STEP_STREAMS = prev
     yard, d, off = _dist(again, want), _dist(coll, want), _dist(plain, want)
-    print(f"premul-sum(2) freq {freq} overlap {overlap} step_streams {step_streams}: vs doubled-lr {d:.3e} "
+    print(f"premul-sum(2) {dtype} freq {freq} overlap {overlap} step_streams {step_streams}: vs doubled-lr {d:.3e} "
           f"(repeat {yard:.3e}); the un-doubled run is {off:.3e} away")
-    assert off > 1e-3, off                      # the control: the factor matters at this learning rate
-    assert d <= max(3.0 * yard, 2e-7), (d, yard)
+    assert off > 1e-2, off                      # the control: the factor matters at this learning rate
+    assert d <= (1e-11 if dtype == torch.float64 else 2e-3), (d, yard)
 
 
 def test_world1_rccl_async_work_semantics(rccl_world1):
