@@ -566,28 +566,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
             }
             if (NEED_U) {
                 float gx, gy, gz;
-                if ((uint32_t)fx < (uint32_t)(nx - 1) && (uint32_t)fy < (uint32_t)(ny - 1)) {
-                    // rows unclamped: (fx,fy) (fx+1,fy) (fx+1,fy+1) (fx,fy+1); the z pair is fetched at
-                    // zb = clamp(fz, 0, nz-2) and picked as Lerp3 does (common.hpp): beyond the upper border both
-                    // corners are the pair's high half, below the lower border both are its low half
+                {
+                    // rows (fx,fy) (fx+1,fy) (fx+1,fy+1) (fx,fy+1), each clamped by itself as Lerp3::setup does (common.hpp) -- a
+                    // sample at a face of the volume is no special case (a lane that recomputed its position there stalled its
+                    // wave on three exposed memory round trips, profiles/r06_march_window.md); the z pair is fetched at
+                    // zb = clamp(fz, 0, nz-2) and picked as Lerp3 does: beyond the upper border both corners are the pair's
+                    // high half, below the lower border both are its low half
+                    const int cx0 = clamp1(fx, nx), cy0 = clamp1(fy, ny);
+                    const uint32_t dX = clamp1(fx + 1, nx) != cx0 ? gxB : 0u, dY = clamp1(fy + 1, ny) != cy0 ? gyB : 0u;
                     const int zb = lg_med3(fz, 0, nz - 2);
                     const bool f_hi = fz > nz - 2, c_lo = fz < 0;
-                    const uint32_t o = __umul24((uint32_t)fx, gxB) + __umul24((uint32_t)fy, gyB) + (uint32_t)zb * 4u;
+                    const uint32_t o = __umul24((uint32_t)cx0, gxB) + __umul24((uint32_t)cy0, gyB) + (uint32_t)zb * 4u;
                     float l0, l1, l2, l3, h0, h1, h2, h3;
-                    buf_load2s(rI, o, 0u, l0, h0);          // (the full-width-integer form: see common.hpp on the
-                    buf_load2s(rI, o, gxB, l1, h1);         //  hipcc narrowing of b64 buffer loads)
-                    buf_load2s(rI, o, gxB + gyB, l2, h2);
-                    buf_load2s(rI, o, gyB, l3, h3);
+                    buf_load2s(rI, o, 0u, l0, h0);
+                    buf_load2s(rI, o + dX, 0u, l1, h1);
+                    buf_load2s(rI, o + dX + dY, 0u, l2, h2);
+                    buf_load2s(rI, o + dY, 0u, l3, h3);
                     const float c0 = f_hi ? h0 : l0, c1 = f_hi ? h1 : l1, c2 = f_hi ? h2 : l2, c3 = f_hi ? h3 : l3;
                     const float c4 = c_lo ? l0 : h0, c5 = c_lo ? l1 : h1, c6 = c_lo ? l2 : h2, c7 = c_lo ? l3 : h3;
                     // include/interp.h:315-326
                     gx = lg_fma(omv, lg_fma(omu, c1 - c0, uu * (c2 - c3)), v * lg_fma(omu, c5 - c4, uu * (c6 - c7)));
                     gy = lg_fma(omv, lg_fma(omt, c3 - c0, t * (c2 - c1)), v * lg_fma(omt, c7 - c4, t * (c6 - c5)));
                     gz = lg_fma(omu, lg_fma(omt, c4 - c0, t * (c5 - c1)), uu * lg_fma(omt, c7 - c3, t * (c6 - c2)));
-                } else {
-                    Lerp3<float, false> Lq;
-                    Lq.setup(hx, hy, hz, nx, ny, nz);
-                    Lq.grad(Ic, gx, gy, gz);
                 }
                 // cuda/interp.cu:230: (Real)((double)diff * dt); for dt = +-1 that is +-diff exactly
                 const float diff = UNIT ? (float)dt * gv : (float)((double)gv * dt);
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) void splat
 // gather offset: about 150 of its 245 vector instructions per voxel-channel.  Here the tile is covered by at most
 // VPL = 2 passes of the 1024-thread workgroup and each lane keeps, per voxel, across the channel loop:
 //   the two LDS byte addresses of its footprint's z cells (or NOWIN), the gather byte offset with the two z-border
-//   flags in its low bits (or NOROW), the three fractions, the voxel index and the three d_u sums
+//   flags in its low bits (rows clamped one by one: no recomputing lane), the three fractions, the voxel index and the three d_u sums
 // -- 10 registers per voxel.  Per channel what is left is: one grad_out load, the eight sequentially flipped weights,
 // eight float64 LDS adds, four pair gathers, the gradient expressions.  Voxels whose footprint leaves the window or
 // whose rows are clamped (well under 1 % of a smooth field) recompute their position from u per channel and take the
@@ -745,11 +745,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
             A0[it] = __umul24(lx0, sxB) + __umul24(ly0, syB) + lz0 * 8u;
             A1[it] = __umul24(lx1, sxB) + __umul24(ly1, syB) + lz1 * 8u;
         }
-        if ((uint32_t)fx < (uint32_t)(nx - 1) && (uint32_t)fy < (uint32_t)(ny - 1)) {
-            // rows unclamped; the z pair is fetched at zb = clamp(fz, 0, nz-2) and picked as Lerp3 does (common.hpp)
+        {
+            // the four (x, y) rows of the footprint, each clamped by itself as Lerp3::setup does (common.hpp): base row
+            // (clamp fx, clamp fy) at zb = clamp(fz, 0, nz-2) with the two z-border flags in its low bits; whether the
+            // x + 1 / y + 1 rows coincide with it (a sample at or beyond a face) rides in the two top bits of A1
+            const int cx0 = clamp1(fx, nx), cy0 = clamp1(fy, ny);
             const int zb = lg_med3(fz, 0, nz - 2);
             const uint32_t f_hi = fz > nz - 2 ? 1u : 0u, c_lo = fz < 0 ? 2u : 0u;
-            OG[it] = (__umul24((uint32_t)fx, gxB) + __umul24((uint32_t)fy, gyB) + (uint32_t)zb * 4u) | f_hi | c_lo;
+            OG[it] = (__umul24((uint32_t)cx0, gxB) + __umul24((uint32_t)cy0, gyB) + (uint32_t)zb * 4u) | f_hi | c_lo;
+            A1[it] = (A1[it] & 0x3fffffffu) | (clamp1(fx + 1, nx) == cx0 ? 0x80000000u : 0u) | (clamp1(fy + 1, ny) == cy0 ? 0x40000000u : 0u);
         }
         if (umode == 1) {
             rux[it] = dun[sv]; ruy[it] = dun[sv + nv]; ruz[it] = dun[sv + 2 * (size_t)nv];
@@ -790,12 +794,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
             // (111 VGPRs instead of 64: one workgroup per CU)
             asm volatile("" : "+v"(A0[it]), "+v"(A1[it]), "+v"(OG[it]), "+v"(FT[it]), "+v"(FU[it]), "+v"(FV[it]), "+v"(SV[it]));
             unsigned long long pq[4];   // the four corner pairs: rows (fx,fy) (fx+1,fy) (fx+1,fy+1) (fx,fy+1)
+            const uint32_t dXv = (A1[it] & 0x80000000u) ? 0u : gxB, dYv = (A1[it] & 0x40000000u) ? 0u : gyB;
             {
-                const uint32_t o = OG[it] & ~3u;
+                const uint32_t o = OG[it] & ~3u;   // (a dead lane's 0xfffffffc reads 0 or a wrapped in-range cell: unused)
                 pq[0] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, 0u, 0));
-                pq[1] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, gxB, 0));
-                pq[2] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, gxB + gyB, 0));
-                pq[3] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o, gyB, 0));
+                pq[1] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o + dXv, 0u, 0));
+                pq[2] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o + dXv + dYv, 0u, 0));
+                pq[3] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rI, o + dYv, 0u, 0));
             }
             const uint32_t sv = SV[it];
             const float gv = gvs[it];
@@ -813,7 +818,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
                     if ((q & 3) == 3) ddx = 1.f - ddx;
                 }
             }
-            const uint32_t a0 = A0[it], a1 = A1[it];
+            const uint32_t a0 = A0[it], a1 = A1[it] & 0x3fffffffu;
             if (a0 != NOWIN) {
                 lds_add(reinterpret_cast<double *>(lago_smem + a0), (double)wq[0]);
                 lds_add(reinterpret_cast<double *>(lago_smem + a1), (double)wq[1]);
@@ -826,27 +831,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
             } else {
                 // beyond the window: the reference's clamped global atomics (include/interp.h:330-401, :431-453)
                 uint32_t X0, X1, Y0, Y1, Z0, Z1;
-                if (OG[it] != NOROW) {
-                    // rows unclamped: the cells follow from the gather offset (fx, fy, zb) and its z-border flags
+                {
+                    // the clamped cells follow from the gather offset (clamped fx, fy; zb), the row flags and the z-border flags
                     const uint32_t o = OG[it] & ~3u;
-                    X0 = o; X1 = o + gxB; Y0 = 0u; Y1 = gyB;
+                    X0 = o; X1 = o + dXv; Y0 = 0u; Y1 = dYv;
                     Z0 = (OG[it] & 1u) ? 4u : 0u;              // floor beyond the upper face: both cells are nz - 1 = zb + 1
                     Z1 = (OG[it] & 2u) ? 0u : 4u;              // floor below the lower face: both cells are 0 = zb
-                } else {
-                    uint32_t tt = threadIdx.x + (uint32_t)it * NT;
-                    // opaque: otherwise the coordinates of this rare path, converted to double, are hoisted out of the
-                    // channel loop and SPILLED by every lane (ten dwords: 335 MB of scratch writes per launch at 8 x 3 x 128^3)
-                    asm volatile("" : "+v"(tt));
-                    const uint32_t a = sg.d_TyTz.div(tt);
-                    const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
-                    const uint32_t b = sg.d_Tz.div(rr);
-                    const uint32_t kk = rr - b * (uint32_t)sg.TZ;
-                    const int fx = lg_floor(shear_pos<UNIT>(x0 + (int)a, dt, un[sv]));
-                    const int fy = lg_floor(shear_pos<UNIT>(y0 + (int)b, dt, un[sv + nv]));
-                    const int fz = lg_floor(shear_pos<UNIT>(z0 + (int)kk, dt, un[sv + 2 * (size_t)nv]));
-                    X0 = __umul24((uint32_t)clamp1(fx, nx), gxB); X1 = __umul24((uint32_t)clamp1(fx + 1, nx), gxB);
-                    Y0 = __umul24((uint32_t)clamp1(fy, ny), gyB); Y1 = __umul24((uint32_t)clamp1(fy + 1, ny), gyB);
-                    Z0 = (uint32_t)clamp1(fz, nz) * 4u; Z1 = (uint32_t)clamp1(fz + 1, nz) * 4u;
                 }
                 (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[0], rdI, X0 + Y0 + Z0, 0, 0);
                 (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wq[1], rdI, X0 + Y0 + Z1, 0, 0);
@@ -859,7 +849,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
             }
             const float t = FT[it], uu = FU[it], v = FV[it];
             float gx, gy, gz;
-            if (OG[it] != NOROW) {
+            {
                 const bool f_hi = OG[it] & 1u, c_lo = OG[it] & 2u;
                 auto lo = [](unsigned long long x) { return __builtin_bit_cast(float, (unsigned int)x); };
                 auto hi = [](unsigned long long x) { return __builtin_bit_cast(float, (unsigned int)(x >> 32)); };
@@ -871,17 +861,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_wave
                 gx = lg_fma(omv, lg_fma(omu, c1 - c0, uu * (c2 - c3)), v * lg_fma(omu, c5 - c4, uu * (c6 - c7)));
                 gy = lg_fma(omv, lg_fma(omt, c3 - c0, t * (c2 - c1)), v * lg_fma(omt, c7 - c4, t * (c6 - c5)));
                 gz = lg_fma(omu, lg_fma(omt, c4 - c0, t * (c5 - c1)), uu * lg_fma(omt, c7 - c3, t * (c6 - c2)));
-            } else {  // rows clamped (a sample outside the grid): position again, same expressions, same bits
-                uint32_t tt = threadIdx.x + (uint32_t)it * NT;
-                asm volatile("" : "+v"(tt));  // as above: nothing of this path may be hoisted out of the channel loop
-                const uint32_t a = sg.d_TyTz.div(tt);
-                const uint32_t rr = tt - a * (uint32_t)(sg.TY * sg.TZ);
-                const uint32_t b = sg.d_Tz.div(rr);
-                const uint32_t kk = rr - b * (uint32_t)sg.TZ;
-                Lerp3<float, false> Lq;
-                Lq.setup(shear_pos<UNIT>(x0 + (int)a, dt, un[sv]), shear_pos<UNIT>(y0 + (int)b, dt, un[sv + nv]),
-                         shear_pos<UNIT>(z0 + (int)kk, dt, un[sv + 2 * (size_t)nv]), nx, ny, nz);
-                Lq.grad(Ic, gx, gy, gz);
             }
             // cuda/interp.cu:230: (Real)((double)diff * dt); for dt = +-1 that is +-diff exactly
             const float diff = UNIT ? (float)dt * gv : (float)((double)gv * dt);
