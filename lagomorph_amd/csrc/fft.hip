@@ -17,6 +17,7 @@
 #include <cmath>
 
 #include <memory>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -404,12 +405,32 @@ static int get_coef(CoefRef &ref, int64_t gen, int inverse, const float *cosX, c
 
 // hipFFT plans are shared process-wide and hipfftSetStream + Exec is not atomic: both are issued under the
 // plan mutex (the Exec only enqueues).
+// A hipFFT plan owns ONE work area: two streams executing the same plan at the same time would race on it (the equal
+// sub-batches of a shoot cut over two streams, lddmm.EXPMAP_STREAMS, ask for the same (shape, batch) plan).
+// Every execution therefore records an event behind itself, and an execution on ANOTHER stream first waits for the
+// event of the previous one: the executions of one plan are serialised on the device, whatever streams they come from.
+// (Not while a stream is being captured: no event of the outside may enter a capture; a graph's replays are ordered by
+// whoever launches them.)
+struct PlanUse { hipEvent_t done = nullptr; hipStream_t stream = nullptr; bool recorded = false; };
+static std::map<hipfftHandle, PlanUse> *g_plan_use = nullptr;   // (under g_plan_mu; heap: never destroyed)
 template <typename F>
 static hipfftResult exec_on(hipfftHandle plan, hipStream_t s, F &&exec) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     hipfftResult r = hipfftSetStream(plan, s);
     if (r != HIPFFT_SUCCESS) return r;
-    return exec();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (capturing) return exec();
+    if (!g_plan_use) g_plan_use = new std::map<hipfftHandle, PlanUse>();
+    PlanUse &u = (*g_plan_use)[plan];
+    if (u.recorded && u.stream != s && hipStreamWaitEvent(s, u.done, 0) != hipSuccess) return HIPFFT_EXEC_FAILED;
+    r = exec();
+    if (r != HIPFFT_SUCCESS) return r;
+    if (!u.done && hipEventCreateWithFlags(&u.done, hipEventDisableTiming) != hipSuccess) { u.done = nullptr; return HIPFFT_EXEC_FAILED; }
+    if (hipEventRecord(u.done, s) != hipSuccess) return HIPFFT_EXEC_FAILED;
+    u.stream = s;
+    u.recorded = true;
+    return r;
 }
 
 // float32, 3D, power-of-two nx: rocFFT does the (y, z) transforms as a batched 2D real plan, the
@@ -519,9 +540,9 @@ static int fluid_metric_unscaled(R *out, const R *m, R *work, int64_t gen, int i
     note_path(LP_FLUID_ROCFFT);
     const int n[3] = {(int)nx, (int)ny, (int)nz};
     FftPlan p;
+    hipStream_t s = (hipStream_t)stream;
     int rc = get_plan(p, dim, n, (int)(nn * dim), sizeof(R) == 8);
     if (rc != LAGO_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
     hipfftResult r = exec_on(p.fwd, s, [&] {
         return sizeof(R) == 4 ? hipfftExecR2C(p.fwd, (hipfftReal *)m, (hipfftComplex *)work)
                               : hipfftExecD2Z(p.fwd, (hipfftDoubleReal *)m, (hipfftDoubleComplex *)work);

@@ -25,6 +25,7 @@
 // the 1/N of the unnormalised transform pair folded in.  Layout of the half spectrum: [n][c][x][y][z <= nz/2] complex,
 // what rocFFT's R2C produces, so the operator kernel does not know which path ran.
 #include <map>
+#include <memory>
 #include <tuple>
 #include <mutex>
 #include <vector>
@@ -538,17 +539,29 @@ struct BluKey {
         return std::tie(N, sign, esize, dev) < std::tie(o.N, o.sign, o.esize, o.dev);
     }
 };
+// A table is held through a shared_ptr (as the coefficient tables of fft.hip): a lookup returns a reference that the
+// caller keeps until its launch is enqueued, so lago_fluid_cache_clear() on another thread cannot free a table between a
+// lookup and the launch that reads it -- the last reference frees it, and hipFree waits for the kernels already enqueued.
+struct BluTab {
+    void *d = nullptr;
+    ~BluTab() {
+        if (!d) return;
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;   // (a capture in progress on another thread is not invalidated)
+        const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+        (void)hipFree(d);
+        if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    }
+};
+using BluRef = std::shared_ptr<BluTab>;
 static std::mutex g_blu_mu;
-static std::map<BluKey, void *> *g_blu = nullptr;   // (heap: never destroyed, as the coefficient cache of fft.hip)
+static std::map<BluKey, BluRef> *g_blu = nullptr;   // (heap: never destroyed, as the coefficient cache of fft.hip)
 constexpr size_t kBluMax = 64;
-static void blu_release_locked() {   // hipFree waits for the device: no kernel still reads a table
-    if (!g_blu) return;
-    for (auto &kv : *g_blu) (void)hipFree(kv.second);
-    g_blu->clear();
-}
 void bluestein_cache_clear() {
-    std::lock_guard<std::mutex> lk(g_blu_mu);
-    blu_release_locked();
+    std::map<BluKey, BluRef> dropped;   // released (and freed) after the lock: lookups are not stalled behind hipFree
+    {
+        std::lock_guard<std::mutex> lk(g_blu_mu);
+        if (g_blu) dropped.swap(*g_blu);
+    }
 }
 int bluestein_cache_entries() {
     std::lock_guard<std::mutex> lk(g_blu_mu);
@@ -556,27 +569,26 @@ int bluestein_cache_entries() {
 }
 
 template <typename R>
-static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
+static BluRef bluestein_table(int N, int M, int sign, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     const BluKey key{N, sign, (int)sizeof(R), dev};
     std::lock_guard<std::mutex> lk(g_blu_mu);
-    if (!g_blu) g_blu = new std::map<BluKey, void *>();
+    if (!g_blu) g_blu = new std::map<BluKey, BluRef>();
     auto it = g_blu->find(key);
     if (it != g_blu->end()) return it->second;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     const size_t cb = 2 * sizeof(R);
-    void *d = nullptr;
-    // a full cache takes no further tables (the direct-DFT stages serve that length): freeing here could pull a table
-    // from under another thread that has looked it up and not launched yet; lago_fluid_cache_clear() empties the cache
+    // a full cache takes no further tables (the direct-DFT stages serve that length); lago_fluid_cache_clear() empties it
     if (g_blu->size() >= kBluMax) return nullptr;
+    BluRef t = std::make_shared<BluTab>();
     {
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
         const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
-        const hipError_t e = hipMalloc(&d, (size_t)M * cb);
+        const hipError_t e = hipMalloc(&t->d, (size_t)M * cb);
         if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
-        if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (e != hipSuccess) { (void)hipGetLastError(); t->d = nullptr; return nullptr; }
     }
     GLines a;
     a.N = N; a.M = M; a.sign = sign; a.L = 1; a.Lp = 1; a.mode = 0; a.inner = 1; a.nlines = 1; a.ppp = 1; a.chunks = 1;
@@ -587,14 +599,12 @@ static const void *bluestein_table(int N, int M, int sign, hipStream_t s) {
     const size_t smem = (size_t)3 * M * cb;
     auto k = bluestein_table_kernel<R>;
     if (smem > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-        (void)hipFree(d);
-        return nullptr;
-    }
-    hipLaunchKernelGGL(k, dim3(1), dim3(kBlock), smem, s, reinterpret_cast<GC<R> *>(d), a);
-    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    (*g_blu)[key] = d;
-    return d;
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return nullptr;   // (~BluTab frees the buffer)
+    hipLaunchKernelGGL(k, dim3(1), dim3(kBlock), smem, s, reinterpret_cast<GC<R> *>(t->d), a);
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    (*g_blu)[key] = t;
+    return t;
 }
 
 // mode 0: `nlines` complex lines of N points, stride `inner`.  modes 1 / 2: `planes` fields of `nlines` contiguous real
@@ -643,10 +653,11 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
             if ((uint64_t)Li > units) Li = (int)units;
             if (Li > L) { L = Li; inpl = true; }
         }
-        const void *tab = (inpl ? ldsbi(L) : ldsb(L)) <= 160 * 1024 ? bluestein_table<R>(N, M, sign, s) : nullptr;
+        // (the reference lives until this function returns, i.e. until the launch that reads the table is enqueued)
+        const BluRef tab = (inpl ? ldsbi(L) : ldsb(L)) <= 160 * 1024 ? bluestein_table<R>(N, M, sign, s) : nullptr;
         if (tab) {
             a.M = M;
-            a.bhat = tab;
+            a.bhat = tab->d;
             a.inplace = inpl ? 1 : 0;
             factorise_pow2(M, a);
             const int Lp = L | 1;

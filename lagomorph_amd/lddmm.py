@@ -5,6 +5,8 @@ and of the per-minibatch arithmetic of ``LDDMMAtlasBuilder``
 (``lddmm.py:108-375``) on device-resident tensors.  Data loading and the CLI of
 the reference are outside this build's scope.
 """
+import threading
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -127,13 +129,22 @@ def _shoot(metric, m0, phiinv, dt, num_steps, v0, keep, out=None):
 # and every shoot that keeps its steps for a backward pass run on the caller's stream alone); `EXPMAP_STREAMS = 1`
 # switches it off -- bench.py does so for the pass it takes its per-kernel roofline from, because with two parts in
 # flight a launch's duration is no longer the time the kernel needs by itself.
+# Memory: the temporaries of a part (Ad_star / sharp / compose outputs, the FFT work buffer) are allocated on its side
+# stream, i.e. in that stream's pool of torch's caching allocator, and a block cached there is not handed to an
+# allocation of another stream.  A loop that alternates forward-only shoots with work on the caller's stream therefore
+# keeps both sets of blocks reserved: measured with tools/measure_split_memory.py (profiles/r06_split_memory.md) --
+# peak ALLOCATED is the same with and without the split, peak RESERVED grows by what one part's temporaries take.
+# Near the capacity of the device set EXPMAP_STREAMS = 1 (or call torch.cuda.empty_cache() between the phases).
 EXPMAP_STREAMS = 2
 EXPMAP_MIN_ITEMS = 1   # batch items a part must have (1: a batch of two shoots as 1 + 1: 1.61-1.71 -> 1.52-1.56 ms at 128^3)
-_side_streams = {}
+_side_streams = threading.local()   # per host thread: concurrent callers do not serialise on one pair of streams
 
 
 def _streams_for(device, n):
-    pool = _side_streams.setdefault(device, [])
+    pools = getattr(_side_streams, "pools", None)
+    if pools is None:
+        pools = _side_streams.pools = {}
+    pool = pools.setdefault(device, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]

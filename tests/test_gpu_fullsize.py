@@ -386,5 +386,6 @@ def test_config4_lddmm_step_160_hip_vs_oracle_backend(lm):
     e_hip = float((Ig.grad.double() - I64.grad).abs().max()) / sc
     e_orc = float((Ic.grad.double().cuda() - I64.grad).abs().max()) / sc
     print(f"I.grad against float64 through HIP: HIP float32 {e_hip:.3g}, oracle backend float32 {e_orc:.3g}")
-    assert e_hip <= max(1e-5, 1.5 * e_orc), {"HIP f32 vs f64": e_hip, "oracle f32 vs f64": e_orc, **errs}
+    assert e_orc <= 4e-5, {"oracle f32 vs f64 (the yardstick drifted)": e_orc}   # observed 1.3e-5
+    assert e_hip <= min(max(1e-5, 1.5 * e_orc), 5e-5), {"HIP f32 vs f64": e_hip, "oracle f32 vs f64": e_orc, **errs}
     assert float((mg - m).abs().max()) > 0

@@ -194,17 +194,20 @@ def test_lddmm_step_160cubed_float32_vs_float64_and_directional_derivative():
     assert abs(fd - an) <= 5e-4 * max(abs(an), abs(fd)), (fd, an)
 
 
-def assert_f32_no_worse_than_reference_form(name, new32, ref32, ref64, slack=1.5, floor=1e-5):
+def assert_f32_no_worse_than_reference_form(name, new32, ref32, ref64, slack=1.5, floor=1e-5, ceiling=5e-5, ref_ceiling=4e-5):
     """north_star's float32 bound is 1e-5 x max.  Two float32 evaluations of one chained formula can sit further apart
     than that although each is as accurate as float32 allows (the chain's conditioning multiplies every rounding).  So
     the comparison is made against the SAME formula in float64: the new form's float32 error must be within the bound,
     or -- where the reference form's own float32 error is already above it -- no larger than `slack` times that.
-    No fixed multiple of 1e-5 appears."""
+    The relative bound has an absolute lid: the yardstick shares most kernels with the form under test, so its
+    own float32 error must stay under `ref_ceiling` (observed: at most 1.4e-5 on these cases) and the new form's under
+    `ceiling`, whatever the yardstick does."""
     t = ref64.double()
     sc = float(t.abs().max())
     e_new = float((new32.double() - t).abs().max()) / sc
     e_ref = float((ref32.double() - t).abs().max()) / sc
-    assert e_new <= max(floor, slack * e_ref), (name, {"new form f32 vs f64": e_new, "reference form f32 vs f64": e_ref})
+    assert e_ref <= ref_ceiling, (name, {"reference form f32 vs f64 (the yardstick drifted)": e_ref})
+    assert e_new <= min(max(floor, slack * e_ref), ceiling), (name, {"new form f32 vs f64": e_new, "reference form f32 vs f64": e_ref})
     return e_new, e_ref
 
 
@@ -347,6 +350,45 @@ def test_expmap_stream_split_same_bits(sp, B, from_identity):
         assert torch.equal(t, one)
     g = lm.expmap(met, m0.clone().requires_grad_(True), num_steps=4, phiinv=p0)
     assert torch.equal(g.detach(), one)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("sp,B", [((48, 40, 56), 4), ((96, 80), 6), ((6, 2053), 2)])
+def test_expmap_stream_split_same_bits_on_the_rocfft_paths(sp, B, mode):
+    """The same with the fluid metric forced onto rocFFT (`fluid_mode` 0 - 2: plan + operator kernel / plan + fused x pass)
+    and EQUAL sub-batches: the two streams then want the same (shape, batch) plan at the same time.  A hipFFT plan owns one
+    work area, so executions of one plan from different streams are serialised by an event (csrc/fft.hip: exec_on;
+    ADVICE r5: the parts of a shoot raced on a shared plan).  Repeated, with different data each time, so that an overlap of the two parts' transforms
+    has a chance to show."""
+    import lagomorph_amd as lm
+    from lagomorph_amd import lddmm
+
+    ext = lm.lagomorph_ext
+    rng = np.random.default_rng(29)
+    d = len(sp)
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    default = lddmm.EXPMAP_STREAMS
+    prev_mode = ext.get_tuning()["fluid_mode"]
+    ext.set_fluid_mode(mode)
+    try:
+        for rep in range(4):
+            m0 = torch.from_numpy(smooth_np(rng, (B, d) + sp, 1.5)).float().cuda()
+            m0 = (m0 * (1.5 / met.sharp(m0).abs().max())).contiguous()
+            with torch.no_grad():
+                lddmm.EXPMAP_STREAMS = 1
+                before = ext.path_launches()
+                one = lm.expmap(met, m0, num_steps=4)
+                after = ext.path_launches()
+                lddmm.EXPMAP_STREAMS = 2
+                two = [lm.expmap(met, m0, num_steps=4) for _ in range(3)]
+            torch.cuda.synchronize()
+            if rep == 0 and mode == 0:
+                assert after["fluid_rocfft"] > before["fluid_rocfft"], "fluid_mode 0 did not reach the rocFFT path"
+            for t in two:
+                assert torch.equal(t, one), (sp, B, mode, rep)
+    finally:
+        lddmm.EXPMAP_STREAMS = default
+        ext.set_fluid_mode(prev_mode)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 1e-5)])
