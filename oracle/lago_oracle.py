@@ -200,6 +200,28 @@ def interp_points(img, pts):
     return lerp, grad
 
 
+def extrap_points(arr, idx):
+    """The clamped accessor and the clamped central differences (lg_clamp / lg_grad_point) of one array (nx, ny[, nz]) at
+    integer indices (npts, dim), in range or not.  Test hook (tests/test_oracle_ref.py)."""
+    arr = _c(arr)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    dim = arr.ndim
+    sh = list(arr.shape) + [1] * (3 - dim)
+    val = np.empty((idx.shape[0],), dtype=arr.dtype)
+    grad = np.empty((idx.shape[0], dim), dtype=arr.dtype)
+    _call("oracle_extrap_points", arr.dtype, _p(val), _p(grad), _p(arr), _p(idx), c_long(idx.shape[0]), c_int(dim),
+          c_long(sh[0]), c_long(sh[1]), c_long(sh[2]))
+    return val, grad
+
+
+def clamp_pairs(fl, ce, size):
+    """clampBackground on (floor, ceil) index pairs (lg_clamp_pair).  Test hook."""
+    fl = np.ascontiguousarray(fl, dtype=np.int64).copy()
+    ce = np.ascontiguousarray(ce, dtype=np.int64).copy()
+    _call("oracle_clamp_pairs", np.dtype(np.float64), _p(fl), _p(ce), c_long(int(size)), c_long(fl.shape[0]))
+    return fl, ce
+
+
 def affine_interp_forward(I, A, T, cpuref=False):
     I = _c(I)
     A, T = _c(A, I.dtype), _c(T, I.dtype)

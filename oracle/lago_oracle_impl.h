@@ -40,15 +40,17 @@ static inline int FN(lg_floor)(REAL x) {
     return f;
 }
 
-/* include/extrap.h:46-57 clampBackground(floor, ceil, size) */
+/* include/extrap.h:46-57 clampBackground(floor, ceil, size).  `size` is a size_t there, so the two upper comparisons are
+ * UNSIGNED: a negative ceil beside a non-negative floor -- not an interpolation footprint (ceil = floor + 1), no kernel
+ * produces it -- is sent to size - 1.  Restated as written (tests/test_oracle_ref.py pins it against the header). */
 static inline void FN(lg_clamp_pair)(int *fl, int *ce, long size) {
     if (*fl < 0) {
         *fl = 0;
         if (*ce < 0) *ce = 0;
     }
-    if (*ce >= size) {
+    if ((unsigned long)(long)*ce >= (unsigned long)size) {
         *ce = (int)(size - 1);
-        if (*fl >= size) *fl = (int)(size - 1);
+        if ((unsigned long)(long)*fl >= (unsigned long)size) *fl = (int)(size - 1);
     }
 }
 
@@ -192,6 +194,50 @@ int FN(oracle_interp_points)(REAL *lerp, REAL *grad, const REAL *img, const REAL
             FN(lg_trilerp_grad)(&grad[3 * q], &grad[3 * q + 1], &grad[3 * q + 2], img, pts[3 * q], pts[3 * q + 1],
                                 pts[3 * q + 2], sx, sy, sz);
         }
+    }
+    return 0;
+}
+
+/* The index rules at caller-given integer indices (test hooks: pinned against the reference's own include/extrap.h
+ * compiled into oracle/_ref).  oracle_extrap_points: idx (npts, dim) of ANY integers; val = the clamped accessor
+ * (get_value_safe<CLAMP>, extrap.h:110-192, through lg_clamp); grad = the clamped central differences of
+ * include/diff.h:7-52 -- for a centre inside the grid by lg_grad_point itself, the function every jtv routine of this
+ * oracle calls (rows a4-a7); for a centre outside (which no kernel produces) by the same expression on lg_clamp'ed
+ * neighbours of the unclamped centre, as diff.h would evaluate it.  oracle_clamp_pairs: clampBackground
+ * (extrap.h:46-57) on (floor, ceil) pairs. */
+static inline void FN(lg_grad_point)(REAL *g, const REAL *a, int dim, long nx, long ny, long nz, long i, long j, long k);
+int FN(oracle_extrap_points)(REAL *val, REAL *grad, const REAL *arr, const long *idx, long npts, int dim, long nx, long ny,
+                             long nz) {
+    if (dim != 2 && dim != 3) return -1;
+    if (dim == 2) nz = 1;
+    for (long q = 0; q < npts; ++q) {
+        const long i = idx[dim * q], j = idx[dim * q + 1], k = dim == 3 ? idx[dim * q + 2] : 0;
+        const long n[3] = {nx, ny, nz}, c[3] = {i, j, k};
+        size_t at[3][3];   /* [axis][minus, centre, plus]: flat offset with that axis' index shifted, every index clamped */
+        for (int a = 0; a < dim; ++a)
+            for (int s = -1; s <= 1; ++s) {
+                size_t off = 0;
+                for (int b = 0; b < dim; ++b) {
+                    const long r = FN(lg_clamp)((int)(c[b] + (b == a ? s : 0)), n[b]);
+                    off = off * (size_t)n[b] + (size_t)r;
+                }
+                at[a][s + 1] = off;
+            }
+        val[q] = arr[at[0][1]];
+        if (i >= 0 && i < nx && j >= 0 && j < ny && k >= 0 && k < nz)
+            FN(lg_grad_point)(grad + dim * q, arr, dim, nx, ny, nz, i, j, k);
+        else
+            for (int a = 0; a < dim; ++a) grad[dim * q + a] = (REAL)0.5f * (arr[at[a][2]] - arr[at[a][0]]);
+    }
+    return 0;
+}
+
+int FN(oracle_clamp_pairs)(long *fl, long *ce, long size, long npts) {
+    for (long q = 0; q < npts; ++q) {
+        int f = (int)fl[q], c = (int)ce[q];
+        FN(lg_clamp_pair)(&f, &c, size);
+        fl[q] = f;
+        ce[q] = c;
     }
     return 0;
 }

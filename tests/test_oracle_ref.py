@@ -103,3 +103,68 @@ def test_interp_forward_through_reference_cores(dtype):
     pos = (ii.astype(np.float64) + 1.0 * u[0].astype(np.float64)).astype(dtype).reshape(3, -1).T.copy()
     want = ref.interp_points(torch.from_numpy(I[0, 0].copy()), torch.from_numpy(pos))[0].numpy().reshape(sh)
     assert np.array_equal(orc.interp_forward(I, u, 1.0)[0, 0], want)
+
+
+# ---- include/extrap.h: the index rules -------------------------------------------------------------
+
+def _indices(rng, sh, n):
+    d = len(sh)
+    idx = np.stack([rng.integers(-4, s + 4, size=n) for s in sh], axis=1)
+    idx[::5] = np.stack([rng.integers(0, s, size=len(idx[::5])) for s in sh], axis=1)   # inside the grid
+    idx[::7, 0] = -1                                   # just below / above every border
+    idx[1::7, 0] = sh[0]
+    idx[2::7, -1] = sh[-1] - 1
+    idx[3::7, -1] = 0
+    idx[4::11] = rng.integers(-10 ** 6, 10 ** 6, size=idx[4::11].shape)   # far out of range
+    return idx.astype(np.int64)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("sh", [(7, 9), (2, 2), (5, 1), (1, 6), (2, 9), (5, 6, 7), (2, 2, 2), (9, 5, 1), (1, 1, 4), (3, 2, 33)])
+def test_clamped_accessor_and_central_differences_against_reference_header(dtype, sh):
+    """include/extrap.h:110-192 get_value_safe<CLAMP> -- the accessor every diff_x / diff_y / diff_z of include/diff.h:7-52
+    calls -- and the central differences around it, on in-range, border, out-of-range, extent-1 and extent-2 indices: the
+    oracle's lg_clamp and lg_grad_point (rows a4-a7: every jtv routine differentiates through them) bit for bit against
+    real reference code."""
+    rng = np.random.default_rng(7 * len(sh) + sum(sh))
+    arr = rng.standard_normal(sh).astype(dtype)
+    idx = _indices(rng, sh, 3000)
+    val_ref, grad_ref = (t.numpy() for t in ref.extrap_points(torch.from_numpy(arr), torch.from_numpy(idx)))
+    val, grad = orc.extrap_points(arr, idx)
+    assert np.array_equal(val, val_ref)
+    assert np.array_equal(grad, grad_ref)
+    # and the accessor is what its name says: the value at the clamped index
+    cl = tuple(np.clip(idx[:, a], 0, sh[a] - 1) for a in range(len(sh)))
+    assert np.array_equal(val_ref, arr[cl])
+    # along an axis of extent 1 the clamped difference is identically zero (the adjoint kernels' thin-axis case)
+    for a, s in enumerate(sh):
+        if s == 1:
+            assert not grad_ref[:, a].any()
+
+
+@pytest.mark.parametrize("sizes", [(7, 9), (2, 2), (5, 1), (5, 6, 7), (2, 2, 2), (9, 1, 4), (3, 4, 33)])
+def test_clamp_background_and_map_point_against_reference_header(sizes):
+    """include/extrap.h:46-77 clampBackground, :194-253 map_point<CLAMP>, :24-38 isInside on (floor, ceil = floor + 1)
+    pairs and on arbitrary pairs: the oracle's lg_clamp_pair (interpolation footprints of rows a1, a9, a10; the clamped
+    target cells of the splats, rows a2, a9, a10) against real reference code, index by index."""
+    rng = np.random.default_rng(sum(sizes))
+    d = len(sizes)
+    fl = np.stack([rng.integers(-5, s + 5, size=4000) for s in sizes], axis=1)
+    ce = fl + 1
+    ce[::9] = np.stack([rng.integers(-5, s + 5, size=len(ce[::9])) for s in sizes], axis=1)   # (not a footprint: any pair)
+    fl[1::13] = rng.integers(-10 ** 6, 10 ** 6, size=fl[1::13].shape)
+    ce[1::13] = fl[1::13] + 1
+    fc = np.concatenate([fl, ce], axis=1).astype(np.int64)
+    out = ref.map_points(torch.from_numpy(fc), list(sizes)).numpy()
+    assert out[:, 2 * d].all(), "map_point<CLAMP> always reports the mapped point as usable (extrap.h:212-217)"
+    for a, s in enumerate(sizes):
+        f, c = orc.clamp_pairs(fl[:, a], ce[:, a], s)
+        assert np.array_equal(f, out[:, a]) and np.array_equal(c, out[:, d + a]), (a, s)
+        # for a footprint pair the rule is the plain clamp of both members (what the HIP kernels compute: common.hpp clamp1)
+        foot = ce[:, a] == fl[:, a] + 1
+        assert np.array_equal(out[foot, a], np.clip(fl[foot, a], 0, s - 1))
+        assert np.array_equal(out[foot, d + a], np.clip(ce[foot, a], 0, s - 1))
+    inside = np.ones(len(fc), dtype=bool)
+    for a, s in enumerate(sizes):
+        inside &= (fl[:, a] >= 0) & (ce[:, a] < s)
+    assert np.array_equal(out[:, 2 * d + 1].astype(bool), inside)
