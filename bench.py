@@ -181,7 +181,24 @@ def micro_fluid(lm, dev, size, batch=8):
         k_inv, _ = time_op(lambda: lm.lagomorph_ext.fluid_operator(Fm, True, met.luts["cos"], met.luts["sin"], *met.params))
         k_fwd, _ = time_op(lambda: lm.lagomorph_ext.fluid_operator(Fm, False, met.luts["cos"], met.luts["sin"], *met.params))
     kbytes = 2 * Fm.numel() * 4
+    # "FFT vs finite-difference solver" (configs[2]): `flat` applied in the spatial domain by periodic stencils written with
+    # torch.roll (tests/fd_fluid.py: an independent derivation from the symbol of cuda/metric.cu:236-254; valid for flat only,
+    # SURVEY section 7) -- a comparator for the timing and a cross-check of the values, not an optimised kernel
+    fd = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from fd_fluid import flat_fd
+
+        with torch.no_grad():
+            fd_ms, _ = time_op(lambda: flat_fd(m, met.params), reps=3, warm=1)
+            dev_ = float((met.flat(m).double() - flat_fd(m.double(), met.params)).abs().max() / flat_fd(m.double(), met.params).abs().max())
+        fd = {"flat_finite_difference_torch_ms": fd_ms, "flat_fft_ms": flat_ms, "fft_speedup": fd_ms / flat_ms,
+              "max_rel_dev_fft_f32_vs_fd_f64": dev_,
+              "note": "spatial-domain flat = l(l(v)) with periodic second / central differences through torch.roll"}
+    except Exception as e:  # a comparator must not cost the line
+        fd = {"error": repr(e)}
     return {
+        "finite_difference_comparator": fd,
         "workload": f"FluidMetric sharp/flat batch {batch} x 3x{size}^3 fp32 (configs[2])",
         "sharp_ms": sharp_ms, "flat_ms": flat_ms,
         "sharp_GBps_ideal72.8B": 72.8 * V / sharp_ms / 1e6,
