@@ -154,7 +154,7 @@ def micro_interp_splat(ext, dev, size, batch=8):
             r["bwd_frac_of_hbm_peak"] = r["bwd_lds_GBps"] / HBM_PEAK_GBPS
         res[label] = r
     # HBM bytes per launch of the two kernels from the PMC passes over tools/run_micro.py (same workload, same batch)
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_traffic_micro.json", "r04_traffic_micro.json", "r03_traffic_micro.json", "r02_traffic_micro.json"))
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_traffic_micro.json", "r05_traffic_micro.json", "r04_traffic_micro.json", "r03_traffic_micro.json", "r02_traffic_micro.json"))
                   if os.path.exists(q)), "")
     if tpath and size == 128 and batch == 8:
         t = json.load(open(tpath))
@@ -996,7 +996,7 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, collected
             # separately with rocprofv3 --pmc and condensed by tools/pmc_traffic.py into profiles/)
             traffic, tsrc = None, None
-            for tname in ("r05_traffic_expmap.json", "r04_traffic_expmap.json", "r03_traffic_expmap.json", "r02_traffic_expmap.json", "r01_traffic.json"):
+            for tname in ("r06_traffic_expmap.json", "r05_traffic_expmap.json", "r04_traffic_expmap.json", "r03_traffic_expmap.json", "r02_traffic_expmap.json", "r01_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and B == 32 and S == 128:
                     for name, rec in json.load(open(tpath)).items():
