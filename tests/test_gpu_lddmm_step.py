@@ -251,7 +251,12 @@ def test_expmap_reverse_sweep_equals_autograd_through_the_loop(sp, dtype, tol):
             lddmm.USE_FUSED_EXPMAP = True
     for i, name in ((1, "d_m0"), (2, "d_phiinv")):
         if tol is None:
-            assert_f32_no_worse_than_reference_form(name, res[True][i], res[False][i], res64[i])
+            # d_phiinv is a POSITION gradient: it contains the cell-wise constant gradient of trilinear interpolation, which
+            # jumps at cell faces, and a float32 sample within an ulp of a face lands on the other side than its float64
+            # twin (tools/debug_step_event.py).  The loop form's own float32 error is 4.6e-3 on the small random case here:
+            # its lids are recorded at that scale; the smooth quantity d_m0 keeps the default 5e-5 / 4e-5
+            lids = dict(ceiling=2e-2, ref_ceiling=2e-2) if name == "d_phiinv" else {}
+            assert_f32_no_worse_than_reference_form(name, res[True][i], res[False][i], res64[i], **lids)
         else:
             err = float((res[True][i] - res[False][i]).abs().max() / res[False][i].abs().max())
             assert err <= tol, (name, err)

@@ -13,7 +13,7 @@ out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 # --streams 1: whole-batch launches on one stream, the launch bench.py's roofline object describes (the product default
 # cuts a forward shoot into two sub-batches on two streams: half-size launches that overlap)
-B="python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-micro --no-atlas --no-extras"
+B="python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-micro --no-atlas --no-epoch --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/expmap_trace -- $B > $out/bench_trace.json 2> $out/bench_trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/expmap_fetch -- $B > /dev/null 2> $out/expmap_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/expmap_write -- $B > /dev/null 2> $out/expmap_write.err
