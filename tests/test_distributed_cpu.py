@@ -238,3 +238,51 @@ def test_two_rank_affine_atlas_equals_one_process(tmp_path, oracle_ext, sp):
     assert np.allclose(np.concatenate([r0["A"], r1["A"]]), As.numpy(), rtol=0, atol=1e-12)
     assert np.allclose(np.concatenate([r0["T"], r1["T"]]), Ts.numpy(), rtol=0, atol=1e-12)
     assert np.allclose(r0["ep"], np.array(ep), rtol=1e-12)
+
+
+def _run_forced(rank, world, port, sp, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lm = _patch_oracle()
+        data = _dataset(6, sp)
+        res = {}
+        for tag, kw in (("plain", {}), ("forced", dict(force_collectives=True)), ("forced_blocking", dict(force_collectives=True, overlap_allreduce=False))):
+            calls = []
+            real = dist.all_reduce
+
+            def spy(t, *a, **k):
+                calls.append((t.numel(), bool(k.get("async_op", False)), torch._C._current_graph_task_id() != -1))
+                return real(t, *a, **k)
+
+            lm.lddmm.dist.all_reduce = spy
+            try:
+                b = lm.LDDMMAtlasBuilder(data, batch_size=2, lddmm_integration_steps=2, reg_weight=1e-1, learning_rate_pose=1e-2,
+                                         learning_rate_image=1e-1, image_update_freq=2, **kw)
+                b.run(num_epochs=2)
+            finally:
+                lm.lddmm.dist.all_reduce = real
+            res[tag] = (b.I.detach().numpy(), torch.cat(b.ms).numpy(), np.array(b.iter_losses), np.array(calls, dtype=np.int64).reshape(-1, 3))
+        np.savez(out, **{f"{t}_{k}": v for t, r in res.items() for k, v in zip(("I", "ms", "loss", "calls"), r)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_one_equal_the_plain_builder(tmp_path):
+    """`force_collectives=True` (round 6: what tests/test_gpu_rccl_world1.py runs over RCCL on the GPU box) on a
+    world-size-1 gloo group: every N-rank branch is taken -- the collective sequence says so -- and, a SUM over one rank
+    being the identity, the results are those of the plain builder exactly (the CPU oracle has no atomics)."""
+    sp = (6, 6, 6)
+    out = str(tmp_path / "forced.npz")
+    mp.spawn(_run_forced, args=(1, _free_port(), sp, out), nprocs=1, join=True)
+    r = np.load(out)
+    nv = int(np.prod(sp))
+    assert r["plain_calls"].size == 0
+    # image_update_freq = 2 on 3 minibatches: per epoch the update after iteration 2 and the forced one at the end
+    want = [(nv, 0, 0)] + [(nv, 1, 1), (nv, 1, 1), (6, 0, 0)] * 2
+    assert [tuple(c) for c in r["forced_calls"].tolist()] == want
+    assert [tuple(c) for c in r["forced_blocking_calls"].tolist()] == [(n, 0, 0) for n, _, _ in want]
+    for tag in ("forced", "forced_blocking"):
+        for k in ("I", "ms", "loss"):
+            assert np.array_equal(r[f"{tag}_{k}"], r[f"plain_{k}"]), (tag, k)
