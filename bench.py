@@ -19,6 +19,11 @@ Also on the same JSON line:
                    -> interp -> loss -> backward through every operator -> momentum update, then ONE RCCL
                    all-reduce of the atlas gradient and the image update) on 160^3 subjects, global
                    minibatch 32 split N ways; voxels/s, ms per step, the all-reduce time, rank count.
+  atlas_epoch   -- BASELINE configs[4] as the workload it names: 256 synthetic 160^3 subjects resident in HBM with their
+                   momenta, global minibatch 32, one `LDDMMAtlasBuilder.epoch()` (8 minibatches, the forced end-of-epoch
+                   image update, the history reduction); ms per epoch, voxels/s, fraction of the HBM bound, peak memory.
+                   At N = 1 both atlas legs run the N-rank code over a world-size-1 RCCL process group created in this
+                   process (`rccl_world_size_1`; LAGO_BENCH_FORCE_DIST=0 switches that off).
   roofline      -- the dominant hand-written kernel of the workload: algorithmic bytes / mean launch time measured
                    live with HIP events on the launch stream, in a SINGLE-STREAM pass of the same shoots that follows
                    the timed region in this process (the timed region runs the product's default, two sub-batches on two

@@ -100,11 +100,15 @@ LAGO_HD int wave_uniform(int v) {  // v is the same in every lane of the wave: k
 }
 LAGO_HD int brev(int v, int bits) { return bits ? (int)(__builtin_bitreverse32((uint32_t)v) >> (32 - bits)) : 0; }
 
+// Roots of unity are taken in DOUBLE and rounded once (round 6): `sincospif` of the float-rounded argument 2 t / m is off by
+// up to |arg| * 2^-24 * pi = 3.7e-7 (six float ulps near arg = 2), which showed as a 1.5 - 2 x larger float32 error of
+// whole transforms than rocFFT's or pocketfft's (profiles/r06_twiddles.md).  The tables are built once per workgroup
+// (one root per thread): the double evaluation costs nothing measurable.
 LAGO_HD float2 twiddle(int t, int m) {  // exp(-2 pi i t / m)
 #ifdef __HIP_DEVICE_COMPILE__
-    float sn, cs;
-    sincospif(-2.0f * (float)t / (float)m, &sn, &cs);
-    return make_float2(cs, sn);
+    double sn, cs;
+    sincospi(-2.0 * (double)t / (double)m, &sn, &cs);
+    return make_float2((float)cs, (float)sn);
 #else
     const double a = -2.0 * 3.14159265358979323846 * (double)t / (double)m;
     return make_float2((float)cos(a), (float)sin(a));

@@ -68,9 +68,9 @@ __device__ __forceinline__ GC<double> root<double>(int k, int n, int sign) {
 }
 template <>
 __device__ __forceinline__ GC<float> root<float>(int k, int n, int sign) {
-    float sn, cs;
-    sincospif((float)(2.0 * (double)k / (double)n), &sn, &cs);
-    return {cs, (float)sign * sn};
+    double sn, cs;   // in double, rounded once (fft_lds.hpp twiddle(): sincospif of the rounded argument is off by up to six ulps)
+    sincospi(2.0 * (double)k / (double)n, &sn, &cs);
+    return {(float)cs, (float)sign * (float)sn};
 }
 
 struct GLines {
@@ -347,9 +347,9 @@ __device__ __forceinline__ GC<R> chirp(int n, int N, int sign) {
         sincospi((double)q / (double)N, &sn, &cs);
         return {cs, (double)sign * sn};
     } else {
-        float sn, cs;
-        sincospif((float)((double)q / (double)N), &sn, &cs);
-        return {cs, (float)sign * sn};
+        double sn, cs;
+        sincospi((double)q / (double)N, &sn, &cs);
+        return {(float)cs, (float)sign * (float)sn};
     }
 }
 
@@ -433,8 +433,8 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
         }
     }
     if (a.M == 0) {
-        // the N-th roots of unity, once (argument reduced exactly, k / N with k < N; sincospi in double for float64
-        // lines, in float for float32 ones: ~1e-7 per twiddle, inside the transform's own rounding)
+        // the N-th roots of unity, once (argument reduced exactly, k / N with k < N; sincospi in double, rounded
+        // once to the line's precision)
         for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, a.sign);
         x = run_stages<R, RMAX, INPL>(x, y, W, a, N, a.sign, nl);
     } else {

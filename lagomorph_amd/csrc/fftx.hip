@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void fluid_xpass_kernel(float2 *__restrict__ F
     float2 *Fn = F + (size_t)n * 3 * NX * xs + (size_t)y * nzc + k0 + kc;
 
     for (int t = threadIdx.x; t < NX / 2; t += 256) {
-        float sn, cs;
-        sincospif(-2.0f * (float)t / (float)NX, &sn, &cs);
-        tw[t] = make_float2(cs, sn);
+        double sn, cs;   // (in double, rounded once: fft_lds.hpp twiddle())
+        sincospi(-2.0 * (double)t / (double)NX, &sn, &cs);
+        tw[t] = make_float2((float)cs, (float)sn);
     }
     // load the bundle: rows r = c*NX + x, kcn contiguous complex each (inactive lanes hold zeros)
     for (int r = row0; r < 3 * NX; r += 16) buf[r * KCP + kc] = act ? Fn[(size_t)r * xs] : make_float2(0.f, 0.f);
