@@ -202,6 +202,9 @@ void tune_affine(int box) { g_affine_box = box ? 1 : 0; }
 // everything clamped onto them and reach out to the image of the source grid's corners).  Matrices whose inverse would
 // make that candidate set large (or that have none) are left, per batch item and decided on the device, to the general
 // kernel (common.hpp: affine_item_regular).  d_I as always: float64 sums per window, one float atomic per touched cell.
+#ifndef LAGO_BOX_ROWS
+#define LAGO_BOX_ROWS 3   // candidate rows a wave of affine_splat_box_kernel keeps in flight (1: 231, 2: 227, 3: 222, 4: 224 us at 8 x 128^3)
+#endif
 struct BoxGeom {
     int nx, ny, nz, BX, BY, BZ;
     uint32_t nbx, nby, nbz, per_item, total;
@@ -293,36 +296,53 @@ __global__ __launch_bounds__(kBlock) void affine_splat_box_kernel(R *__restrict_
     R *dIn = BC ? d_I : d_I + (size_t)n * nc * nv;
     for (int c = 0; c < nc; ++c) {
         const R *gc = gon + (size_t)c * nv;
-        // one wave per candidate row (i, j), lanes along z.  (Requesting the next row's grad_out values ahead of the
-        // ownership test -- software pipelining over the ~25 rows a wave walks -- measured 15 % SLOWER: it loads the
-        // candidates that are not owned as well.)
-        for (int row = wave; row < rows; row += kBlock / 64) {
-            const int i = s0[0] + row / cy, j = s0[1] + row % cy;   // (scalar)
-            const R fi = (R)i - ox, fj = (R)j - oy;
-            for (int k = s0[2] + lane; k <= s1[2]; k += 64) {
+        // one wave per candidate row (i, j), lanes along z, LAGO_BOX_ROWS rows in flight per wave: every row's positions and
+        // ownership first, with its grad_out value requested through a buffer load whose offset is out of range for the
+        // lanes that do NOT own their candidate (no memory traffic for them: a plain prefetch of the next row measured
+        // 15 % slower in round 4 because it loaded every candidate), then the weights and LDS adds of all of them -- one
+        // dependent memory round trip per LAGO_BOX_ROWS rows instead of one per row.
+        const BufRsrc rgo = make_rsrc(gc, (uint32_t)(nv * sizeof(R)));
+        constexpr int UR = LAGO_BOX_ROWS;
+        for (int row0 = wave; row0 < rows; row0 += (kBlock / 64) * UR) {
+            for (int kb = s0[2]; kb <= s1[2]; kb += 64) {
+                const int k = kb + lane;
                 const R fk = (R)k - oz;
-                // cuda/affine.cu:42-61 (as affine_bwd_kernel above)
-                const R hx = lg_fma(An[2], fk, lg_fma(An[0], fi, An[1] * fj)) + Tn[0] + ox;
-                const R hy = lg_fma(An[5], fk, lg_fma(An[3], fi, An[4] * fj)) + Tn[1] + oy;
-                const R hz = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
-                const int fx = lg_floor(hx), fy = lg_floor(hy), fz = lg_floor(hz);
-                const int gx0 = clamp1(fx, nx), gy0 = clamp1(fy, ny), gz0 = clamp1(fz, nz);
-                const uint32_t lx = (uint32_t)(gx0 - X0), ly = (uint32_t)(gy0 - Y0), lz = (uint32_t)(gz0 - Z0);
-                if (lx >= (uint32_t)ex || ly >= (uint32_t)ey || lz >= (uint32_t)ez) continue;   // another box owns it
-                const R diff = gc[((size_t)i * ny + j) * nz + k];
-                const uint32_t lx1 = (uint32_t)(clamp1(fx + 1, nx) - X0), ly1 = (uint32_t)(clamp1(fy + 1, ny) - Y0),
-                               lz1 = (uint32_t)(clamp1(fz + 1, nz) - Z0);
-                const uint32_t cxs[2] = {lx, lx1}, cys[2] = {ly, ly1}, czs[2] = {lz, lz1};
-                // sequentially flipped weights (include/interp.h:431-453): x outer, y, z inner
-                R ddx = (R)1.f - (hx - (R)fx), ddy = (R)1.f - (hy - (R)fy), ddz = (R)1.f - (hz - (R)fz);
+                R hx[UR], hy[UR], hz[UR], diff[UR];
+                int fx[UR], fy[UR], fz[UR];
+                uint32_t lx[UR], ly[UR], lz[UR];
+                bool own[UR];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const R w = (ddx * ddy * ddz) * diff;
-                    __hip_atomic_fetch_add(win + ((cxs[q >> 2] * (uint32_t)WY + cys[(q >> 1) & 1]) * (uint32_t)WZ + czs[q & 1]),
-                                           (double)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ddz = (R)1.f - ddz;
-                    if (q & 1) ddy = (R)1.f - ddy;
-                    if ((q & 3) == 3) ddx = (R)1.f - ddx;
+                for (int q = 0; q < UR; ++q) {
+                    const int row = row0 + q * (kBlock / 64);
+                    const int i = s0[0] + row / cy, j = s0[1] + row % cy;   // (scalar)
+                    const R fi = (R)i - ox, fj = (R)j - oy;
+                    // cuda/affine.cu:42-61 (as affine_bwd_kernel above)
+                    hx[q] = lg_fma(An[2], fk, lg_fma(An[0], fi, An[1] * fj)) + Tn[0] + ox;
+                    hy[q] = lg_fma(An[5], fk, lg_fma(An[3], fi, An[4] * fj)) + Tn[1] + oy;
+                    hz[q] = lg_fma(An[8], fk, lg_fma(An[6], fi, An[7] * fj)) + Tn[2] + oz;
+                    fx[q] = lg_floor(hx[q]); fy[q] = lg_floor(hy[q]); fz[q] = lg_floor(hz[q]);
+                    lx[q] = (uint32_t)(clamp1(fx[q], nx) - X0); ly[q] = (uint32_t)(clamp1(fy[q], ny) - Y0); lz[q] = (uint32_t)(clamp1(fz[q], nz) - Z0);
+                    own[q] = row < rows && k <= s1[2] && lx[q] < (uint32_t)ex && ly[q] < (uint32_t)ey && lz[q] < (uint32_t)ez;   // else: another box owns it
+                    const uint32_t off = (uint32_t)((((size_t)i * ny + j) * nz + k) * sizeof(R));
+                    diff[q] = buf_load1<R>(rgo, own[q] ? off : 0xffffffffu);
+                }
+#pragma unroll
+                for (int q = 0; q < UR; ++q) {
+                    if (!own[q]) continue;
+                    const uint32_t lx1 = (uint32_t)(clamp1(fx[q] + 1, nx) - X0), ly1 = (uint32_t)(clamp1(fy[q] + 1, ny) - Y0),
+                                   lz1 = (uint32_t)(clamp1(fz[q] + 1, nz) - Z0);
+                    const uint32_t cxs[2] = {lx[q], lx1}, cys[2] = {ly[q], ly1}, czs[2] = {lz[q], lz1};
+                    // sequentially flipped weights (include/interp.h:431-453): x outer, y, z inner
+                    R ddx = (R)1.f - (hx[q] - (R)fx[q]), ddy = (R)1.f - (hy[q] - (R)fy[q]), ddz = (R)1.f - (hz[q] - (R)fz[q]);
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        const R w = (ddx * ddy * ddz) * diff[q];
+                        __hip_atomic_fetch_add(win + ((cxs[c8 >> 2] * (uint32_t)WY + cys[(c8 >> 1) & 1]) * (uint32_t)WZ + czs[c8 & 1]),
+                                               (double)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ddz = (R)1.f - ddz;
+                        if (c8 & 1) ddy = (R)1.f - ddy;
+                        if ((c8 & 3) == 3) ddx = (R)1.f - ddx;
+                    }
                 }
             }
         }
