@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Marching-window splat (lago_tuning.splat_shear_mc = 3, splat_march3_kernel) against the shipped geometry-once kernel
-(mode 2) in one process: parity on a sweep of shapes / steps / start modes / field roughness (d_u bits, d_I relative),
+(mode 2) in one process.  NEEDS the library with `profiles/r06_march_window.patch` applied (`git apply` it, rebuild): the
+kernel is not in the tree (measured, not faster: profiles/r06_march_window.md); on the shipped library mode 3 is mode 2.
+What it does: parity on a sweep of shapes / steps / start modes / field roughness (d_u bits, d_I relative),
 then timings at 8 x 128^3, 8 x 160^3 and 32 x 160^3.   env: QUICK=1 parity only."""
 import os
 import sys

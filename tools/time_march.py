@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of the C = 3 splat with d_u through one library (LAGO_HIP_LIBRARY selects an A/B build): modes 2 and 3,
+"""Timing of the C = 3 splat with d_u through one library (LAGO_HIP_LIBRARY selects an A/B build): modes 2 and 3 (mode 3 =
+the marching-window kernel of `profiles/r06_march_window.patch`; on the shipped library every mode >= 2 is the shipped kernel),
 batch B x S^3.  env: S (128), B (8), MODES ("2,3"), PARITY=1 compares mode 3 with mode 2."""
 import os
 import sys
