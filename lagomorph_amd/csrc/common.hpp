@@ -360,11 +360,25 @@ struct Lerp3 {
             c[q + 4] = c_lo ? lo : hi;
         }
     }
-    // include/interp.h:115-122
+    // include/interp.h:115-122.  The z-border selection is made AFTER the two (x, y) interpolations: the floor-z group
+    // c0..c3 is either the four `lo` halves or the four `hi` halves (f_hi is one flag for all four rows), the ceil-z group
+    // likewise, and both groups go through the same expression G -- so fma(omv, f_hi ? G(hi) : G(lo), v * (c_lo ? G(lo) :
+    // G(hi))) is value_of(c) bit for bit with two selects instead of eight (the gather kernels are half bound by vector
+    // instruction issue: 48 of Ad_star's 424 vector instructions per thread were these selects).
     __device__ __forceinline__ R value(const R *__restrict__ img) const {
-        R c[8];
-        fetch(img, c);
-        return value_of(c);
+        if (THIN_OK && thin) {
+            R c[8];
+            fetch(img, c);
+            return value_of(c);
+        }
+        const BufRsrc r = make_rsrc(img, bytes);
+        R lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) buf_load2<R>(r, rb[q], lo[q], hi[q]);
+        const R omt = (R)1.f - t, omu = (R)1.f - u, omv = (R)1.f - v;
+        const R glo = lg_fma(omu, lg_fma(omt, lo[0], t * lo[1]), u * lg_fma(omt, lo[3], t * lo[2]));
+        const R ghi = lg_fma(omu, lg_fma(omt, hi[0], t * hi[1]), u * lg_fma(omt, hi[3], t * hi[2]));
+        return lg_fma(omv, f_hi ? ghi : glo, v * (c_lo ? glo : ghi));
     }
     __device__ __forceinline__ R value_of(const R (&c)[8]) const {
         const R omt = (R)1.f - t, omu = (R)1.f - u, omv = (R)1.f - v;

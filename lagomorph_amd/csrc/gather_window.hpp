@@ -160,6 +160,23 @@ struct GWLerp {
             c[q + 4] = c_lo ? lo : hi;
         }
     }
+    // fetch + value_of with the z-border selection behind the two (x, y) interpolations (Lerp3::value, common.hpp: same bits,
+    // two selects instead of eight)
+    __device__ __forceinline__ float value(const float *win) const {
+        uint32_t p = pk;
+        asm volatile("" : "+v"(p));
+        const uint32_t b0 = p & 0x3fffu;
+        const uint32_t dX = (p & (1u << 14)) ? (uint32_t)(GW::WY * GW::WZ) : 0u, dY = (p & (1u << 15)) ? (uint32_t)GW::WZ : 0u;
+        const bool f_hi = p & (1u << 16), c_lo = p & (1u << 17);
+        const uint32_t rb[4] = {b0, b0 + dX, b0 + dX + dY, b0 + dY};
+        float lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lo[q] = win[rb[q]]; hi[q] = win[rb[q] + 1]; }
+        const float omt = 1.f - t, omu = 1.f - u, omv = 1.f - v;
+        const float glo = lg_fma(omu, lg_fma(omt, lo[0], t * lo[1]), u * lg_fma(omt, lo[3], t * lo[2]));
+        const float ghi = lg_fma(omu, lg_fma(omt, hi[0], t * hi[1]), u * lg_fma(omt, hi[3], t * hi[2]));
+        return lg_fma(omv, f_hi ? ghi : glo, v * (c_lo ? glo : ghi));
+    }
     // Lerp3::value_of (include/interp.h:115-122)
     __device__ __forceinline__ float value_of(const float (&c)[8]) const {
         const float omt = 1.f - t, omu = 1.f - u, omv = 1.f - v;

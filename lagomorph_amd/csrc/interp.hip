@@ -179,9 +179,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const BufRsrc ro = make_rsrc(on + (size_t)c * nv, plane);
 #pragma unroll
             for (int e = 0; e < U; ++e) {
-                float q[8];
-                L[e].fetch(gwin, q);
-                float val = L[e].value_of(q);
+                float val = L[e].value(gwin);
                 if constexpr (STRAY) {
                     const bool mine = outm & (1u << e);
                     if (__builtin_amdgcn_ballot_w64(mine) != 0) {  // wave-uniform
