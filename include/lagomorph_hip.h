@@ -108,7 +108,8 @@ typedef struct lago_tuning {
      * otherwise.  2: the tuned passes, rocFFT for the rest (1: rocFFT 2D
      * (y, z) plan + fused x-axis pass, nx in {64,128,256}; 0: rocFFT 3D plan + operator kernel; a mode falls back to
      * the next lower one for shapes it does not support); the rocFFT plans are spot-checked against a direct DFT
-     * (csrc/fft.hip).  Results agree to rounding */
+     * (csrc/fft.hip).  Results agree to rounding.  4: as 3, with the generic passes' x transforms and operator as three
+     * launches instead of the fused one (csrc/fftg.hip: fft_xop_kernel) -- the same bits; the comparison switch */
     int32_t fluid_mode;
     /* FFT-pass fluid metric: batch items per x-pass workgroup (0, the default: chosen by the size of the launch) */
     int32_t fluid_xpass_ipw;

@@ -38,7 +38,7 @@ FLAGS = [
 
 
 def _deps():
-    return [os.path.join(CSRC, h) for h in ("common.hpp", "fft_lds.hpp", "stencil_tile.hpp", "gather_window.hpp")] + [
+    return [os.path.join(CSRC, h) for h in ("common.hpp", "fft_lds.hpp", "stencil_tile.hpp", "gather_window.hpp", "fluid_bin.hpp")] + [
         os.path.join(HERE, "..", "include", "lagomorph_hip.h")]
 
 

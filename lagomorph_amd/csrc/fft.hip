@@ -572,7 +572,13 @@ static int fluid_metric_unscaled(R *out, const R *m, R *work, int64_t gen, int i
 }  // namespace lago
 
 namespace lago {
-void tune_fluid(int mode) { g_fluid_xpass = mode < 0 ? 0 : (mode > 3 ? 3 : mode); }
+void tune_generic_fuse(int on);   // fftg.hip
+// mode 4: as 3 (the default), but the generic passes run the x transforms and the operator as three launches instead of the
+// fused fft_xop_kernel -- the A/B and bit-comparison switch of that fusion
+void tune_fluid(int mode) {
+    g_fluid_xpass = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
+    tune_generic_fuse(mode != 4);
+}
 }  // namespace lago
 
 extern "C" {

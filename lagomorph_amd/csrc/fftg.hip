@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fluid_bin.hpp"
 
 namespace lago {
 
@@ -478,6 +479,75 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
     }
 }
 
+// The x pass of the 3D operator with the operator inside (round 6): forward transform along x, the per-frequency 3 x 3
+// operator on the three components, inverse transform -- ONE read and ONE write of the half spectrum instead of three of
+// each (x forward, operator kernel, x inverse): 5 instead of 7 passes per fluid_metric call on the generic path.  A
+// workgroup takes L adjacent (y, z-bin) columns of one batch item, all three components: 3 L lines in LDS, line index
+// 3 j + c (a column's components adjacent, so the valid lines of a ragged last chunk are contiguous).  The stages are
+// those of fft_lines_kernel (run_stages on the same roots), the operator is fluid_bin.hpp's: the bits of the three
+// separate launches.  Lengths that run as Bluestein convolutions or in place keep the separate passes (host).
+struct XopArgs {
+    const void *cosX, *sinX, *cosY, *sinY, *cosZ, *sinZ;
+    double alpha, beta, gamma, scale;
+    uint32_t cols;      // columns per component plane: Y * zc
+    uint32_t zc;        // bins of the last axis
+    uint32_t chunks;    // chunks of L columns per batch item
+    FastDiv dchunks, dzc, dLc;
+    int Lc;             // columns per workgroup (a.L = 3 Lc lines)
+};
+
+template <typename R, int RMAX, bool INV>
+__global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spec, GLines a, XopArgs o) {
+    extern __shared__ __align__(16) unsigned char lago_fg[];
+    typedef GC<R> C;
+    const int N = a.N, Lp = a.Lp, Lc = o.Lc;
+    C *x = reinterpret_cast<C *>(lago_fg), *y = x + (size_t)Lp * N, *W = y + (size_t)Lp * N;
+    const uint32_t n = o.dchunks.div(blockIdx.x);
+    const uint32_t c0 = (blockIdx.x - n * o.chunks) * (uint32_t)Lc;      // first column
+    const int ncol = (int)min((uint32_t)Lc, o.cols - c0);
+    const int nl = 3 * ncol;
+    const size_t planeC = (size_t)N * o.cols;                            // complex elements per component
+    C *base = spec + (size_t)n * 3 * planeC + c0;
+    // load: (component, point, column) with the column fastest over the threads
+    for (int i = threadIdx.x; i < 3 * N * Lc; i += kBlock) {
+        const int r = (int)o.dLc.div((uint32_t)i), j = i - r * Lc;
+        const int c = (int)a.dN.div((uint32_t)r), pt = r - c * N;
+        if (j < ncol) x[(size_t)pt * Lp + 3 * j + c] = base[(size_t)c * planeC + (size_t)pt * o.cols + j];
+    }
+    for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, -1);
+    C *res = run_stages<R, RMAX>(x, y, W, a, N, -1, nl);
+    // operator: frequency kx = point index (the stages return natural order), (ky, kz) from the column
+    const R *cX = (const R *)o.cosX, *sX = (const R *)o.sinX, *cY = (const R *)o.cosY, *sY = (const R *)o.sinY,
+            *cZ = (const R *)o.cosZ, *sZ = (const R *)o.sinZ;
+    const R scale = (R)o.scale;
+    for (int i = threadIdx.x; i < N * Lc; i += kBlock) {
+        const int kx = (int)o.dLc.div((uint32_t)i), j = i - kx * Lc;
+        if (j < ncol) {
+            const uint32_t col = c0 + (uint32_t)j;
+            const uint32_t ky = o.dzc.div(col), kz = col - ky * o.zc;
+            FluidBin3<R, INV> op;
+            op.setup(cX[kx], cY[ky], cZ[kz], sX[kx], sY[ky], sZ[kz], o.alpha, o.beta, o.gamma);
+            C *q = res + (size_t)kx * Lp + 3 * j;
+            C A = q[0], B = q[1], Cc = q[2];
+            op.apply(A.re, B.re, Cc.re);
+            op.apply(A.im, B.im, Cc.im);
+            q[0] = C{A.re * scale, A.im * scale};   // scale == 1 is a bitwise no-op (as in the operator kernel)
+            q[1] = C{B.re * scale, B.im * scale};
+            q[2] = C{Cc.re * scale, Cc.im * scale};
+        }
+    }
+    // the inverse transform on the conjugate roots (run_stages begins with a barrier: the operator's writes and these)
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, +1);
+    C *other = res == x ? y : x;
+    res = run_stages<R, RMAX>(res, other, W, a, N, +1, nl);
+    for (int i = threadIdx.x; i < 3 * N * Lc; i += kBlock) {
+        const int r = (int)o.dLc.div((uint32_t)i), j = i - r * Lc;
+        const int c = (int)a.dN.div((uint32_t)r), pt = r - c * N;
+        if (j < ncol) base[(size_t)c * planeC + (size_t)pt * o.cols + j] = res[(size_t)pt * Lp + 3 * j + c];
+    }
+}
+
 // power-of-two length: radix-8 stages first (512 = 8 * 8 * 8: three LDS round trips instead of five), then 4, then 2
 static void factorise_pow2(int N, GLines &a) {
     a.nfac = 0;
@@ -743,6 +813,96 @@ static int lines_pass(GC<R> *spec, const R *rin, R *rout, int N, uint64_t inner,
     return LAGO_OK;
 }
 
+std::atomic<int> g_generic_fuse{1};   // 1 (default): the x pass of the 3D generic path carries the operator (fft_xop_kernel)
+void tune_generic_fuse(int on) { g_generic_fuse = on ? 1 : 0; }
+
+// x forward + operator + x inverse in one launch; returns 1 when the length is left to the separate passes (Bluestein
+// lines, lengths whose three-component chunk does not fit the LDS).
+template <typename R>
+static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY, const R *cosZ,
+                    const R *sinZ, double alpha, double beta, double gamma, int64_t nn, int64_t X, int64_t Y, int64_t zc,
+                    double scale, hipStream_t s) {
+    const int N = (int)X;
+    if (N < 2 || largest_prime_factor(N) >= 29) return 1;
+    {   // a factor 11 or 13 beside powers of two only takes the 155 - 164-register instantiation of the stages: with three
+        // components' lines per workgroup on top it loses to the separate passes (182 x 218 x 182: +1.6 %)
+        GLines t;
+        factorise(N, t);
+        bool r13 = false, odd_small = false;
+        for (int f = 0; f < t.nfac; ++f) {
+            r13 = r13 || t.fac[f] == 11 || t.fac[f] == 13;
+            odd_small = odd_small || t.fac[f] == 3 || t.fac[f] == 5 || t.fac[f] == 7;
+        }
+        if (r13 && !odd_small) return 1;
+    }
+    const uint64_t cols = (uint64_t)Y * (uint64_t)zc;
+    if (cols >= (1ull << 31) || (uint64_t)nn * cols >= (1ull << 31)) return 1;
+    GLines a;
+    a.N = N;
+    a.inner = (uint32_t)cols;
+    a.nlines = 0;
+    a.sign = -1;
+    a.mode = 0;
+    a.nhalf = N / 2 + 1;
+    factorise(N, a);
+    a.M = 0;
+    a.bhat = nullptr;
+    a.inplace = 0;
+    const size_t cb = 2 * sizeof(R);
+    auto lds = [&](int lc) { return ((size_t)2 * ((3 * lc) | 1) + 1) * N * cb; };
+    // columns per workgroup: FEW -- three (float64) or four (float32) adjacent columns, 48 / 32 B, within 40 KB of LDS, so
+    // that four and more of these long-lived workgroups (load, forward stages, operator, inverse stages, store) share a CU.
+    // Measured (tools/time_generic_fuse.py with the column count forced, profiles/r06_generic_fuse.md): float64 128^3
+    // 2 / 3 / 4 / 6 / 8 columns -3.7 / -9.8 / -4.8 / -3.4 / +13 % against the separate passes, float64 160^3 -8.1 / -8.1 /
+    // -7.0 / +13.8 / +5.9 %, float32 120^3 +3.9 / +0.8 / -9.5 / -7.9 / -7.4 %.
+    int Lc = sizeof(R) == 8 ? 3 : 4;
+    while (Lc > 1 && lds(Lc) > 40 * 1024) --Lc;
+    if (lds(Lc) > 160 * 1024) return 1;
+    if ((uint64_t)Lc > cols) Lc = (int)cols;
+    a.L = 3 * Lc;
+    a.Lp = a.L | 1;
+    a.ppp = 0;
+    a.chunks = 0;
+    a.dinner = FastDiv(a.inner);
+    a.dN = FastDiv((uint32_t)N);
+    a.dL = FastDiv((uint32_t)a.L);
+    a.dnhalf = FastDiv((uint32_t)a.nhalf);
+    a.dchunks = FastDiv(1u);
+    bool pow2 = true, r13 = false, odd_small = false;
+    for (int f = 0, st = 1; f < a.nfac; ++f) {
+        a.ds[f] = FastDiv((uint32_t)st);
+        a.dr[f] = FastDiv((uint32_t)(a.fac[f] + 1) / 2u);
+        st *= a.fac[f];
+        pow2 = pow2 && (a.fac[f] == 2 || a.fac[f] == 4 || a.fac[f] == 8);
+        r13 = r13 || a.fac[f] == 11 || a.fac[f] == 13;
+        odd_small = odd_small || a.fac[f] == 3 || a.fac[f] == 5 || a.fac[f] == 7;
+    }
+    XopArgs o;
+    o.cosX = cosX; o.sinX = sinX; o.cosY = cosY; o.sinY = sinY; o.cosZ = cosZ; o.sinZ = sinZ;
+    o.alpha = alpha; o.beta = beta; o.gamma = gamma; o.scale = scale;
+    o.cols = (uint32_t)cols;
+    o.zc = (uint32_t)zc;
+    o.chunks = (uint32_t)((cols + Lc - 1) / Lc);
+    o.dchunks = FastDiv(o.chunks);
+    o.dzc = FastDiv(o.zc);
+    o.dLc = FastDiv((uint32_t)Lc);
+    o.Lc = Lc;
+    const uint64_t grid = (uint64_t)nn * o.chunks;
+    if (grid >= (1ull << 31)) return 1;
+    const size_t smem = lds(Lc);
+#define LAGO_XOP(RM)                                                                                                 \
+    do {                                                                                                             \
+        auto k = inverse ? fft_xop_kernel<R, RM, true> : fft_xop_kernel<R, RM, false>;                               \
+        if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, a, o);                              \
+    } while (0)
+    if (pow2) LAGO_XOP(4);
+    else if (r13 && !odd_small) LAGO_XOP(13);
+    else LAGO_XOP(7);
+#undef LAGO_XOP
+    return LAGO_OK;
+}
+
 // out = irfft(L^(+-2) rfft(m)) through the generic passes; work: the half spectrum (nn * dim * nx * ny * (nz/2 + 1) complex)
 template <typename R>
 int fluid_metric_generic(R *out, const R *m, R *work, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY,
@@ -756,15 +916,23 @@ int fluid_metric_generic(R *out, const R *m, R *work, int inverse, const R *cosX
     if (rc != LAGO_OK) return rc;
     rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, -1, 0, s);
     if (rc != LAGO_OK) return rc;
+    const double scale = 1.0 / ((double)X * (double)Y * (double)Z);
+    bool fused = false;
+    if (dim == 3 && g_generic_fuse) {   // x forward + operator + x inverse in one launch where the length allows
+        rc = xop_pass<R>(spec, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nn, X, Y, zc, scale, s);
+        if (rc < 0 || rc > 1) return rc;
+        fused = rc == LAGO_OK;
+    }
+    if (!fused) {
     rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, -1, 0, s);
     if (rc != LAGO_OK) return rc;
-    const double scale = 1.0 / ((double)X * (double)Y * (double)Z);
     const int64_t cx = nx, cy = dim == 2 ? ny / 2 + 1 : ny, cz = dim == 3 ? nz / 2 + 1 : 1;
     rc = fluid_operator_impl<R>(work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, cx, cy, cz,
                                 (void *)s, scale);
     if (rc != LAGO_OK) return rc;
     rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, +1, 0, s);
     if (rc != LAGO_OK) return rc;
+    }
     rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, +1, 0, s);
     if (rc != LAGO_OK) return rc;
     rc = lines_pass<R>(spec, nullptr, out, (int)Z, 1, (uint64_t)(X * Y), (uint64_t)planes, +1, 2, s);

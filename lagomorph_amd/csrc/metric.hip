@@ -12,6 +12,7 @@
 // computed once per bin exactly as the reference does.  Pure streaming: every
 // byte of Fm is read once and written once.
 #include "common.hpp"
+#include "fluid_bin.hpp"
 
 namespace lago {
 
@@ -43,52 +44,15 @@ __global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm,
     const size_t nv = g.nvox;  // complex bins per component
     Cplx<R> *F = Fm + v.s;
     if (DIM == 3) {
-        const R wx = cosX[v.i], wy = cosY[v.j], wz = cosZ[v.k];
-        const R sx = sinX[v.i], sy = sinY[v.j], sz = sinZ[v.k];
-        const R lambda = (R)__builtin_fma(alpha, (double)(wx + wy + wz), gamma);
-        const R l00 = (R)__builtin_fma(-beta, (double)wx, (double)lambda);
-        const R l11 = (R)__builtin_fma(-beta, (double)wy, (double)lambda);
-        const R l22 = (R)__builtin_fma(-beta, (double)wz, (double)lambda);
-        const R l10 = (R)(beta * (double)sx * (double)sy);
-        const R l20 = (R)(beta * (double)sx * (double)sz);
-        const R l21 = (R)(beta * (double)sy * (double)sz);
-        const R L00 = lg_fma(l20, l20, lg_fma(l00, l00, l10 * l10));
-        const R L10 = lg_fma(l20, l21, lg_fma(l00, l10, l10 * l11));
-        const R L11 = lg_fma(l21, l21, lg_fma(l10, l10, l11 * l11));
-        const R L20 = lg_fma(l20, l22, lg_fma(l00, l20, l10 * l21));
-        const R L21 = lg_fma(l21, l22, lg_fma(l10, l20, l11 * l21));
-        const R L22 = lg_fma(l22, l22, lg_fma(l20, l20, l21 * l21));
-        R ooG00 = 0, G10 = 0, ooG11 = 0, G20 = 0, G21 = 0, ooG22 = 0;
-        if (INV) {  // cuda/metric.cu:47-78
-            ooG00 = recip_via_double(safe_sqrt(L00));
-            G10 = L10 * ooG00;
-            G20 = L20 * ooG00;
-            ooG11 = lg_fma(-G10, G10, L11);
-            ooG11 = recip_via_double(safe_sqrt(ooG11));
-            G21 = lg_fma(-G20, G10, L21) * ooG11;
-            ooG22 = lg_fma(-G21, G21, lg_fma(-G20, G20, L22));
-            ooG22 = recip_via_double(safe_sqrt(ooG22));
-        }
+        FluidBin3<R, INV> op;   // (fluid_bin.hpp: shared with the FFT passes that apply the operator in place)
+        op.setup(cosX[v.i], cosY[v.j], cosZ[v.k], sinX[v.i], sinY[v.j], sinZ[v.k], alpha, beta, gamma);
         for (int n = 0; n < nn; ++n, F += 3 * nv) {
             Cplx<R> a = F[0], b = F[nv], c = F[2 * nv];
             R X[2] = {a.re, a.im}, Y[2] = {b.re, b.im}, Z[2] = {c.re, c.im};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 R bX = X[q], bY = Y[q], bZ = Z[q];
-                if (INV) {  // cuda/metric.cu:103-130
-                    R y0 = bX * ooG00;
-                    R y1 = lg_fma(-G10, y0, bY) * ooG11;
-                    R y2 = lg_fma(-G21, y1, lg_fma(-G20, y0, bZ)) * ooG22;
-                    bZ = y2 * ooG22;
-                    bY = lg_fma(-G21, bZ, y1) * ooG11;
-                    bX = lg_fma(-G20, bZ, lg_fma(-G10, bY, y0)) * ooG00;
-                } else {  // cuda/metric.cu:145-160
-                    R x = lg_fma(L20, bZ, lg_fma(L00, bX, L10 * bY));
-                    R y = lg_fma(L21, bZ, lg_fma(L10, bX, L11 * bY));
-                    bZ = lg_fma(L22, bZ, lg_fma(L20, bX, L21 * bY));
-                    bX = x;
-                    bY = y;
-                }
+                op.apply(bX, bY, bZ);
                 X[q] = bX; Y[q] = bY; Z[q] = bZ;
             }
             F[0] = Cplx<R>{X[0] * scale, X[1] * scale};  // scale == 1 is a bitwise no-op

@@ -293,7 +293,8 @@ def set_vector_kernels(on):
 def set_fluid_mode(mode):
     """fluid_metric implementation: 3 (default) the tuned LDS-tiled FFT passes where the shape allows and the generic
     hand-written passes for everything else (no rocFFT); 2 the tuned passes with rocFFT fallbacks, 1 rocFFT 2D plan +
-    fused x pass, 0 rocFFT 3D plan + operator kernel."""
+    fused x pass, 0 rocFFT 3D plan + operator kernel; 4 = 3 with the generic passes' x transforms and operator as three
+    launches instead of the fused one (same bits: the comparison switch of that fusion)."""
     tune(fluid_mode=mode)
 
 
