@@ -496,7 +496,7 @@ struct XopArgs {
     int Lc;             // columns per workgroup (a.L = 3 Lc lines)
 };
 
-template <typename R, int RMAX, bool INV>
+template <typename R, int RMAX, bool INV, int DIM>
 __global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spec, GLines a, XopArgs o) {
     extern __shared__ __align__(16) unsigned char lago_fg[];
     typedef GC<R> C;
@@ -505,18 +505,20 @@ __global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spe
     const uint32_t n = o.dchunks.div(blockIdx.x);
     const uint32_t c0 = (blockIdx.x - n * o.chunks) * (uint32_t)Lc;      // first column
     const int ncol = (int)min((uint32_t)Lc, o.cols - c0);
-    const int nl = 3 * ncol;
+    const int nl = DIM * ncol;
     const size_t planeC = (size_t)N * o.cols;                            // complex elements per component
-    C *base = spec + (size_t)n * 3 * planeC + c0;
+    C *base = spec + (size_t)n * DIM * planeC + c0;
     // load: (component, point, column) with the column fastest over the threads
-    for (int i = threadIdx.x; i < 3 * N * Lc; i += kBlock) {
+    for (int i = threadIdx.x; i < DIM * N * Lc; i += kBlock) {
         const int r = (int)o.dLc.div((uint32_t)i), j = i - r * Lc;
         const int c = (int)a.dN.div((uint32_t)r), pt = r - c * N;
-        if (j < ncol) x[(size_t)pt * Lp + 3 * j + c] = base[(size_t)c * planeC + (size_t)pt * o.cols + j];
+        if (j < ncol) x[(size_t)pt * Lp + DIM * j + c] = base[(size_t)c * planeC + (size_t)pt * o.cols + j];
     }
     for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, -1);
     C *res = run_stages<R, RMAX>(x, y, W, a, N, -1, nl);
-    // operator: frequency kx = point index (the stages return natural order), (ky, kz) from the column
+    // operator: the frequency along the transformed axis = point index (the stages return natural order), the others from
+    // the column.  3D: (kx, ky, kz) = (point, column / zc, column % zc); 2D (geometry (1, nx, ny): the transformed axis is
+    // the fields' first one, LUT "X"): (point, column)
     const R *cX = (const R *)o.cosX, *sX = (const R *)o.sinX, *cY = (const R *)o.cosY, *sY = (const R *)o.sinY,
             *cZ = (const R *)o.cosZ, *sZ = (const R *)o.sinZ;
     const R scale = (R)o.scale;
@@ -524,16 +526,26 @@ __global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spe
         const int kx = (int)o.dLc.div((uint32_t)i), j = i - kx * Lc;
         if (j < ncol) {
             const uint32_t col = c0 + (uint32_t)j;
-            const uint32_t ky = o.dzc.div(col), kz = col - ky * o.zc;
-            FluidBin3<R, INV> op;
-            op.setup(cX[kx], cY[ky], cZ[kz], sX[kx], sY[ky], sZ[kz], o.alpha, o.beta, o.gamma);
-            C *q = res + (size_t)kx * Lp + 3 * j;
-            C A = q[0], B = q[1], Cc = q[2];
-            op.apply(A.re, B.re, Cc.re);
-            op.apply(A.im, B.im, Cc.im);
-            q[0] = C{A.re * scale, A.im * scale};   // scale == 1 is a bitwise no-op (as in the operator kernel)
-            q[1] = C{B.re * scale, B.im * scale};
-            q[2] = C{Cc.re * scale, Cc.im * scale};
+            C *q = res + (size_t)kx * Lp + DIM * j;
+            if constexpr (DIM == 3) {
+                const uint32_t ky = o.dzc.div(col), kz = col - ky * o.zc;
+                FluidBin3<R, INV> op;
+                op.setup(cX[kx], cY[ky], cZ[kz], sX[kx], sY[ky], sZ[kz], o.alpha, o.beta, o.gamma);
+                C A = q[0], B = q[1], Cc = q[2];
+                op.apply(A.re, B.re, Cc.re);
+                op.apply(A.im, B.im, Cc.im);
+                q[0] = C{A.re * scale, A.im * scale};   // scale == 1 is a bitwise no-op (as in the operator kernel)
+                q[1] = C{B.re * scale, B.im * scale};
+                q[2] = C{Cc.re * scale, Cc.im * scale};
+            } else {
+                FluidBin2<R, INV> op;
+                op.setup(cX[kx], cY[col], sX[kx], sY[col], o.alpha, o.beta, o.gamma);
+                C A = q[0], B = q[1];
+                op.apply(A.re, B.re);
+                op.apply(A.im, B.im);
+                q[0] = C{A.re * scale, A.im * scale};
+                q[1] = C{B.re * scale, B.im * scale};
+            }
         }
     }
     // the inverse transform on the conjugate roots (run_stages begins with a barrier: the operator's writes and these)
@@ -541,10 +553,10 @@ __global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spe
     for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, +1);
     C *other = res == x ? y : x;
     res = run_stages<R, RMAX>(res, other, W, a, N, +1, nl);
-    for (int i = threadIdx.x; i < 3 * N * Lc; i += kBlock) {
+    for (int i = threadIdx.x; i < DIM * N * Lc; i += kBlock) {
         const int r = (int)o.dLc.div((uint32_t)i), j = i - r * Lc;
         const int c = (int)a.dN.div((uint32_t)r), pt = r - c * N;
-        if (j < ncol) base[(size_t)c * planeC + (size_t)pt * o.cols + j] = res[(size_t)pt * Lp + 3 * j + c];
+        if (j < ncol) base[(size_t)c * planeC + (size_t)pt * o.cols + j] = res[(size_t)pt * Lp + DIM * j + c];
     }
 }
 
@@ -820,9 +832,11 @@ void tune_generic_fuse(int on) { g_generic_fuse = on ? 1 : 0; }
 // lines, lengths whose three-component chunk does not fit the LDS).
 template <typename R>
 static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, const R *cosY, const R *sinY, const R *cosZ,
-                    const R *sinZ, double alpha, double beta, double gamma, int64_t nn, int64_t X, int64_t Y, int64_t zc,
+                    const R *sinZ, double alpha, double beta, double gamma, int dim, int64_t nn, int64_t X, int64_t Y, int64_t zc,
                     double scale, hipStream_t s) {
-    const int N = (int)X;
+    // 3D: lines along X, columns (y, z-bin).  2D (geometry (1, nx, ny)): lines along Y = the fields' first axis, columns z-bin
+    const int N = (int)(dim == 3 ? X : Y);
+    if (dim == 2) Y = 1;
     if (N < 2 || largest_prime_factor(N) >= 29) return 1;
     {   // a factor 11 or 13 beside powers of two only takes the 155 - 164-register instantiation of the stages: with three
         // components' lines per workgroup on top it loses to the separate passes (182 x 218 x 182: +1.6 %)
@@ -849,7 +863,7 @@ static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, cons
     a.bhat = nullptr;
     a.inplace = 0;
     const size_t cb = 2 * sizeof(R);
-    auto lds = [&](int lc) { return ((size_t)2 * ((3 * lc) | 1) + 1) * N * cb; };
+    auto lds = [&](int lc) { return ((size_t)2 * ((dim * lc) | 1) + 1) * N * cb; };
     // columns per workgroup: FEW -- three (float64) or four (float32) adjacent columns, 48 / 32 B, within 40 KB of LDS, so
     // that four and more of these long-lived workgroups (load, forward stages, operator, inverse stages, store) share a CU.
     // Measured (tools/time_generic_fuse.py with the column count forced, profiles/r06_generic_fuse.md): float64 128^3
@@ -859,7 +873,7 @@ static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, cons
     while (Lc > 1 && lds(Lc) > 40 * 1024) --Lc;
     if (lds(Lc) > 160 * 1024) return 1;
     if ((uint64_t)Lc > cols) Lc = (int)cols;
-    a.L = 3 * Lc;
+    a.L = dim * Lc;
     a.Lp = a.L | 1;
     a.ppp = 0;
     a.chunks = 0;
@@ -892,7 +906,8 @@ static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, cons
     const size_t smem = lds(Lc);
 #define LAGO_XOP(RM)                                                                                                 \
     do {                                                                                                             \
-        auto k = inverse ? fft_xop_kernel<R, RM, true> : fft_xop_kernel<R, RM, false>;                               \
+        auto k = dim == 3 ? (inverse ? fft_xop_kernel<R, RM, true, 3> : fft_xop_kernel<R, RM, false, 3>)             \
+                          : (inverse ? fft_xop_kernel<R, RM, true, 2> : fft_xop_kernel<R, RM, false, 2>);            \
         if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, a, o);                              \
     } while (0)
@@ -914,27 +929,41 @@ int fluid_metric_generic(R *out, const R *m, R *work, int inverse, const R *cosX
     GC<R> *spec = reinterpret_cast<GC<R> *>(work);
     int rc = lines_pass<R>(spec, m, nullptr, (int)Z, 1, (uint64_t)(X * Y), (uint64_t)planes, -1, 1, s);
     if (rc != LAGO_OK) return rc;
-    rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, -1, 0, s);
-    if (rc != LAGO_OK) return rc;
     const double scale = 1.0 / ((double)X * (double)Y * (double)Z);
+    // The last forward transform, the operator and the first inverse transform in one launch where the length allows
+    // (fft_xop_kernel): along x in 3D, along y -- the fields' first axis -- in 2D.
     bool fused = false;
-    if (dim == 3 && g_generic_fuse) {   // x forward + operator + x inverse in one launch where the length allows
-        rc = xop_pass<R>(spec, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, nn, X, Y, zc, scale, s);
+    if (dim == 3) {
+        rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, -1, 0, s);
+        if (rc != LAGO_OK) return rc;
+    }
+    if (g_generic_fuse) {
+        rc = xop_pass<R>(spec, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, X, Y, zc, scale, s);
         if (rc < 0 || rc > 1) return rc;
         fused = rc == LAGO_OK;
     }
     if (!fused) {
-    rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, -1, 0, s);
-    if (rc != LAGO_OK) return rc;
-    const int64_t cx = nx, cy = dim == 2 ? ny / 2 + 1 : ny, cz = dim == 3 ? nz / 2 + 1 : 1;
-    rc = fluid_operator_impl<R>(work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, cx, cy, cz,
-                                (void *)s, scale);
-    if (rc != LAGO_OK) return rc;
-    rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, +1, 0, s);
-    if (rc != LAGO_OK) return rc;
+        if (dim == 2) {
+            rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, -1, 0, s);
+            if (rc != LAGO_OK) return rc;
+        }
+        rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, -1, 0, s);
+        if (rc != LAGO_OK) return rc;
+        const int64_t cx = nx, cy = dim == 2 ? ny / 2 + 1 : ny, cz = dim == 3 ? nz / 2 + 1 : 1;
+        rc = fluid_operator_impl<R>(work, inverse, cosX, sinX, cosY, sinY, cosZ, sinZ, alpha, beta, gamma, dim, nn, cx, cy, cz,
+                                    (void *)s, scale);
+        if (rc != LAGO_OK) return rc;
+        rc = lines_pass<R>(spec, nullptr, nullptr, (int)X, (uint64_t)(Y * zc), (uint64_t)(planes * Y * zc), 1, +1, 0, s);
+        if (rc != LAGO_OK) return rc;
+        if (dim == 2) {
+            rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, +1, 0, s);
+            if (rc != LAGO_OK) return rc;
+        }
     }
-    rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, +1, 0, s);
-    if (rc != LAGO_OK) return rc;
+    if (dim == 3) {
+        rc = lines_pass<R>(spec, nullptr, nullptr, (int)Y, (uint64_t)zc, (uint64_t)(planes * X * zc), 1, +1, 0, s);
+        if (rc != LAGO_OK) return rc;
+    }
     rc = lines_pass<R>(spec, nullptr, out, (int)Z, 1, (uint64_t)(X * Y), (uint64_t)planes, +1, 2, s);
     if (rc != LAGO_OK) return rc;
     return finish_launch(s, "fluid_metric");

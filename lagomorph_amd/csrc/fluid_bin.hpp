@@ -65,4 +65,38 @@ struct FluidBin3 {
     }
 };
 
+// the 2D operator (cuda/metric.cu:20-45, :80-101, :132-143, :162-218)
+template <typename R, bool INV>
+struct FluidBin2 {
+    R L00, L10, L11, ooG00, G10, ooG11;
+    __device__ __forceinline__ void setup(R wx, R wy, R sx, R sy, double alpha, double beta, double gamma) {
+        const R lambda = (R)__builtin_fma(alpha, (double)(wx + wy), gamma);
+        const R l00 = (R)__builtin_fma(-beta, (double)wx, (double)lambda);
+        const R l11 = (R)__builtin_fma(-beta, (double)wy, (double)lambda);
+        const R l10 = (R)(beta * (double)sx * (double)sy);
+        L00 = lg_fma(l00, l00, l10 * l10);
+        L10 = lg_fma(l00, l10, l10 * l11);
+        L11 = lg_fma(l11, l11, l10 * l10);
+        ooG00 = G10 = ooG11 = 0;
+        if (INV) {  // cuda/metric.cu:20-45
+            ooG00 = fb_recip_via_double(fb_safe_sqrt(L00));
+            G10 = L10 * ooG00;
+            ooG11 = lg_fma(-G10, G10, L11);
+            ooG11 = fb_recip_via_double(fb_safe_sqrt(ooG11));
+        }
+    }
+    __device__ __forceinline__ void apply(R &bX, R &bY) const {
+        if (INV) {  // cuda/metric.cu:80-101
+            R y0 = bX * ooG00;
+            R y1 = lg_fma(-G10, y0, bY) * ooG11;
+            bY = y1 * ooG11;
+            bX = lg_fma(-G10, bY, y0) * ooG00;
+        } else {  // cuda/metric.cu:132-143
+            R x = lg_fma(L00, bX, L10 * bY);
+            bY = lg_fma(L10, bX, L11 * bY);
+            bX = x;
+        }
+    }
+};
+
 }  // namespace lago

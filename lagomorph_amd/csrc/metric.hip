@@ -22,17 +22,6 @@ struct alignas(2 * sizeof(R)) Cplx {
 };
 
 // cuda/metric.cu:14-18
-template <typename R>
-__device__ __forceinline__ R safe_sqrt(R x) {
-    if ((double)x < 1e-8) return (R)1e-4;
-    return sizeof(R) == 4 ? (R)sqrtf((float)x) : (R)sqrt((double)x);  // correctly rounded (IEEE) forms
-}
-
-template <typename R>
-__device__ __forceinline__ R recip_via_double(R x) {  // `1./x` with x a Real: double division, narrowed
-    return (R)(1. / (double)x);
-}
-
 template <typename R, int DIM, bool INV>
 __global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm, const R *__restrict__ cosX,
                                                        const R *__restrict__ sinX, const R *__restrict__ cosY,
@@ -60,37 +49,15 @@ __global__ __launch_bounds__(kBlock) void fluid_kernel(Cplx<R> *__restrict__ Fm,
             F[2 * nv] = Cplx<R>{Z[0] * scale, Z[1] * scale};
         }
     } else {
-        const R wx = cosX[v.j], wy = cosY[v.k];
-        const R lambda = (R)__builtin_fma(alpha, (double)(wx + wy), gamma);
-        const R l00 = (R)__builtin_fma(-beta, (double)wx, (double)lambda);
-        const R l11 = (R)__builtin_fma(-beta, (double)wy, (double)lambda);
-        const R l10 = (R)(beta * (double)sinX[v.j] * (double)sinY[v.k]);
-        const R L00 = lg_fma(l00, l00, l10 * l10);
-        const R L10 = lg_fma(l00, l10, l10 * l11);
-        const R L11 = lg_fma(l11, l11, l10 * l10);
-        R ooG00 = 0, G10 = 0, ooG11 = 0;
-        if (INV) {  // cuda/metric.cu:20-45
-            ooG00 = recip_via_double(safe_sqrt(L00));
-            G10 = L10 * ooG00;
-            ooG11 = lg_fma(-G10, G10, L11);
-            ooG11 = recip_via_double(safe_sqrt(ooG11));
-        }
+        FluidBin2<R, INV> op;
+        op.setup(cosX[v.j], cosY[v.k], sinX[v.j], sinY[v.k], alpha, beta, gamma);
         for (int n = 0; n < nn; ++n, F += 2 * nv) {
             Cplx<R> a = F[0], b = F[nv];
             R X[2] = {a.re, a.im}, Y[2] = {b.re, b.im};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 R bX = X[q], bY = Y[q];
-                if (INV) {  // cuda/metric.cu:80-101
-                    R y0 = bX * ooG00;
-                    R y1 = lg_fma(-G10, y0, bY) * ooG11;
-                    bY = y1 * ooG11;
-                    bX = lg_fma(-G10, bY, y0) * ooG00;
-                } else {  // cuda/metric.cu:132-143
-                    R x = lg_fma(L00, bX, L10 * bY);
-                    bY = lg_fma(L10, bX, L11 * bY);
-                    bX = x;
-                }
+                op.apply(bX, bY);
                 X[q] = bX; Y[q] = bY;
             }
             F[0] = Cplx<R>{X[0] * scale, X[1] * scale};

@@ -16,12 +16,14 @@ g = torch.Generator(device="cuda").manual_seed(3)
 cases = [((128, 128, 128), 8, torch.float64), ((160, 160, 160), 4, torch.float64), ((64, 48, 80), 4, torch.float64),
          ((33, 29, 31), 4, torch.float64), ((182, 218, 182), 1, torch.float32), ((100, 120, 60), 4, torch.float32),
          ((120, 120, 120), 8, torch.float32), ((176, 208, 176), 1, torch.float32), ((91, 77, 55), 2, torch.float32),
-         ((7, 9, 6), 3, torch.float64), ((2, 3, 4), 2, torch.float32), ((59, 64, 64), 2, torch.float32), ((128, 128, 128), 8, torch.float32)]
+         ((7, 9, 6), 3, torch.float64), ((2, 3, 4), 2, torch.float32), ((59, 64, 64), 2, torch.float32), ((128, 128, 128), 8, torch.float32),
+         ((256, 256), 8, torch.float32), ((256, 256), 8, torch.float64), ((100, 90), 4, torch.float32), ((33, 21), 3, torch.float64),
+         ((512, 384), 4, torch.float32), ((26, 30), 2, torch.float32), ((59, 40), 2, torch.float64)]
 bad = 0
 for sp, B, dt in cases:
     for params in ([0.1, 0.0, 0.01], [0.1, 0.05, 0.01]):
         met = lm.FluidMetric(params)
-        x = torch.randn((B, 3) + sp, device="cuda", generator=g, dtype=dt)
+        x = torch.randn((B, len(sp)) + sp, device="cuda", generator=g, dtype=dt)
         res, tim, paths = {}, {}, {}
         with torch.no_grad():
             for mode in (3, 4):
