@@ -485,7 +485,8 @@ __global__ __launch_bounds__(kBlock) void fft_lines_kernel(GC<R> *__restrict__ s
 // workgroup takes L adjacent (y, z-bin) columns of one batch item, all three components: 3 L lines in LDS, line index
 // 3 j + c (a column's components adjacent, so the valid lines of a ragged last chunk are contiguous).  The stages are
 // those of fft_lines_kernel (run_stages on the same roots), the operator is fluid_bin.hpp's: the bits of the three
-// separate launches.  Lengths that run as Bluestein convolutions or in place keep the separate passes (host).
+// separate launches.  Lengths that run as Bluestein convolutions keep the separate passes (host); power-of-two lines of 256
+// points and more run their stages in place (INPL: one line buffer, twice the adjacent columns in the same LDS).
 struct XopArgs {
     const void *cosX, *sinX, *cosY, *sinY, *cosZ, *sinZ;
     double alpha, beta, gamma, scale;
@@ -496,12 +497,12 @@ struct XopArgs {
     int Lc;             // columns per workgroup (a.L = 3 Lc lines)
 };
 
-template <typename R, int RMAX, bool INV, int DIM>
+template <typename R, int RMAX, bool INV, int DIM, bool INPL = false>
 __global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spec, GLines a, XopArgs o) {
     extern __shared__ __align__(16) unsigned char lago_fg[];
     typedef GC<R> C;
     const int N = a.N, Lp = a.Lp, Lc = o.Lc;
-    C *x = reinterpret_cast<C *>(lago_fg), *y = x + (size_t)Lp * N, *W = y + (size_t)Lp * N;
+    C *x = reinterpret_cast<C *>(lago_fg), *y = INPL ? x : x + (size_t)Lp * N, *W = y + (size_t)Lp * N;
     const uint32_t n = o.dchunks.div(blockIdx.x);
     const uint32_t c0 = (blockIdx.x - n * o.chunks) * (uint32_t)Lc;      // first column
     const int ncol = (int)min((uint32_t)Lc, o.cols - c0);
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spe
         if (j < ncol) x[(size_t)pt * Lp + DIM * j + c] = base[(size_t)c * planeC + (size_t)pt * o.cols + j];
     }
     for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, -1);
-    C *res = run_stages<R, RMAX>(x, y, W, a, N, -1, nl);
+    C *res = run_stages<R, RMAX, INPL>(x, y, W, a, N, -1, nl);
     // operator: the frequency along the transformed axis = point index (the stages return natural order), the others from
     // the column.  3D: (kx, ky, kz) = (point, column / zc, column % zc); 2D (geometry (1, nx, ny): the transformed axis is
     // the fields' first one, LUT "X"): (point, column)
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void fft_xop_kernel(GC<R> *__restrict__ spe
     __syncthreads();
     for (int k = threadIdx.x; k < N; k += kBlock) W[k] = root<R>(k, N, +1);
     C *other = res == x ? y : x;
-    res = run_stages<R, RMAX>(res, other, W, a, N, +1, nl);
+    res = run_stages<R, RMAX, INPL>(res, other, W, a, N, +1, nl);
     for (int i = threadIdx.x; i < DIM * N * Lc; i += kBlock) {
         const int r = (int)o.dLc.div((uint32_t)i), j = i - r * Lc;
         const int c = (int)a.dN.div((uint32_t)r), pt = r - c * N;
@@ -871,7 +872,23 @@ static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, cons
     // -7.0 / +13.8 / +5.9 %, float32 120^3 +3.9 / +0.8 / -9.5 / -7.9 / -7.4 %.
     int Lc = sizeof(R) == 8 ? 3 : 4;
     while (Lc > 1 && lds(Lc) > 40 * 1024) --Lc;
-    if (lds(Lc) > 160 * 1024) return 1;
+    // lines of 256 points and more, power-of-two: the stages IN PLACE (stage_inplace: one line buffer, half the LDS per column)
+    // with up to 96 B of adjacent columns within 84 KB.  Measured against the ping-pong form above (tools/sweep_xop_inplace.py,
+    // profiles/r06_xop_inplace.md): float64 256 x 128 x 128 -20 % (6 columns), float64 512^2 -24 % (4), float32 1024^2 -30 %
+    // (4), float32 256^2 -12 % (12); 128- and 64-point lines gain nothing at any column count (+2 ... -4 %) and keep it.
+    auto ldsi = [&](int lc) { return ((size_t)((dim * lc) | 1) + 1) * N * cb; };
+    bool inpl = false;
+    if (N >= 256) {
+        bool p2 = true;
+        for (int f = 0; f < a.nfac; ++f) p2 = p2 && (a.fac[f] == 2 || a.fac[f] == 4 || a.fac[f] == 8);
+        int Li = (int)(96 / cb);
+        while (Li > 1 && (dim * Li * N > 8192 || ldsi(Li) > 84 * 1024)) --Li;   // (stage_inplace: L N <= 8192)
+        if (p2 && Li >= 2 && dim * Li * N <= 8192 && ldsi(Li) <= 84 * 1024) {
+            Lc = Li;
+            inpl = true;
+        }
+    }
+    if ((inpl ? ldsi(Lc) : lds(Lc)) > 160 * 1024) return 1;
     if ((uint64_t)Lc > cols) Lc = (int)cols;
     a.L = dim * Lc;
     a.Lp = a.L | 1;
@@ -903,7 +920,15 @@ static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, cons
     o.Lc = Lc;
     const uint64_t grid = (uint64_t)nn * o.chunks;
     if (grid >= (1ull << 31)) return 1;
-    const size_t smem = lds(Lc);
+    const size_t smem = inpl ? ldsi(Lc) : lds(Lc);
+    a.inplace = inpl ? 1 : 0;
+#define LAGO_XOP_I()                                                                                                 \
+    do {                                                                                                             \
+        auto k = dim == 3 ? (inverse ? fft_xop_kernel<R, 4, true, 3, true> : fft_xop_kernel<R, 4, false, 3, true>)   \
+                          : (inverse ? fft_xop_kernel<R, 4, true, 2, true> : fft_xop_kernel<R, 4, false, 2, true>);  \
+        if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, a, o);                              \
+    } while (0)
 #define LAGO_XOP(RM)                                                                                                 \
     do {                                                                                                             \
         auto k = dim == 3 ? (inverse ? fft_xop_kernel<R, RM, true, 3> : fft_xop_kernel<R, RM, false, 3>)             \
@@ -911,10 +936,12 @@ static int xop_pass(GC<R> *spec, int inverse, const R *cosX, const R *sinX, cons
         if (smem > 64 * 1024) LAGO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kBlock), smem, s, spec, a, o);                              \
     } while (0)
-    if (pow2) LAGO_XOP(4);
+    if (pow2 && inpl) LAGO_XOP_I();
+    else if (pow2) LAGO_XOP(4);
     else if (r13 && !odd_small) LAGO_XOP(13);
     else LAGO_XOP(7);
 #undef LAGO_XOP
+#undef LAGO_XOP_I
     return LAGO_OK;
 }
 

@@ -81,13 +81,15 @@ def test_first_euler_step_uses_the_scaled_operator():
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("sp,B", [((64, 48, 80), 3), ((33, 29, 31), 2), ((100, 120, 60), 2), ((91, 77, 55), 2), ((7, 9, 6), 3),
                                   ((2, 3, 4), 2), ((59, 64, 64), 2), ((128, 30, 34), 2), ((26, 40, 44), 1),
-                                  ((256, 192), 3), ((100, 90), 2), ((33, 21), 3), ((59, 40), 2), ((26, 30), 2), ((5, 4), 2)])
+                                  ((256, 192), 3), ((512, 40), 2), ((1024, 24), 2), ((2048, 10), 1), ((256, 14, 18), 2), ((512, 6, 10), 1),
+                                  ((100, 90), 2), ((33, 21), 3), ((59, 40), 2), ((26, 30), 2), ((5, 4), 2)])
 def test_generic_passes_fused_x_pass_has_the_bits_of_the_separate_launches(sp, B, dtype):
     """csrc/fftg.hip: fft_xop_kernel (x forward + operator + x inverse in one launch, round 6; `fluid_mode` 3) against the three
     separate launches (`fluid_mode` 4) on the generic path: the same stages on the same roots and the operator of
     fluid_bin.hpp, hence the same bits -- sharp and flat, with and without the beta term, 3D (along x) and 2D (along the
     fields' first axis); lengths with a prime factor of 29
-    or more (59: a Bluestein line) and the radix-13 instantiation (26 = 2 x 13) keep the separate launches in both modes."""
+    or more (59: a Bluestein line) and the radix-13 instantiation (26 = 2 x 13) keep the separate launches in both modes;
+    power-of-two lines of 256 ... 1024 points run the fused pass with in-place stages (2048: one column only, ping-pong)."""
     import lagomorph_amd as lm
 
     ext = lm.lagomorph_ext

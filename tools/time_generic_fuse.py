@@ -14,8 +14,10 @@ ext = lm.lagomorph_ext
 g = torch.Generator(device="cuda").manual_seed(3)
 met = lm.FluidMetric([0.1, 0.0, 0.01])
 for sp, B, dt in (((128, 128, 128), 8, torch.float64), ((160, 160, 160), 4, torch.float64), ((120, 120, 120), 8, torch.float32),
-                  ((182, 218, 182), 2, torch.float32), ((100, 120, 60), 8, torch.float32), ((96, 96, 96), 8, torch.float64)):
-    x = torch.randn((B, 3) + sp, device="cuda", generator=g, dtype=dt)
+                  ((182, 218, 182), 2, torch.float32), ((100, 120, 60), 8, torch.float32), ((96, 96, 96), 8, torch.float64),
+                  ((256, 128, 128), 4, torch.float64), ((1024, 1024), 16, torch.float32), ((512, 512), 32, torch.float64),
+                  ((256, 256), 64, torch.float32)):
+    x = torch.randn((B, len(sp)) + sp, device="cuda", generator=g, dtype=dt)
     t = {3: [], 4: []}
     with torch.no_grad():
         for rep in range(5):
