@@ -4,7 +4,7 @@
 //
 //   zy_forward_kernel : grid = nn*3*nx planes, 512 threads, LDS = ny*(nz/2+1)*8 B (planes below 80 KB: two per CU);
 //                       zy_forward_persist_kernel: one persistent 1024-thread workgroup per CU for larger planes
-//   fluid_xpass2_kernel: grid = nn*(ny*(nz/32) + ny/16) tiles of 3 x nx x 16 bins, 256 threads;
+//   fluid_xpass2_kernel: grid = nn*(ny*nz/32 + ny/16) tiles of 3 x nx x 16 bins, 256 threads;
 //                       fluid_xpass2_persist_kernel: two persistent workgroups per CU once the launch is large
 //   zy_inverse_kernel : grid = nn*3*nx planes (and its persistent form)
 //
@@ -27,6 +27,11 @@ template <> struct SzOf<128> { using T = fl::Sz<1, 7>; };
 template <> struct SzOf<160> { using T = fl::Sz<5, 5>; };
 template <> struct SzOf<192> { using T = fl::Sz<3, 6>; };
 template <> struct SzOf<256> { using T = fl::Sz<1, 8>; };
+// 176 = 11 * 16 and 208 = 13 * 16 (half lengths 88, 104): the 176 x 208 x 176 volumes of the OASIS brain images (round 6)
+template <> struct SzOf<88> { using T = fl::Sz<11, 3>; };
+template <> struct SzOf<104> { using T = fl::Sz<13, 3>; };
+template <> struct SzOf<176> { using T = fl::Sz<11, 4>; };
+template <> struct SzOf<208> { using T = fl::Sz<13, 4>; };
 
 template <int NY, int NZ>
 using ZYK = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T>;
@@ -264,7 +269,7 @@ static hipError_t fluid2d_launch(float *out, const float *m, int inverse, const 
                                  const float *cosY, const float *sinY, double alpha, double beta, double gamma,
                                  int64_t nn, hipStream_t s, float oscale) {
     using K = ZYK2D<NY, NZ>;
-    constexpr size_t smem = (size_t)(2 * NY * K::PZ + K::LTW) * sizeof(float2);
+    constexpr size_t smem = (size_t)(2 * NY * K::PZ + K::TWN) * sizeof(float2);
     static_assert(smem <= 160 * 1024, "two planes do not fit the LDS");
     const float scale = (float)(1.0 / ((double)NY * (double)NZ));
     if (inverse) {
@@ -380,8 +385,9 @@ __global__ __launch_bounds__(NT) void fluid_xpass2_persist_kernel(fl::XArgs a) {
     X(64, 64) X(64, 96) X(64, 128) X(64, 160) X(64, 192) X(96, 64) X(96, 96) X(96, 128) X(96, 160) X(96, 192)      \
     X(128, 64) X(128, 96) X(128, 128) X(128, 160) X(128, 192) X(160, 64) X(160, 96) X(160, 128) X(160, 160) X(160, 192) \
     X(192, 64) X(192, 96) X(192, 128) X(192, 160) X(192, 192)                                          \
-    X(32, 64) X(32, 128) X(32, 256) X(64, 256) X(128, 256) X(256, 64) X(256, 128)
-#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256)
+    X(32, 64) X(32, 128) X(32, 256) X(64, 256) X(128, 256) X(256, 64) X(256, 128)                      \
+    X(208, 176) X(176, 176) X(176, 208)
+#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256) X(176) X(208)
 
 bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz) {
     bool okx = false, okyz = false;
@@ -513,7 +519,7 @@ std::atomic<int> g_native_stage_mask{7};
 int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
                         int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s, float oscale) {
     const int64_t nzh = nz / 2, planes = nn * 3 * nx;
-    const int64_t items = ny * (nzh / 16) + ny / 16;
+    const int64_t items = ny * nzh / 16 + ny / 16;   // tiles of 16 consecutive (r, q) positions + the Nyquist plane's
     if (planes >= (1ll << 31) || nn * items >= (1ll << 31)) return fail_invalid("fluid_metric: batch too large");
     fl::ZYArgs za;
     za.in = m;
@@ -529,7 +535,7 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     xa.tabN = tab + (size_t)nx * ny * nzh * 6;
     xa.ny = (int)ny;
     xa.nzh = (int)nzh;
-    xa.nch = (int)(nzh / 16);
+    xa.nch = (int)(ny * nzh / 16);
     xa.items_per_n = (int)items;
     xa.scale = (float)scale;
     xa.nn = (int)nn;

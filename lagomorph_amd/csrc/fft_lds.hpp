@@ -119,7 +119,8 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 
-// A transform length N = R * 2^L2 with R in {1, 3, 5} (64, 96, 128, 160, 192, 256, ...).
+// A transform length N = R * 2^L2 with R in {1, 3, 5, 7, 11, 13} (64, 96, 128, 160, 192, 256, ...; 176 = 11 * 16 and
+// 208 = 13 * 16: the 176 x 208 x 176 brain volumes of the OASIS images, round 6).
 // Forward = decimation in frequency: one radix-R level (R > 1), then the radix-2 levels of the R sub-transforms of
 // 2^L2 points, up to four at a time in registers (stage plan below).  Frequency k = R*k2 + k1 ends up at position
 // k1*2^L2 + bitrev(k2): the order is never undone, in LDS or in memory.  Inverse = the same data
@@ -127,7 +128,7 @@ constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 template <int R_, int L2_>
 struct Sz {
     static constexpr int R = R_, L2 = L2_, M = 1 << L2_, N = R_ * (1 << L2_);
-    static_assert(R_ == 1 || R_ == 3 || R_ == 5, "radix 1, 3 or 5 times a power of two");
+    static_assert(R_ == 1 || R_ == 3 || R_ == 5 || R_ == 7 || R_ == 11 || R_ == 13, "radix 1, 3, 5, 7, 11 or 13 times a power of two");
 };
 template <class S>
 LAGO_HD int pos_of(int k) {  // position of frequency k after the forward transform
@@ -145,7 +146,7 @@ LAGO_HD int freq_at(int p) {  // frequency held at position p
 // radix-R level takes the top radix-2 level with it (a radix-2R stage on 2R points).  80 = 5*16, 128 and 160 points are
 // two stages, 64 two, 256 two -- every stage is one read and one write of the tile in LDS, which is what the passes
 // are bound by once their HBM traffic is hidden (tools/probes/zy_probe.hip).
-constexpr bool plan_fuse(int r, int l2) { return r > 1 && l2 == 5; }
+constexpr bool plan_fuse(int r, int l2) { return (r == 3 || r == 5) && l2 == 5; }
 constexpr int plan_lr(int r, int l2) { return l2 - (plan_fuse(r, l2) ? 1 : 0); }      // radix-2 levels left to the groups
 constexpr int group_count(int lr) { return (lr + 3) / 4; }
 constexpr int group_s(int lr, int g) {       // levels of group g: as even as possible, the larger groups first
@@ -237,6 +238,62 @@ LAGO_HD void radix2_stage(float2 *buf, const float2 *tw, int tid) {
     }
 }
 
+// cos / sin of 2 pi m / R for the odd radices 7, 11, 13 (m is a constant after unrolling: the chains fold away)
+template <int R>
+LAGO_HD constexpr float odd_cos(int m) {
+    const int h = m > R / 2 ? R - m : m;
+    if (h == 0) return 1.0f;
+    if (R == 7) return h == 1 ? 0.62348980185873348336f : h == 2 ? -0.22252093395631439288f : -0.90096886790241914600f;
+    if (R == 11)
+        return h == 1 ? 0.84125353283118120551f : h == 2 ? 0.41541501300188643508f : h == 3 ? -0.14231483827328514358f
+             : h == 4 ? -0.65486073394528510061f : -0.95949297361449736865f;
+    return h == 1 ? 0.88545602565320991051f : h == 2 ? 0.56806474673115581187f : h == 3 ? 0.12053668025532304764f
+         : h == 4 ? -0.35460488704253562142f : h == 5 ? -0.74851074817110108128f : -0.97094181742605201180f;
+}
+template <int R>
+LAGO_HD constexpr float odd_sin(int m) {
+    const int h = m > R / 2 ? R - m : m;
+    const float sg = m > R / 2 ? -1.0f : 1.0f;
+    if (h == 0) return 0.0f;
+    if (R == 7) return sg * (h == 1 ? 0.78183148246802980363f : h == 2 ? 0.97492791218182361934f : 0.43388373911755812040f);
+    if (R == 11)
+        return sg * (h == 1 ? 0.54064081745559755543f : h == 2 ? 0.90963199535451833011f : h == 3 ? 0.98982144188093268422f
+                   : h == 4 ? 0.75574957435425826890f : 0.28173255684142967104f);
+    return sg * (h == 1 ? 0.46472317204376856203f : h == 2 ? 0.82298386589365635224f : h == 3 ? 0.99270887409805397272f
+               : h == 4 ? 0.93501624268541483342f : h == 5 ? 0.66312265824079519305f : 0.23931566428755776665f);
+}
+// R-point DFT, R = 7, 11, 13, through the symmetric pairs a_j = x_j + x_(R-j), b_j = x_j - x_(R-j):
+// y_k = x_0 + sum_j cos(2 pi j k / R) a_j -+ i sum_j sin(2 pi j k / R) b_j, y_(R-k) its mirror: (R - 1)^2 multiply-adds
+template <int R, int SGN>
+LAGO_HD void dft_odd(float2 *v) {
+    constexpr int H = (R - 1) / 2;
+    float2 a[H], b[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+        a[j - 1] = make_float2(v[j].x + v[R - j].x, v[j].y + v[R - j].y);
+        b[j - 1] = make_float2(v[j].x - v[R - j].x, v[j].y - v[R - j].y);
+    }
+    const float2 x0 = v[0];
+    float2 s = x0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) s = make_float2(s.x + a[j].x, s.y + a[j].y);
+    v[0] = s;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        float2 e = x0, o = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            const int m = (j * k) % R;
+            const float c = odd_cos<R>(m), sn = odd_sin<R>(m);
+            e = make_float2(fmaf(c, a[j - 1].x, e.x), fmaf(c, a[j - 1].y, e.y));
+            o = make_float2(fmaf(sn, b[j - 1].x, o.x), fmaf(sn, b[j - 1].y, o.y));
+        }
+        const float2 jv = SGN < 0 ? make_float2(o.y, -o.x) : make_float2(-o.y, o.x);   // -+ i o
+        v[k] = make_float2(e.x + jv.x, e.y + jv.y);
+        v[R - k] = make_float2(e.x - jv.x, e.y - jv.y);
+    }
+}
+
 // R-point DFT of v[0..R) in place; SGN = -1 forward (exp(-2 pi i r k / R)), +1 inverse
 template <int R, int SGN>
 LAGO_HD void dft_small(float2 *v) {
@@ -265,6 +322,8 @@ LAGO_HD void dft_small(float2 *v) {
         v[4] = make_float2(e1.x - j1.x, e1.y - j1.y);
         v[2] = make_float2(e2.x + j2.x, e2.y + j2.y);
         v[3] = make_float2(e2.x - j2.x, e2.y - j2.y);
+    } else if constexpr (R > 5) {
+        dft_odd<R, SGN>(v);
     }
 }
 
@@ -399,7 +458,7 @@ LAGO_HD void fluid_bin(const float *c, float2 &X, float2 &Y, float2 &Z, float sc
 struct XArgs {
     float2 *main_, *nyq;        // split spectrum (see the header comment)
     const float *tabM, *tabN;   // coefficients [kx][r][q < nzh][6] and [kx][r][6], (r, q) as in the spectrum
-    int ny, nzh, nch, items_per_n;
+    int ny, nzh, nch, items_per_n;   // nch = ny * nzh / 16 tiles of the main block, items_per_n = nch + ny / 16
     int nn, ipw;                // batch size; batch items one workgroup runs through with the same coefficients
     float scale;
     uint32_t total;             // ceil(nn / ipw) * items_per_n workgroups
@@ -412,10 +471,12 @@ struct XPass {
     using T = Xf<SX, KCP, 1, KL, 3, NX * KCP, NX, NT>;
     static constexpr int G = stage_count<SX>();
     static constexpr int NPH = 2 * G + 3;  // load | G forward stages | operator | G inverse stages | store
-    static constexpr int ROWS_IT = NT / 8, KLD = 3 * NX / ROWS_IT;  // float4 loads: 8 lanes per 16-bin row
+    static constexpr int ROWS_IT = NT / 8, KLD = (3 * NX + ROWS_IT - 1) / ROWS_IT;  // float4 loads: 8 lanes per 16-bin row
+    static constexpr bool RAGGED = 3 * NX % ROWS_IT != 0;           // (176 and 208 points: the last pass is guarded)
     static constexpr int RG = NT / KL, NOP = NX / RG;               // operator: NOP bins per thread
     static constexpr size_t SMEM = (size_t)(3 * NX * KCP + NX) * sizeof(float2);
-    static_assert(3 * NX % ROWS_IT == 0 && NX % RG == 0, "tile does not divide over the threads");
+    static_assert(NX % RG == 0, "tile does not divide over the threads");
+    LAGO_HD static bool row_ok(int rg, int k) { return !RAGGED || rg + k * ROWS_IT < 3 * NX; }
 
     struct Block {  // workgroup-uniform
         float2 *base;
@@ -429,13 +490,15 @@ struct XPass {
         return locate(a, blk / (uint32_t)a.items_per_n * (uint32_t)a.ipw, blk % (uint32_t)a.items_per_n);
     }
     LAGO_HD static Block locate(const XArgs &a, uint32_t n, uint32_t item) {   // batch item n, bin tile `item`
-        const uint32_t nmain = (uint32_t)a.ny * a.nch;
+        // the (r, q) positions of one x are contiguous in memory: a tile is 16 consecutive positions of that run (16 kz of
+        // one ky where nzh is a multiple of 16; the tiles of an 88-bin row straddle rows -- the pass does not care which
+        // bins it holds, the coefficient table is laid out the same way)
+        const uint32_t nmain = (uint32_t)a.nch;
         Block b;
         if (item < nmain) {
-            const uint32_t ky = item / (uint32_t)a.nch, ch = item % (uint32_t)a.nch;
             b.xs = (size_t)a.ny * a.nzh;
-            b.base = a.main_ + (size_t)n * 3 * NX * b.xs + (size_t)ky * a.nzh + ch * KL;
-            b.tb = a.tabM + ((size_t)ky * a.nzh + ch * KL) * 6;
+            b.base = a.main_ + (size_t)n * 3 * NX * b.xs + (size_t)item * KL;
+            b.tb = a.tabM + (size_t)item * KL * 6;
             b.tks = b.xs * 6;
         } else {
             const uint32_t j = item - nmain;
@@ -451,7 +514,7 @@ struct XPass {
     // persistent workgroup can request its next tile while it transforms the current one (fft3.hip).
     LAGO_HD static void load_one(int tid, const Block &b, float4 (&v)[KLD], int k) {
         const int rg = tid >> 3, l8 = tid & 7;
-        v[k] = ldg4<LAGO_NT_X_LD>(reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8));
+        if (row_ok(rg, k)) v[k] = ldg4<LAGO_NT_X_LD>(reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8));
     }
     LAGO_HD static void load_coef(int tid, Regs &r, const Block &b) {
         const int kc = tid & (KL - 1), row0 = tid / KL;
@@ -470,6 +533,7 @@ struct XPass {
         const int rg = tid >> 3, l8 = tid & 7;
 #pragma unroll
         for (int k = 0; k < KLD; ++k) {
+            if (!row_ok(rg, k)) continue;
             float2 *d = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
             d[0] = make_float2(v[k].x, v[k].y);
             d[1] = make_float2(v[k].z, v[k].w);
@@ -510,6 +574,7 @@ struct XPass {
             const int rg = tid >> 3, l8 = tid & 7;
 #pragma unroll
             for (int k = 0; k < KLD; ++k) {
+                if (!row_ok(rg, k)) continue;
                 const float2 *s = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
                 const float2 a = s[0], c = s[1];
                 stg4<LAGO_NT_X_ST>(reinterpret_cast<float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8),
@@ -540,14 +605,17 @@ constexpr int zy_threads(int ny, int nzh) { return (size_t)ny * (nzh + 1) * 8 > 
 template <class SY, class SZH, int NT = zy_threads(SY::N, SZH::N)>
 struct ZY {
     static constexpr int NY = SY::N, NZH = SZH::N, NZ = 2 * NZH, PZ = NZH + 1;
-    static constexpr int LTW = clcm(NY, NZ);   // one table of LTW-th roots serves both axes and the real-FFT split
+    // one table of lcm(NY, NZ)-th roots serves both axes and the real-FFT split; where that table would push the plane
+    // over the 160 KB of LDS (208 x 176: lcm 2288) the axes take a table each, NZ-th roots followed by NY-th roots
+    static constexpr bool TW2 = (size_t)(NY * PZ + clcm(NY, NZ)) * sizeof(float2) > 160 * 1024;
+    static constexpr int LTW = TW2 ? NZ : clcm(NY, NZ), LTWY = TW2 ? NY : LTW, TWY0 = TW2 ? NZ : 0, TWN = TW2 ? NZ + NY : LTW;
     using TZ = Xf<SZH, 1, PZ, NY, 1, 0, LTW, NT>;   // along z, lanes over y
-    using TY = Xf<SY, PZ, 1, NZH, 1, 0, LTW, NT>;   // along y, lanes over kz
+    using TY = Xf<SY, PZ, 1, NZH, 1, 0, LTWY, NT>;  // along y, lanes over kz
     static constexpr int GZ = stage_count<SZH>(), GY = stage_count<SY>();
     static constexpr int NPH = GZ + GY + 4;  // load | stages | split | stages | unpack | store   (mirrored for the inverse)
     static constexpr int F4 = NY * NZH / 2;        // float4 (two complex) per plane
     static constexpr int KV = (F4 + NT - 1) / NT;  // ... per thread (the last pass is guarded)
-    static constexpr size_t SMEM = (size_t)(NY * PZ + LTW) * sizeof(float2);
+    static constexpr size_t SMEM = (size_t)(NY * PZ + TWN) * sizeof(float2);
     static constexpr int THREADS = NT;
     static_assert(KV >= 1 && NZH % 2 == 0, "rows must hold whole float4");
 
@@ -568,6 +636,7 @@ struct ZY {
 
     LAGO_HD static void fill_twiddles(int tid, float2 *tw) {
         for (int t = tid; t < LTW; t += NT) tw[t] = twiddle(t, LTW);
+        if (TW2) for (int t = tid; t < LTWY; t += NT) tw[TWY0 + t] = twiddle(t, LTWY);
     }
     // phase 0 in two halves -- the plane's global loads into registers, registers into the LDS plane -- so that a
     // persistent workgroup can request its next plane while it transforms the current one (fft3.hip)
@@ -659,7 +728,7 @@ struct ZY {
                 }
             }
         } else if (ph <= GZ + 1 + GY) {
-            run_stage<TY, true>(ph - GZ - 2, P, tw, tid);
+            run_stage<TY, true>(ph - GZ - 2, P, tw + TWY0, tid);
         } else if (ph == GZ + GY + 2) {
             // column 0 carried A + iB with A = X[0](y), B = X[NZH](y) both real: separate their
             // transforms FA(ky) = (P(ky) + conj P(-ky))/2, FB(ky) = -i (P(ky) - conj P(-ky))/2.
@@ -700,7 +769,7 @@ struct ZY {
             inv_load(tid, mainp, nyqp, v);
             inv_fill(tid, v, P);
         } else if (ph <= GY) {
-            run_stage<TY, false>(ph - 1, P, tw, tid);
+            run_stage<TY, false>(ph - 1, P, tw + TWY0, tid);
         } else if (ph == GY + 1) {
             // merge X back into the half-length transform (twice it: the missing factor 2 of the
             // real inverse): 2E = X[k] + conj X[NZH-k], 2O = (X[k] - conj X[NZH-k]) conj(w^k),

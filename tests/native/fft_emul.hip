@@ -118,7 +118,7 @@ static int run_case() {
     // x pass
     XArgs xa;
     xa.main_ = mainb; xa.nyq = nyqb; xa.tabM = tabP.data(); xa.tabN = tabP.data() + (size_t)NX * NY * NZH * 6;
-    xa.ny = NY; xa.nzh = NZH; xa.nch = NZH / 16; xa.items_per_n = NY * xa.nch + NY / 16;
+    xa.ny = NY; xa.nzh = NZH; xa.nch = NY * NZH / 16; xa.items_per_n = xa.nch + NY / 16;
     xa.nn = NN; xa.ipw = 1; xa.scale = scale; xa.total = (uint32_t)(NN * xa.items_per_n);
     std::vector<typename Xp::Regs> regs(256);
     for (uint32_t blk = 0; blk < xa.total; ++blk) {
@@ -185,6 +185,13 @@ int main() {
     bad += run_case<Sz<1, 8>, Sz<1, 5>, Sz<1, 5>, false>();   // 256 x 32 x 64
     bad += run_case<Sz<1, 5>, Sz<3, 6>, Sz<1, 7>, true>();    // 32 x 192 x 256
     bad += run_case<Sz<1, 5>, Sz<1, 7>, Sz<3, 5>, false>();   // 32 x 128 x 192
+    // radix 11 and 13 (176 = 11 * 16, 208 = 13 * 16; half lengths 88 = 11 * 8, 104 = 13 * 8): ragged x-pass rows, tiles of
+    // 16 positions that straddle the 88-bin rows, a twiddle table per axis where the common one does not fit (208 x 176)
+    bad += run_case<Sz<11, 4>, Sz<1, 5>, Sz<1, 5>, true>();    // 176 x 32 x 64
+    bad += run_case<Sz<13, 4>, Sz<1, 5>, Sz<11, 3>, false>();  // 208 x 32 x 176
+    bad += run_case<Sz<1, 5>, Sz<13, 4>, Sz<11, 3>, true>();   // 32 x 208 x 176
+    bad += run_case<Sz<1, 5>, Sz<11, 4>, Sz<13, 3>, false>();  // 32 x 176 x 208
+    bad += run_case<Sz<1, 5>, Sz<11, 4>, Sz<11, 3>, true>();   // 32 x 176 x 176
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }
