@@ -301,7 +301,7 @@ int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, 
 // threads per x-pass workgroup: 256, except for the 256-point tile (104 KB: one workgroup per CU, which 512 threads
 // serve 12 % faster).  Measured (tools/ab_fluid.py): wider workgroups LOSE 3-14 % at 128, 160 and 192 points, where
 // two or three 256-thread workgroups share a CU and their 120+ VGPRs per thread would cost the second one.
-template <int NX> constexpr int xpass_wide() { return NX >= 256 ? 512 : 256; }
+template <int NX> constexpr int xpass_wide() { return NX >= 256 || NX == 208 ? 512 : 256; }   // (208: 86 KB, alone on its CU as well)
 
 template <int NX, bool INV, int NT>
 __global__ __launch_bounds__(NT) void fluid_xpass2_kernel(fl::XArgs a) {
@@ -408,7 +408,7 @@ static hipError_t zy_launch(const fl::ZYArgs &a, bool inverse, hipStream_t s) {
     static_assert(K::SMEM <= 160 * 1024, "plane does not fit the LDS");
     // one workgroup per CU (plane above 80 KB) and the next plane's registers fit beside the transform's (not the
     // 256-point rows / columns, which spill): persistent grid with register prefetch
-    constexpr bool kPersist = K::SMEM > 80 * 1024 && K::KV <= 8 && NY < 256 && NZ < 256 && !(NY == 128 && NZ == 192);   // (128, 192: six full slots + the column-0 slot: 16 spilled registers)
+    constexpr bool kPersist = K::SMEM > 80 * 1024 && K::KV <= 9 && NY < 256 && NZ < 256 && !(NY == 128 && NZ == 192);   // (128, 192: six full slots + the column-0 slot: 16 spilled registers)
     if constexpr (kPersist) if (g_zy_persist) {
         const uint32_t grid = std::min<uint32_t>(a.total, 256u);
         if (inverse) {
@@ -458,7 +458,10 @@ static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t
     const int mode = g_xpass_persist;   // 2 (tests): whatever the size of the launch
     const uint32_t grid = (uint32_t)std::min<uint64_t>(256u * per_cu, pairs);
     // (192 points: 263 VGPRs, one 256-thread workgroup per CU -- stays with the one-shot workgroups)
-    const bool persist = mode && per_cu >= 2 && NX <= 160 && (mode >= 2 || pairs >= 8ull * grid) && pairs < (1ull << 32);
+    // (176 points: the one-shot kernel's 264 registers leave ONE workgroup per CU, the persistent one's 245 two: persistent from
+    // one pair per workgroup on -- 176 x 208 x 176 at batch 1 / 2: 205 -> 189 / 356 -> 304 us per sharp)
+    const bool persist = mode && per_cu >= 2 && (NX <= 160 || NX == 176) &&
+                         (mode >= 2 || pairs >= 8ull * grid || (NX == 176 && pairs >= grid)) && pairs < (1ull << 32);
     if (inverse) {
         using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
         if (persist) {

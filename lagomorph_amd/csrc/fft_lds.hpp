@@ -473,10 +473,11 @@ struct XPass {
     static constexpr int NPH = 2 * G + 3;  // load | G forward stages | operator | G inverse stages | store
     static constexpr int ROWS_IT = NT / 8, KLD = (3 * NX + ROWS_IT - 1) / ROWS_IT;  // float4 loads: 8 lanes per 16-bin row
     static constexpr bool RAGGED = 3 * NX % ROWS_IT != 0;           // (176 and 208 points: the last pass is guarded)
-    static constexpr int RG = NT / KL, NOP = NX / RG;               // operator: NOP bins per thread
+    static constexpr int RG = NT / KL, NOP = (NX + RG - 1) / RG;    // operator: NOP bins per thread
+    static constexpr bool RAGGED_OP = NX % RG != 0;                 // (208 points over 512 threads: 6 1/2 rows per thread)
     static constexpr size_t SMEM = (size_t)(3 * NX * KCP + NX) * sizeof(float2);
-    static_assert(NX % RG == 0, "tile does not divide over the threads");
     LAGO_HD static bool row_ok(int rg, int k) { return !RAGGED || rg + k * ROWS_IT < 3 * NX; }
+    LAGO_HD static bool op_ok(int p) { return !RAGGED_OP || p < NX; }
 
     struct Block {  // workgroup-uniform
         float2 *base;
@@ -520,6 +521,7 @@ struct XPass {
         const int kc = tid & (KL - 1), row0 = tid / KL;
 #pragma unroll
         for (int i = 0; i < NOP; ++i) {
+            if (!op_ok(row0 + i * RG)) continue;
             const float *t = b.tb + (size_t)freq_at<SX>(row0 + i * RG) * b.tks + kc * 6;
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
@@ -562,6 +564,7 @@ struct XPass {
 #pragma unroll
             for (int i = 0; i < NOP; ++i) {
                 const int p = row0 + i * RG;
+                if (!op_ok(p)) continue;
                 float2 *bx = buf + (0 * NX + p) * KCP + kc, *by = buf + (1 * NX + p) * KCP + kc,
                        *bz = buf + (2 * NX + p) * KCP + kc;
                 float2 X = *bx, Y = *by, Z = *bz;

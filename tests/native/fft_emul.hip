@@ -48,11 +48,11 @@ static void op_double(const float *c, cd &X, cd &Y, cd &Z) {
     }
 }
 
-template <class SX, class SY, class SZH, bool INV>
+template <class SX, class SY, class SZH, bool INV, int NN = 2, int XT = 256>
 static int run_case() {
-    constexpr int NX = SX::N, NY = SY::N, NZH = SZH::N, NZ = 2 * NZH, NZC = NZH + 1, NN = 2;
+    constexpr int NX = SX::N, NY = SY::N, NZH = SZH::N, NZ = 2 * NZH, NZC = NZH + 1;
     using Zy = ZY<SY, SZH>;
-    using Xp = XPass<SX, INV, 256>;
+    using Xp = XPass<SX, INV, XT>;   // XT threads per x-pass workgroup
     constexpr int ZT = Zy::THREADS;
     const size_t plane = (size_t)NY * NZ, nplanes = (size_t)NN * 3 * NX;
     std::vector<float> m(nplanes * plane), out(nplanes * plane, 0.f);
@@ -120,12 +120,12 @@ static int run_case() {
     xa.main_ = mainb; xa.nyq = nyqb; xa.tabM = tabP.data(); xa.tabN = tabP.data() + (size_t)NX * NY * NZH * 6;
     xa.ny = NY; xa.nzh = NZH; xa.nch = NY * NZH / 16; xa.items_per_n = xa.nch + NY / 16;
     xa.nn = NN; xa.ipw = 1; xa.scale = scale; xa.total = (uint32_t)(NN * xa.items_per_n);
-    std::vector<typename Xp::Regs> regs(256);
+    std::vector<typename Xp::Regs> regs(XT);
     for (uint32_t blk = 0; blk < xa.total; ++blk) {
         const auto b = Xp::locate(xa, blk);
         float2 *buf = lds.data(), *tw = buf + 3 * NX * Xp::KCP;
         for (int ph = 0; ph < Xp::NPH; ++ph)
-            for (int tid = 0; tid < 256; ++tid) Xp::phase(ph, tid, regs[tid], b, buf, tw, xa.scale);
+            for (int tid = 0; tid < XT; ++tid) Xp::phase(ph, tid, regs[tid], b, buf, tw, xa.scale);
     }
     // zy inverse
     for (size_t p = 0; p < nplanes; ++p) {
@@ -188,10 +188,9 @@ int main() {
     // radix 11 and 13 (176 = 11 * 16, 208 = 13 * 16; half lengths 88 = 11 * 8, 104 = 13 * 8): ragged x-pass rows, tiles of
     // 16 positions that straddle the 88-bin rows, a twiddle table per axis where the common one does not fit (208 x 176)
     bad += run_case<Sz<11, 4>, Sz<1, 5>, Sz<1, 5>, true>();    // 176 x 32 x 64
-    bad += run_case<Sz<13, 4>, Sz<1, 5>, Sz<11, 3>, false>();  // 208 x 32 x 176
-    bad += run_case<Sz<1, 5>, Sz<13, 4>, Sz<11, 3>, true>();   // 32 x 208 x 176
-    bad += run_case<Sz<1, 5>, Sz<11, 4>, Sz<13, 3>, false>();  // 32 x 176 x 208
-    bad += run_case<Sz<1, 5>, Sz<11, 4>, Sz<11, 3>, true>();   // 32 x 176 x 176
+    bad += run_case<Sz<13, 4>, Sz<1, 5>, Sz<1, 5>, false, 2, 512>();   // 208 x 32 x 64, the 512-thread x pass (6 1/2 operator rows per thread)
+    bad += run_case<Sz<1, 5>, Sz<13, 4>, Sz<11, 3>, true, 1>();   // 32 x 208 x 176 (one batch item)
+    bad += run_case<Sz<1, 5>, Sz<11, 4>, Sz<13, 3>, false, 1>();  // 32 x 176 x 208 (one batch item)
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }

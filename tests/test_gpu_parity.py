@@ -591,7 +591,9 @@ def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
                                 (160, 160, 160), (96, 64, 160), (160, 96, 192), (192, 160, 96), (64, 192, 192),
                                 # every plane shape served by the persistent zy kernels (above 80 KB of LDS)
                                 (64, 128, 192), (64, 160, 128), (64, 192, 128), (64, 128, 160), (64, 160, 192),
-                                (96, 192, 160)])
+                                (96, 192, 160),
+                                # radix 11 / 13 (round 6): planes and x lines of the 176 x 208 x 176 brain grid
+                                (64, 208, 176), (64, 176, 208), (64, 176, 176), (176, 64, 64), (208, 32, 64), (176, 208, 176)])
 @pytest.mark.parametrize("inverse", [True, False])
 def test_fused_fluid_metric_paths(ext, sp, inverse):
     """float32 3D: the three implementations of FluidMetric sharp/flat -- (2) three LDS-tiled FFT
@@ -601,7 +603,7 @@ def test_fused_fluid_metric_paths(ext, sp, inverse):
     import lagomorph_amd as lm
 
     rng = np.random.default_rng(hash((sp, inverse)) % 2**31)
-    m = rnd(rng, (3, 3) + sp, torch.float32)  # odd batch: the x pass pairs batch items per workgroup
+    m = rnd(rng, ((3 if np.prod(sp) < 4e6 else 1), 3) + sp, torch.float32)  # odd batch: the x pass pairs batch items per workgroup
     md = dev(m)
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     f = met.sharp if inverse else met.flat
@@ -863,15 +865,16 @@ def test_rocfft_guard_bookkeeping(ext):
         ext.set_fluid_mode(3)
 
 
+@pytest.mark.parametrize("plane", [(160, 160), (208, 176)])
 @pytest.mark.parametrize("batch", [1, 2, 5])
-def test_persistent_zy_passes_any_plane_count(ext, batch):
+def test_persistent_zy_passes_any_plane_count(ext, batch, plane):
     """Planes above 80 KB of LDS run on a grid of at most 256 persistent workgroups that prefetch their next plane:
     fewer planes than workgroups (batch 1: 192), a ragged last round (batch 2: 384 = 256 + 128) and several rounds
     (batch 5: 960), against the oracle and bit for bit against the one-plane-per-workgroup kernels."""
     import lagomorph_amd as lm
 
     rng = np.random.default_rng(batch)
-    m = rnd(rng, (batch, 3, 64, 160, 160), torch.float32)
+    m = rnd(rng, (batch, 3, 64) + plane, torch.float32)
     met = lm.FluidMetric([0.1, 0.05, 0.01])
     got = met.sharp(dev(m))
     assert_close(got, orc.fluid_metric_apply(m, [0.1, 0.05, 0.01], True), torch.float32, "persistent zy passes vs oracle")
@@ -884,7 +887,7 @@ def test_persistent_zy_passes_any_plane_count(ext, batch):
 
 
 @pytest.mark.parametrize("shape,batch", [((64, 64, 64), 1), ((64, 96, 64), 3), ((128, 64, 96), 2), ((160, 64, 64), 5),
-                                         ((96, 32, 128), 7)])
+                                         ((96, 32, 128), 7), ((176, 32, 64), 3), ((176, 176, 176), 1)])
 @pytest.mark.parametrize("inverse", [True, False])
 def test_persistent_x_pass_any_pair_count(ext, shape, batch, inverse):
     """The x pass as a persistent grid: each workgroup walks a contiguous run of (bin tile, batch item) pairs with its
