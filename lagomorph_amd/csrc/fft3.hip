@@ -458,10 +458,7 @@ static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t
     const int mode = g_xpass_persist;   // 2 (tests): whatever the size of the launch
     const uint32_t grid = (uint32_t)std::min<uint64_t>(256u * per_cu, pairs);
     // (192 points: 263 VGPRs, one 256-thread workgroup per CU -- stays with the one-shot workgroups)
-    // (176 points: the one-shot kernel's 264 registers leave ONE workgroup per CU, the persistent one's 245 two: persistent from
-    // one pair per workgroup on -- 176 x 208 x 176 at batch 1 / 2: 205 -> 189 / 356 -> 304 us per sharp)
-    const bool persist = mode && per_cu >= 2 && (NX <= 160 || NX == 176) &&
-                         (mode >= 2 || pairs >= 8ull * grid || (NX == 176 && pairs >= grid)) && pairs < (1ull << 32);
+    const bool persist = mode && per_cu >= 2 && (NX <= 160 || NX == 176) && (mode >= 2 || pairs >= 8ull * grid) && pairs < (1ull << 32);
     if (inverse) {
         using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
         if (persist) {

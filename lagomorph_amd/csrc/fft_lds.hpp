@@ -406,6 +406,59 @@ LAGO_HD void radixR_stage(float2 *buf, const float2 *tw, int tid) {
     }
 }
 
+// The radix-R level for R = 7, 11, 13 (never fused with a radix-2 level): the arithmetic of radixR_stage with dft_odd,
+// STREAMED -- the inverse's twiddles are multiplied in as the inputs are read into the symmetric pairs, every output
+// pair is multiplied by its (forward) twiddle and stored as soon as it is formed -- so that a work item holds R - 1 pair
+// values and one output pair instead of R inputs, R twiddles and R outputs: the 1024-thread persistent zy kernels of the
+// 208 x 176 planes (128 registers per thread, nine float4 of the next plane in flight) spilled 12 - 23 registers with the
+// array form.
+template <class X, bool FWD>
+LAGO_HD void radix_odd_stage(float2 *buf, const float2 *tw, int tid) {
+    using Sq = typename X::S;
+    constexpr int R = Sq::R, M = Sq::M, H = (R - 1) / 2, ITEMS = X::NB * M * X::NL, TWS = X::LTW / Sq::N;
+    for (int w = tid; w < ITEMS; w += X::NT) {
+        const int lane = w % X::NL;
+        const int q = w / X::NL;
+        const int m = q % M, b = q / M;
+        float2 *p = buf + b * X::BS + m * X::ES + lane * X::LS;
+        const float2 x0 = p[0];
+        float2 a[H], d[H];
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            float2 u = p[j * M * X::ES], v = p[(R - j) * M * X::ES];
+            if (!FWD) {
+                u = cmulc(u, tw[m * j * TWS]);
+                v = cmulc(v, tw[m * (R - j) * TWS]);
+            }
+            a[j - 1] = make_float2(u.x + v.x, u.y + v.y);
+            d[j - 1] = make_float2(u.x - v.x, u.y - v.y);
+        }
+        float2 s = x0;
+#pragma unroll
+        for (int j = 0; j < H; ++j) s = make_float2(s.x + a[j].x, s.y + a[j].y);
+        p[0] = s;
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            float2 e = x0, o = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 1; j <= H; ++j) {
+                const int mm = (j * k) % R;
+                const float c = odd_cos<R>(mm), sn = odd_sin<R>(mm);
+                e = make_float2(fmaf(c, a[j - 1].x, e.x), fmaf(c, a[j - 1].y, e.y));
+                o = make_float2(fmaf(sn, d[j - 1].x, o.x), fmaf(sn, d[j - 1].y, o.y));
+            }
+            const float2 jv = FWD ? make_float2(o.y, -o.x) : make_float2(-o.y, o.x);   // -+ i o
+            float2 yk = make_float2(e.x + jv.x, e.y + jv.y), ym = make_float2(e.x - jv.x, e.y - jv.y);
+            if (FWD) {
+                yk = cmul(yk, tw[m * k * TWS]);
+                ym = cmul(ym, tw[m * (R - k) * TWS]);
+            }
+            p[k * M * X::ES] = yk;
+            p[(R - k) * M * X::ES] = ym;
+        }
+    }
+}
+
 // stage number `g` of the forward transform / of the inverse transform (which runs the stages in reverse order);
 // g is a constant after unrolling
 template <class X, bool FWD>
@@ -413,7 +466,10 @@ LAGO_HD void run_stage(int g, float2 *buf, const float2 *tw, int tid) {
     using Sq = typename X::S;
     constexpr int G = stage_count<Sq>(), HASR = Sq::R > 1 ? 1 : 0;
     const int gg = FWD ? g : G - 1 - g;
-    if (HASR && gg == 0) radixR_stage<X, FWD>(buf, tw, tid);
+    if (HASR && gg == 0) {
+        if constexpr (Sq::R > 5) radix_odd_stage<X, FWD>(buf, tw, tid);
+        else radixR_stage<X, FWD>(buf, tw, tid);
+    }
     else if (gg - HASR == 0) radix2_stage<X, 0, FWD>(buf, tw, tid);
     else if (gg - HASR == 1) radix2_stage<X, 1, FWD>(buf, tw, tid);
     else radix2_stage<X, 2, FWD>(buf, tw, tid);
