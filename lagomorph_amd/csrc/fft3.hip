@@ -32,6 +32,14 @@ template <> struct SzOf<88> { using T = fl::Sz<11, 3>; };
 template <> struct SzOf<104> { using T = fl::Sz<13, 3>; };
 template <> struct SzOf<176> { using T = fl::Sz<11, 4>; };
 template <> struct SzOf<208> { using T = fl::Sz<13, 4>; };
+// 7, 9 and 15 times a power of two: 96 x 112 x 96 and 192 x 224 x 160 (cropped MNI grids), 144^3 / 144 x 176 x 144, 240
+template <> struct SzOf<56> { using T = fl::Sz<7, 3>; };
+template <> struct SzOf<112> { using T = fl::Sz<7, 4>; };
+template <> struct SzOf<224> { using T = fl::Sz<7, 5>; };
+template <> struct SzOf<72> { using T = fl::Sz<9, 3>; };
+template <> struct SzOf<144> { using T = fl::Sz<9, 4>; };
+template <> struct SzOf<120> { using T = fl::Sz<15, 3>; };
+template <> struct SzOf<240> { using T = fl::Sz<15, 4>; };
 
 template <int NY, int NZ>
 using ZYK = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T>;
@@ -301,7 +309,7 @@ int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, 
 // threads per x-pass workgroup: 256, except for the 256-point tile (104 KB: one workgroup per CU, which 512 threads
 // serve 12 % faster).  Measured (tools/ab_fluid.py): wider workgroups LOSE 3-14 % at 128, 160 and 192 points, where
 // two or three 256-thread workgroups share a CU and their 120+ VGPRs per thread would cost the second one.
-template <int NX> constexpr int xpass_wide() { return NX >= 256 || NX == 208 ? 512 : 256; }   // (208: 86 KB, alone on its CU as well)
+template <int NX> constexpr int xpass_wide() { return NX >= 208 ? 512 : 256; }   // (208, 224, 240: 86 - 100 KB, alone on their CU as well)
 
 template <int NX, bool INV, int NT>
 __global__ __launch_bounds__(NT) void fluid_xpass2_kernel(fl::XArgs a) {
@@ -386,8 +394,10 @@ __global__ __launch_bounds__(NT) void fluid_xpass2_persist_kernel(fl::XArgs a) {
     X(128, 64) X(128, 96) X(128, 128) X(128, 160) X(128, 192) X(160, 64) X(160, 96) X(160, 128) X(160, 160) X(160, 192) \
     X(192, 64) X(192, 96) X(192, 128) X(192, 160) X(192, 192)                                          \
     X(32, 64) X(32, 128) X(32, 256) X(64, 256) X(128, 256) X(256, 64) X(256, 128)                      \
-    X(208, 176) X(176, 176) X(176, 208)
-#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256) X(176) X(208)
+    X(208, 176) X(176, 176) X(176, 208)                                                                \
+    X(112, 96) X(96, 112) X(112, 112) X(128, 112) X(112, 128) X(224, 160) X(160, 224) X(224, 128)      \
+    X(144, 144) X(176, 144) X(144, 176) X(240, 160) X(160, 240)
+#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256) X(176) X(208) X(112) X(224) X(144) X(240)
 
 bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz) {
     bool okx = false, okyz = false;

@@ -119,8 +119,8 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 
-// A transform length N = R * 2^L2 with R in {1, 3, 5, 7, 11, 13} (64, 96, 128, 160, 192, 256, ...; 176 = 11 * 16 and
-// 208 = 13 * 16: the 176 x 208 x 176 brain volumes of the OASIS images, round 6).
+// A transform length N = R * 2^L2 with R odd, R <= 15 (64, 96, 128, 160, 192, 256, ...; round 6: 176 = 11 * 16 and
+// 208 = 13 * 16 -- the 176 x 208 x 176 brain volumes of the OASIS images -- and 112 / 224, 144, 240 = 7, 9, 15 times 2^a).
 // Forward = decimation in frequency: one radix-R level (R > 1), then the radix-2 levels of the R sub-transforms of
 // 2^L2 points, up to four at a time in registers (stage plan below).  Frequency k = R*k2 + k1 ends up at position
 // k1*2^L2 + bitrev(k2): the order is never undone, in LDS or in memory.  Inverse = the same data
@@ -128,7 +128,8 @@ constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 template <int R_, int L2_>
 struct Sz {
     static constexpr int R = R_, L2 = L2_, M = 1 << L2_, N = R_ * (1 << L2_);
-    static_assert(R_ == 1 || R_ == 3 || R_ == 5 || R_ == 7 || R_ == 11 || R_ == 13, "radix 1, 3, 5, 7, 11 or 13 times a power of two");
+    static_assert(R_ == 1 || R_ == 3 || R_ == 5 || R_ == 7 || R_ == 9 || R_ == 11 || R_ == 13 || R_ == 15,
+                  "an odd factor up to 15 times a power of two");
 };
 template <class S>
 LAGO_HD int pos_of(int k) {  // position of frequency k after the forward transform
@@ -238,11 +239,15 @@ LAGO_HD void radix2_stage(float2 *buf, const float2 *tw, int tid) {
     }
 }
 
-// cos / sin of 2 pi m / R for the odd radices 7, 11, 13 (m is a constant after unrolling: the chains fold away)
+// cos / sin of 2 pi m / R for the odd radices 7 ... 15 (m is a constant after unrolling: the chains fold away)
 template <int R>
 LAGO_HD constexpr float odd_cos(int m) {
     const int h = m > R / 2 ? R - m : m;
     if (h == 0) return 1.0f;
+    if (R == 9) return h == 1 ? 0.76604444311897801345f : h == 2 ? 0.17364817766693035894f : h == 3 ? -0.5f : -0.93969262078590842791f;
+    if (R == 15)
+        return h == 1 ? 0.91354545764260086660f : h == 2 ? 0.66913060635885823757f : h == 3 ? 0.30901699437494745126f
+             : h == 4 ? -0.10452846326765347085f : h == 5 ? -0.5f : h == 6 ? -0.80901699437494745126f : -0.97814760073380568883f;
     if (R == 7) return h == 1 ? 0.62348980185873348336f : h == 2 ? -0.22252093395631439288f : -0.90096886790241914600f;
     if (R == 11)
         return h == 1 ? 0.84125353283118120551f : h == 2 ? 0.41541501300188643508f : h == 3 ? -0.14231483827328514358f
@@ -255,6 +260,13 @@ LAGO_HD constexpr float odd_sin(int m) {
     const int h = m > R / 2 ? R - m : m;
     const float sg = m > R / 2 ? -1.0f : 1.0f;
     if (h == 0) return 0.0f;
+    if (R == 9)
+        return sg * (h == 1 ? 0.64278760968653936292f : h == 2 ? 0.98480775301220802032f : h == 3 ? 0.86602540378443859659f
+                   : 0.34202014332566871291f);
+    if (R == 15)
+        return sg * (h == 1 ? 0.40673664307580020827f : h == 2 ? 0.74314482547739424412f : h == 3 ? 0.95105651629515353118f
+                   : h == 4 ? 0.99452189536827328986f : h == 5 ? 0.86602540378443859659f : h == 6 ? 0.58778525229247313710f
+                   : 0.20791169081775934258f);
     if (R == 7) return sg * (h == 1 ? 0.78183148246802980363f : h == 2 ? 0.97492791218182361934f : 0.43388373911755812040f);
     if (R == 11)
         return sg * (h == 1 ? 0.54064081745559755543f : h == 2 ? 0.90963199535451833011f : h == 3 ? 0.98982144188093268422f
@@ -262,38 +274,6 @@ LAGO_HD constexpr float odd_sin(int m) {
     return sg * (h == 1 ? 0.46472317204376856203f : h == 2 ? 0.82298386589365635224f : h == 3 ? 0.99270887409805397272f
                : h == 4 ? 0.93501624268541483342f : h == 5 ? 0.66312265824079519305f : 0.23931566428755776665f);
 }
-// R-point DFT, R = 7, 11, 13, through the symmetric pairs a_j = x_j + x_(R-j), b_j = x_j - x_(R-j):
-// y_k = x_0 + sum_j cos(2 pi j k / R) a_j -+ i sum_j sin(2 pi j k / R) b_j, y_(R-k) its mirror: (R - 1)^2 multiply-adds
-template <int R, int SGN>
-LAGO_HD void dft_odd(float2 *v) {
-    constexpr int H = (R - 1) / 2;
-    float2 a[H], b[H];
-#pragma unroll
-    for (int j = 1; j <= H; ++j) {
-        a[j - 1] = make_float2(v[j].x + v[R - j].x, v[j].y + v[R - j].y);
-        b[j - 1] = make_float2(v[j].x - v[R - j].x, v[j].y - v[R - j].y);
-    }
-    const float2 x0 = v[0];
-    float2 s = x0;
-#pragma unroll
-    for (int j = 0; j < H; ++j) s = make_float2(s.x + a[j].x, s.y + a[j].y);
-    v[0] = s;
-#pragma unroll
-    for (int k = 1; k <= H; ++k) {
-        float2 e = x0, o = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int j = 1; j <= H; ++j) {
-            const int m = (j * k) % R;
-            const float c = odd_cos<R>(m), sn = odd_sin<R>(m);
-            e = make_float2(fmaf(c, a[j - 1].x, e.x), fmaf(c, a[j - 1].y, e.y));
-            o = make_float2(fmaf(sn, b[j - 1].x, o.x), fmaf(sn, b[j - 1].y, o.y));
-        }
-        const float2 jv = SGN < 0 ? make_float2(o.y, -o.x) : make_float2(-o.y, o.x);   // -+ i o
-        v[k] = make_float2(e.x + jv.x, e.y + jv.y);
-        v[R - k] = make_float2(e.x - jv.x, e.y - jv.y);
-    }
-}
-
 // R-point DFT of v[0..R) in place; SGN = -1 forward (exp(-2 pi i r k / R)), +1 inverse
 template <int R, int SGN>
 LAGO_HD void dft_small(float2 *v) {
@@ -322,8 +302,6 @@ LAGO_HD void dft_small(float2 *v) {
         v[4] = make_float2(e1.x - j1.x, e1.y - j1.y);
         v[2] = make_float2(e2.x + j2.x, e2.y + j2.y);
         v[3] = make_float2(e2.x - j2.x, e2.y - j2.y);
-    } else if constexpr (R > 5) {
-        dft_odd<R, SGN>(v);
     }
 }
 
@@ -406,12 +384,14 @@ LAGO_HD void radixR_stage(float2 *buf, const float2 *tw, int tid) {
     }
 }
 
-// The radix-R level for R = 7, 11, 13 (never fused with a radix-2 level): the arithmetic of radixR_stage with dft_odd,
-// STREAMED -- the inverse's twiddles are multiplied in as the inputs are read into the symmetric pairs, every output
-// pair is multiplied by its (forward) twiddle and stored as soon as it is formed -- so that a work item holds R - 1 pair
+// The radix-R level for odd R = 7 ... 15, prime or not (never fused with a radix-2 level), through the symmetric pairs
+// a_j = x_j + x_(R-j), d_j = x_j - x_(R-j): y_k = x_0 + sum_j cos(2 pi j k / R) a_j -+ i sum_j sin(2 pi j k / R) d_j and
+// y_(R-k) its mirror, (R - 1)^2 multiply-adds.  STREAMED -- the inverse's twiddles are multiplied in as the inputs are read
+// into the symmetric pairs, every output pair is multiplied by its (forward) twiddle and stored as soon as it is formed --
+// so that a work item holds R - 1 pair
 // values and one output pair instead of R inputs, R twiddles and R outputs: the 1024-thread persistent zy kernels of the
 // 208 x 176 planes (128 registers per thread, nine float4 of the next plane in flight) spilled 12 - 23 registers with the
-// array form.
+// array form (inputs, twiddles and outputs in arrays around an R-point DFT, as radixR_stage has it for R = 3, 5).
 template <class X, bool FWD>
 LAGO_HD void radix_odd_stage(float2 *buf, const float2 *tw, int tid) {
     using Sq = typename X::S;

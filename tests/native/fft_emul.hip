@@ -189,8 +189,14 @@ int main() {
     // 16 positions that straddle the 88-bin rows, a twiddle table per axis where the common one does not fit (208 x 176)
     bad += run_case<Sz<11, 4>, Sz<1, 5>, Sz<1, 5>, true>();    // 176 x 32 x 64
     bad += run_case<Sz<13, 4>, Sz<1, 5>, Sz<1, 5>, false, 2, 512>();   // 208 x 32 x 64, the 512-thread x pass (6 1/2 operator rows per thread)
-    bad += run_case<Sz<1, 5>, Sz<13, 4>, Sz<11, 3>, true, 1>();   // 32 x 208 x 176 (one batch item)
-    bad += run_case<Sz<1, 5>, Sz<11, 4>, Sz<13, 3>, false, 1>();  // 32 x 176 x 208 (one batch item)
+    bad += run_case<Sz<1, 4>, Sz<13, 4>, Sz<11, 3>, true, 1>();   // 16 x 208 x 176 (one batch item)
+    bad += run_case<Sz<1, 4>, Sz<11, 4>, Sz<13, 3>, false, 1>();  // 16 x 176 x 208 (one batch item)
+    // odd factors 7, 9 (not a prime: the pair form of the odd level holds for any odd radix) and 15: 112 = 7 * 16, 144 = 9 * 16,
+    // 240 = 15 * 16 (512-thread x pass, 7 1/2 operator rows per thread), half lengths 56 = 7 * 8 and 72 = 9 * 8
+    bad += run_case<Sz<7, 4>, Sz<1, 5>, Sz<1, 5>, true>();           // 112 x 32 x 64
+    bad += run_case<Sz<1, 4>, Sz<7, 4>, Sz<7, 3>, false, 1>();       // 16 x 112 x 112
+    bad += run_case<Sz<1, 4>, Sz<9, 4>, Sz<9, 3>, true, 1>();        // 16 x 144 x 144
+    bad += run_case<Sz<15, 4>, Sz<1, 5>, Sz<1, 5>, false, 1, 512>(); // 240 x 32 x 64
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }

@@ -1,6 +1,6 @@
 """GPU: the hand-written FFT passes of the fluid metric over the stage plans they are instantiated for -- 256 points
 (two groups of four levels), 192 (radix 3 in front of 3 + 3), 96 / 160 (radix-6 / radix-10 stage), 64 and 128, 176 / 208
-(radix 11 / 13 in front of four levels; half lengths 88 / 104), mixed
+(radix 11 / 13 in front of four levels; half lengths 88 / 104), 112 / 224, 144, 240 (odd factors 7, 9, 15), mixed
 planes, persistent and one-shot forms -- against the float64 path (rocFFT, spot-checked on first use) at 2e-6 of the
 result's maximum (observed 3-5e-7).  The host emulation (tests/test_fft_emulation.py) checks the same code thread by
 thread without a GPU; this is the hardware side of it."""
@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(256, 64, 128), (64, 256, 64), (256, 128, 256), (192, 192, 192), (96, 96, 96), (64, 64, 64), (128, 32, 64),
           (160, 96, 64), (96, 160, 192), (128, 128, 160),
           # radix 11 and 13 (round 6): the 176 x 208 x 176 brain grid and its permutations, mixed with the older lengths
-          (176, 208, 176), (208, 176, 176), (176, 176, 208), (176, 64, 64), (208, 96, 128), (64, 208, 176), (160, 176, 176)]
+          (176, 208, 176), (208, 176, 176), (176, 176, 208), (176, 64, 64), (208, 96, 128), (64, 208, 176), (160, 176, 176),
+          # odd factors 7, 9, 15: cropped MNI grids (96 x 112 x 96, 192 x 224 x 160), 144^3, 144 x 176 x 144, 240-point axes
+          (96, 112, 96), (112, 112, 112), (112, 128, 112), (112, 112, 128), (192, 224, 160), (224, 160, 224), (128, 224, 128),
+          (144, 144, 144), (144, 176, 144), (176, 144, 176), (240, 160, 240), (160, 240, 160)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"{a}x{b}x{c}" for a, b, c in SHAPES])

@@ -593,7 +593,10 @@ def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
                                 (64, 128, 192), (64, 160, 128), (64, 192, 128), (64, 128, 160), (64, 160, 192),
                                 (96, 192, 160),
                                 # radix 11 / 13 (round 6): planes and x lines of the 176 x 208 x 176 brain grid
-                                (64, 208, 176), (64, 176, 208), (64, 176, 176), (176, 64, 64), (208, 32, 64), (176, 208, 176)])
+                                (64, 208, 176), (64, 176, 208), (64, 176, 176), (176, 64, 64), (208, 32, 64), (176, 208, 176),
+                                # odd factors 7, 9, 15
+                                (96, 112, 96), (112, 96, 112), (144, 144, 144), (64, 224, 160), (224, 32, 64), (240, 64, 64),
+                                (64, 160, 240), (64, 240, 160), (64, 144, 176)])
 @pytest.mark.parametrize("inverse", [True, False])
 def test_fused_fluid_metric_paths(ext, sp, inverse):
     """float32 3D: the three implementations of FluidMetric sharp/flat -- (2) three LDS-tiled FFT
@@ -865,7 +868,7 @@ def test_rocfft_guard_bookkeeping(ext):
         ext.set_fluid_mode(3)
 
 
-@pytest.mark.parametrize("plane", [(160, 160), (208, 176)])
+@pytest.mark.parametrize("plane", [(160, 160), (208, 176), (224, 160)])
 @pytest.mark.parametrize("batch", [1, 2, 5])
 def test_persistent_zy_passes_any_plane_count(ext, batch, plane):
     """Planes above 80 KB of LDS run on a grid of at most 256 persistent workgroups that prefetch their next plane:

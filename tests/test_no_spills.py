@@ -25,6 +25,9 @@ ALLOWED = [  # (pattern on the demangled name, spilled VGPRs allowed)
     # have none (tools/time_oasis_fft.py, profiles/r06_radix11_13.md): 208 x 176 planes 870 against 987 us per sharp at
     # batch 8, 176 x 176 373 against 450, 176 x 208 460 against 527.
     (r"lago::zy_(forward|inverse)_persist_kernel<(208, 176|176, 176|176, 208)>", 12),
+    # ... and of the 224 x 160, 160 x 224 and 144 x 176 planes (odd factors 7 and 9; inverse only, 3 - 11 registers): sharp at 4 x 192
+    # x 224 x 160 514 against 580 us one-shot, 4 x 224 x 160 x 224 630 against 719, 8 x 144 x 144 x 176 506 against 610
+    (r"lago::zy_inverse_persist_kernel<(224, 160|160, 224|144, 176)>", 11),
 ]
 
 
