@@ -40,6 +40,12 @@ template <> struct SzOf<72> { using T = fl::Sz<9, 3>; };
 template <> struct SzOf<144> { using T = fl::Sz<9, 4>; };
 template <> struct SzOf<120> { using T = fl::Sz<15, 3>; };
 template <> struct SzOf<240> { using T = fl::Sz<15, 4>; };
+// 8 times an odd factor (ny % 16 = 8: the Nyquist plane's last tile is half a tile) and the half lengths that go with them:
+// 88 x 104 x 88 (the 176 x 208 x 176 grid at half resolution: multiscale momenta), 120^3, 80^3 (160^3 at half resolution)
+template <> struct SzOf<40> { using T = fl::Sz<5, 3>; };
+template <> struct SzOf<44> { using T = fl::Sz<11, 2>; };
+template <> struct SzOf<52> { using T = fl::Sz<13, 2>; };
+template <> struct SzOf<60> { using T = fl::Sz<15, 2>; };
 
 template <int NY, int NZ>
 using ZYK = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T>;
@@ -396,8 +402,9 @@ __global__ __launch_bounds__(NT) void fluid_xpass2_persist_kernel(fl::XArgs a) {
     X(32, 64) X(32, 128) X(32, 256) X(64, 256) X(128, 256) X(256, 64) X(256, 128)                      \
     X(208, 176) X(176, 176) X(176, 208)                                                                \
     X(112, 96) X(96, 112) X(112, 112) X(128, 112) X(112, 128) X(224, 160) X(160, 224) X(224, 128)      \
-    X(144, 144) X(176, 144) X(144, 176) X(240, 160) X(160, 240)
-#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256) X(176) X(208) X(112) X(224) X(144) X(240)
+    X(144, 144) X(176, 144) X(144, 176) X(240, 160) X(160, 240)                                        \
+    X(104, 88) X(88, 88) X(88, 104) X(120, 120) X(80, 80)
+#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256) X(176) X(208) X(112) X(224) X(144) X(240) X(88) X(104) X(120) X(80)
 
 bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz) {
     bool okx = false, okyz = false;
@@ -407,6 +414,9 @@ bool fluid_native_supported(int64_t nx, int64_t ny, int64_t nz) {
 #define X(NY, NZ) okyz = okyz || (ny == NY && nz == NZ);
     LAGO_ZY_SHAPES(X)
 #undef X
+    // a Nyquist plane whose rows are not whole tiles (ny % 16 = 8) needs the x-pass instantiations that mask the short tile:
+    // those of the lengths 88, 104, 120 (fft_lds.hpp: XPass::TAIL)
+    if (ny % 16 != 0 && nx % 16 == 0) return false;
     return okx && okyz;
 }
 
@@ -468,10 +478,12 @@ static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t
     const int mode = g_xpass_persist;   // 2 (tests): whatever the size of the launch
     const uint32_t grid = (uint32_t)std::min<uint64_t>(256u * per_cu, pairs);
     // (192 points: 263 VGPRs, one 256-thread workgroup per CU -- stays with the one-shot workgroups)
-    const bool persist = mode && per_cu >= 2 && (NX <= 160 || NX == 176) && (mode >= 2 || pairs >= 8ull * grid) && pairs < (1ull << 32);
+    // (the persistent kernels exist only for the lengths whose tile fits a CU twice)
+    constexpr bool kCanPersist = K0::SMEM * 2 <= 160 * 1024 && (NX <= 160 || NX == 176);
+    const bool persist = mode && kCanPersist && (mode >= 2 || pairs >= 8ull * grid) && pairs < (1ull << 32);
     if (inverse) {
         using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
-        if (persist) {
+        if constexpr (kCanPersist) if (persist) {
             auto k = fluid_xpass2_persist_kernel<NX, true, NT>;
             hipError_t e = allow_smem(k, K::SMEM);
             if (e != hipSuccess) return e;
@@ -484,7 +496,7 @@ static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t
         hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
     } else {
         using K = fl::XPass<typename SzOf<NX>::T, false, NT>;
-        if (persist) {
+        if constexpr (kCanPersist) if (persist) {
             auto k = fluid_xpass2_persist_kernel<NX, false, NT>;
             hipError_t e = allow_smem(k, K::SMEM);
             if (e != hipSuccess) return e;
@@ -529,7 +541,7 @@ std::atomic<int> g_native_stage_mask{7};
 int fluid_metric_native(float *out, const float *m, float *work, const float *tab, int inverse, int64_t nn,
                         int64_t nx, int64_t ny, int64_t nz, double scale, hipStream_t s, float oscale) {
     const int64_t nzh = nz / 2, planes = nn * 3 * nx;
-    const int64_t items = ny * nzh / 16 + ny / 16;   // tiles of 16 consecutive (r, q) positions + the Nyquist plane's
+    const int64_t items = ny * nzh / 16 + (ny + 15) / 16;   // tiles of 16 consecutive (r, q) positions + the Nyquist plane's (the last one may be short)
     if (planes >= (1ll << 31) || nn * items >= (1ll << 31)) return fail_invalid("fluid_metric: batch too large");
     fl::ZYArgs za;
     za.in = m;

@@ -494,7 +494,7 @@ LAGO_HD void fluid_bin(const float *c, float2 &X, float2 &Y, float2 &Z, float sc
 struct XArgs {
     float2 *main_, *nyq;        // split spectrum (see the header comment)
     const float *tabM, *tabN;   // coefficients [kx][r][q < nzh][6] and [kx][r][6], (r, q) as in the spectrum
-    int ny, nzh, nch, items_per_n;   // nch = ny * nzh / 16 tiles of the main block, items_per_n = nch + ny / 16
+    int ny, nzh, nch, items_per_n;   // nch = ny * nzh / 16 tiles of the main block, items_per_n = nch + ceil(ny / 16)
     int nn, ipw;                // batch size; batch items one workgroup runs through with the same coefficients
     float scale;
     uint32_t total;             // ceil(nn / ipw) * items_per_n workgroups
@@ -514,12 +514,19 @@ struct XPass {
     static constexpr size_t SMEM = (size_t)(3 * NX * KCP + NX) * sizeof(float2);
     LAGO_HD static bool row_ok(int rg, int k) { return !RAGGED || rg + k * ROWS_IT < 3 * NX; }
     LAGO_HD static bool op_ok(int p) { return !RAGGED_OP || p < NX; }
+    // TAIL: the instantiations for NX = 88, 104, 120 (8 x odd) also serve planes with ny % 16 = 8, whose Nyquist plane ends
+    // with half a tile (Block::nv = 8: the other lanes load zeros and store nothing).  The lengths with NX % 16 = 0 carry no
+    // such code (their kernels sit at the register count that lets two workgroups share a CU) and take ny % 16 = 0 only.
+    static constexpr bool TAIL = NX % 16 != 0;
+    template <class B> LAGO_HD static bool bin_ok(const B &b, int c) { if constexpr (TAIL) return c < b.nv; else return true; }
 
     struct Block {  // workgroup-uniform
         float2 *base;
         size_t xs;        // x stride (complex elements); component stride = NX * xs
         const float *tb;  // coefficient row of bin lane 0 at kx = 0
         size_t tks;       // kx stride of the coefficient table (floats)
+        int nv;           // bins of the tile that exist: 16, or ny % 16 (even) in the last tile of a Nyquist plane whose rows
+                          // are not whole tiles (ny = 88, 104, 120): the other lanes load zeros and store nothing
     };
     struct Regs { float coef[NOP][6]; };
 
@@ -537,12 +544,14 @@ struct XPass {
             b.base = a.main_ + (size_t)n * 3 * NX * b.xs + (size_t)item * KL;
             b.tb = a.tabM + (size_t)item * KL * 6;
             b.tks = b.xs * 6;
+            b.nv = KL;
         } else {
             const uint32_t j = item - nmain;
             b.xs = (size_t)a.ny;
             b.base = a.nyq + (size_t)n * 3 * NX * b.xs + j * KL;
             b.tb = a.tabN + (size_t)j * KL * 6;
             b.tks = b.xs * 6;
+            b.nv = TAIL ? min(KL, a.ny - (int)j * KL) : KL;
         }
         return b;
     }
@@ -551,13 +560,19 @@ struct XPass {
     // persistent workgroup can request its next tile while it transforms the current one (fft3.hip).
     LAGO_HD static void load_one(int tid, const Block &b, float4 (&v)[KLD], int k) {
         const int rg = tid >> 3, l8 = tid & 7;
-        if (row_ok(rg, k)) v[k] = ldg4<LAGO_NT_X_LD>(reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8));
+        if (!bin_ok(b, 2 * l8)) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (row_ok(rg, k)) v[k] = ldg4<LAGO_NT_X_LD>(reinterpret_cast<const float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8));
     }
     LAGO_HD static void load_coef(int tid, Regs &r, const Block &b) {
         const int kc = tid & (KL - 1), row0 = tid / KL;
 #pragma unroll
         for (int i = 0; i < NOP; ++i) {
             if (!op_ok(row0 + i * RG)) continue;
+            if (!bin_ok(b, kc)) {   // (no such bin: zeros in, zeros out)
+#pragma unroll
+                for (int e = 0; e < 6; ++e) r.coef[i][e] = 0.f;
+                continue;
+            }
             const float *t = b.tb + (size_t)freq_at<SX>(row0 + i * RG) * b.tks + kc * 6;
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
@@ -613,7 +628,7 @@ struct XPass {
             const int rg = tid >> 3, l8 = tid & 7;
 #pragma unroll
             for (int k = 0; k < KLD; ++k) {
-                if (!row_ok(rg, k)) continue;
+                if (!row_ok(rg, k) || !bin_ok(b, 2 * l8)) continue;
                 const float2 *s = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
                 const float2 a = s[0], c = s[1];
                 stg4<LAGO_NT_X_ST>(reinterpret_cast<float4 *>(b.base + (size_t)(rg + k * ROWS_IT) * b.xs + 2 * l8),

@@ -118,7 +118,7 @@ static int run_case() {
     // x pass
     XArgs xa;
     xa.main_ = mainb; xa.nyq = nyqb; xa.tabM = tabP.data(); xa.tabN = tabP.data() + (size_t)NX * NY * NZH * 6;
-    xa.ny = NY; xa.nzh = NZH; xa.nch = NY * NZH / 16; xa.items_per_n = xa.nch + NY / 16;
+    xa.ny = NY; xa.nzh = NZH; xa.nch = NY * NZH / 16; xa.items_per_n = xa.nch + (NY + 15) / 16;
     xa.nn = NN; xa.ipw = 1; xa.scale = scale; xa.total = (uint32_t)(NN * xa.items_per_n);
     std::vector<typename Xp::Regs> regs(XT);
     for (uint32_t blk = 0; blk < xa.total; ++blk) {
@@ -197,6 +197,10 @@ int main() {
     bad += run_case<Sz<1, 4>, Sz<7, 4>, Sz<7, 3>, false, 1>();       // 16 x 112 x 112
     bad += run_case<Sz<1, 4>, Sz<9, 4>, Sz<9, 3>, true, 1>();        // 16 x 144 x 144
     bad += run_case<Sz<15, 4>, Sz<1, 5>, Sz<1, 5>, false, 1, 512>(); // 240 x 32 x 64
+    // ny % 16 = 8: the last tile of the Nyquist plane holds 8 bins (the other lanes load zeros and store nothing);
+    // half lengths 44 = 11 * 4 and 52 = 13 * 4 (two radix-2 levels), 88-point x lines (5 1/2 operator rows per thread)
+    bad += run_case<Sz<11, 3>, Sz<13, 3>, Sz<11, 2>, true, 1>();     // 88 x 104 x 88
+    bad += run_case<Sz<13, 3>, Sz<11, 3>, Sz<13, 2>, false, 1>();    // 104 x 88 x 104 (x lengths with NX % 16 = 0 do not take such planes)
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }
