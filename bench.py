@@ -33,6 +33,7 @@ Also on the same JSON line:
                    reference_cpu_path: the reference's OWN CPU code (extension/cpu/affine.cpp, oracle/_ref) timed
                    beside the HIP kernel that replaces it, BASELINE configs[0] included.
   interp_splat, fluid, other_ops -- BASELINE configs[1] / configs[2] micro-measurements (N = 1 only).
+  brain_grid -- the shoot and the metric on a 176 x 208 x 176 volume (not a BASELINE config; N = 1 only).
 """
 import argparse
 import json
@@ -265,6 +266,37 @@ def micro_ops(lm, dev, size, batch=8):
                        "forward_us": 1e3 * f_ms, "adjoint_us": 1e3 * b_ms, "pair_us": 1e3 * (f_ms + b_ms),
                        "voxels": 2 * 64 * 64, "pair_voxels_per_s": 2 * 64 * 64 / ((f_ms + b_ms) * 1e-3)}
     return out
+
+
+def micro_brain_grid(lm, dev, batch=8, shape=(176, 208, 176), steps=10):
+    """Not a BASELINE config: the same shoot on a real brain-MRI grid (176 x 208 x 176 = 11*16 x 13*16 x 11*16, the OASIS
+    atlas-space volume), whose extents the fluid metric's LDS-tiled FFT passes cover since round 6 (radix-11 / radix-13
+    levels); beside it the metric alone, on the default path and through rocFFT's 3D plan + operator kernel."""
+    ext = lm.lagomorph_ext
+    g = torch.Generator(device=dev).manual_seed(77)
+    met = lm.FluidMetric([0.1, 0.0, 0.01])
+    vox = batch * shape[0] * shape[1] * shape[2]
+    with torch.no_grad():
+        m = gaussian_blur(torch.randn((batch, 3) + shape, device=dev, generator=g), 4.0)
+        m *= 2.5 / met.sharp(m).abs().max()
+        n0 = ext.path_launches("fluid_lds")
+        ref = met.sharp(m)
+        tuned = ext.path_launches("fluid_lds") == n0 + 1
+        t_sharp = time_op(lambda: met.sharp(m), reps=10, warm=3)[0]
+        t_shoot = time_op(lambda: lm.expmap(met, m, num_steps=steps), reps=3, warm=1)[0]
+        mode = ext.get_tuning()["fluid_mode"]
+        try:
+            ext.set_fluid_mode(0)
+            out = met.sharp(m)
+            dev_rocfft = float((out.double() - ref.double()).abs().max() / ref.double().abs().max())
+            t_rocfft = time_op(lambda: met.sharp(m), reps=5, warm=2)[0]
+        finally:
+            ext.set_fluid_mode(mode)
+    return {"workload": f"lddmm.expmap, {steps} Euler steps, batch {batch} x 3 x {shape[0]}x{shape[1]}x{shape[2]} fp32 (not a BASELINE config)",
+            "expmap_ms": t_shoot, "Gvoxel_step_per_s": vox * steps / t_shoot / 1e6,
+            "sharp_ms": t_sharp, "sharp_path": "LDS-tiled passes" if tuned else "generic passes",
+            "sharp_frac_of_single_pass_ideal_at_hbm_peak": vox * 72.8 / (t_sharp * 1e-3) / 8.0e12,
+            "sharp_ms_rocfft_3d_plus_operator": t_rocfft, "max_rel_dev_from_rocfft": dev_rocfft}
 
 
 def micro_atlas_step(lm, dev, size, batch=8):
@@ -1044,6 +1076,8 @@ def main():
             result["other_ops"] = micro_ops(lm, dev, S)
             torch.cuda.empty_cache()
             result["atlas_step_128"] = micro_atlas_step(lm, dev, S)
+            torch.cuda.empty_cache()
+            result["brain_grid"] = micro_brain_grid(lm, dev)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S, E, args.cpu_sample_batch)
