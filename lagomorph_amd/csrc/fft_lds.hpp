@@ -862,5 +862,154 @@ struct ZY {
     static constexpr int NPH_INV = GY + GZ + 3;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Planes above the LDS (256 x 256, 192 x 224, ...: ny * (nz/2 + 1) * 8 B > 160 KB): the zy pass in two launches -- ROWS
+// (real transform along z of 64 rows per workgroup: the z phases of ZY on a 64-row "plane") and COLUMNS (transform along
+// y of 3 components x ny x 16 kz bins per workgroup, the data flow of the x pass without an operator) -- around the same
+// x pass: five launches instead of three, the same spectrum layout (row r holds ky = freq_at(r), column q holds kz =
+// freq_at(q), Nyquist plane apart) and the same coefficient table.
+template <class SZH_>
+struct ZRows {
+    static constexpr int RB = 64, NT = 512;
+    using K = ZY<Sz<1, 6>, SZH_, NT>;   // only its z phases are run
+    static constexpr int NZH = K::NZH, NZ = K::NZ, PZ = K::PZ, GZ = K::GZ, GYK = K::GY, KV = K::KV, F4 = K::F4;
+    static constexpr size_t SMEM = K::SMEM;
+    static_assert(!K::TW2, "one twiddle table");
+    // forward: phases 0 .. GZ + 1 of K::fwd_phase (load, z stages, split), then this store: column 0 keeps the packed pair
+    // (X[0], X[NZH]) of the row, which the column pass takes apart after ITS transform
+    LAGO_HD static void fwd_store(int tid, const float2 *P, float2 *mainp) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            if (tid + k * NT >= F4) continue;
+            const int e = (tid + k * NT) * 2, r = e / NZH, c = e % NZH;
+            const float2 *row = P + r * PZ;
+            const float2 a = row[c], cc = row[c + 1];
+            stg4<LAGO_NT_ZF_ST>(reinterpret_cast<float4 *>(mainp) + (tid + k * NT), make_float4(a.x, a.y, cc.x, cc.y));
+        }
+    }
+    // inverse: this fill (column 0 arrives packed from the column pass), then phases GY + 1 .. GY + GZ + 2 of K::inv_phase
+    // (merge, z stages, store with the output factor)
+    LAGO_HD static void inv_fill(int tid, const float2 *mainp, float2 *P) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            if (tid + k * NT >= F4) continue;
+            const float4 v = ldg4<LAGO_NT_ZI_LD>(reinterpret_cast<const float4 *>(mainp) + (tid + k * NT));
+            const int e = (tid + k * NT) * 2, r = e / NZH, c = e % NZH;
+            P[r * PZ + c] = make_float2(v.x, v.y);
+            P[r * PZ + c + 1] = make_float2(v.z, v.w);
+        }
+    }
+};
+
+struct YArgs {
+    float2 *main_, *nyq;
+    int nx, ny, nzh, ntile;   // ntile = nzh / 16 bin tiles per row
+    uint32_t total;           // nn * nx * ntile workgroups
+    int rev;
+};
+
+template <class SY_, int NT_ = 256>
+struct YPass {
+    static constexpr int NY = SY_::N, NT = NT_, KL = 16, KCP = KL + 1;
+    using T = Xf<SY_, KCP, 1, KL, 3, NY * KCP, NY, NT>;
+    static constexpr int G = stage_count<SY_>();
+    static constexpr int NPH = G + 3;   // forward: load | G stages | column 0 apart | store; inverse: load | column 0 packed | G stages | store
+    static constexpr int ROWS_IT = NT / 8, KLD = (3 * NY + ROWS_IT - 1) / ROWS_IT;
+    static constexpr bool RAGGED = 3 * NY % ROWS_IT != 0;
+    static constexpr size_t SMEM = (size_t)(3 * NY * KCP + NY) * sizeof(float2);
+    struct Block {   // workgroup-uniform: the three components of one (batch item, x), 16 kz bins of every row
+        float2 *base, *nyq;
+        size_t rs, cs, ncs;   // row stride, component stride (complex elements); component stride of the Nyquist plane
+        bool first;           // the tile holds column 0 (the packed real columns kz = 0 and kz = nz/2)
+    };
+    LAGO_HD static Block locate(const YArgs &a, uint32_t blk) {
+        const uint32_t qt = blk % (uint32_t)a.ntile, nxi = blk / (uint32_t)a.ntile;
+        const uint32_t x = nxi % (uint32_t)a.nx, n = nxi / (uint32_t)a.nx;
+        const size_t plane0 = (size_t)n * 3 * a.nx + x;
+        Block b;
+        b.rs = (size_t)a.nzh;
+        b.cs = (size_t)a.nx * a.ny * a.nzh;
+        b.ncs = (size_t)a.nx * a.ny;
+        b.base = a.main_ + plane0 * a.ny * a.nzh + (size_t)qt * KL;
+        b.nyq = a.nyq + plane0 * a.ny;
+        b.first = qt == 0;
+        return b;
+    }
+    LAGO_HD static float2 *row_ptr(const Block &b, int rr) { return b.base + (size_t)(rr / NY) * b.cs + (size_t)(rr % NY) * b.rs; }
+    LAGO_HD static void load_fill(int tid, const Block &b, float2 *buf) {
+        const int rg = tid >> 3, l8 = tid & 7;
+        float4 v[KLD];
+#pragma unroll
+        for (int k = 0; k < KLD; ++k)
+            if (!RAGGED || rg + k * ROWS_IT < 3 * NY) v[k] = ldg4<0>(reinterpret_cast<const float4 *>(row_ptr(b, rg + k * ROWS_IT) + 2 * l8));
+#pragma unroll
+        for (int k = 0; k < KLD; ++k) {
+            if (RAGGED && rg + k * ROWS_IT >= 3 * NY) continue;
+            float2 *d = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
+            d[0] = make_float2(v[k].x, v[k].y);
+            d[1] = make_float2(v[k].z, v[k].w);
+        }
+    }
+    LAGO_HD static void store(int tid, const Block &b, const float2 *buf) {
+        const int rg = tid >> 3, l8 = tid & 7;
+#pragma unroll
+        for (int k = 0; k < KLD; ++k) {
+            if (RAGGED && rg + k * ROWS_IT >= 3 * NY) continue;
+            const float2 *s = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
+            const float2 a = s[0], c = s[1];
+            stg4<0>(reinterpret_cast<float4 *>(row_ptr(b, rg + k * ROWS_IT) + 2 * l8), make_float4(a.x, a.y, c.x, c.y));
+        }
+    }
+    LAGO_HD static void fill_twiddles(int tid, float2 *tw) {
+        for (int t = tid; t < NY; t += NT) tw[t] = twiddle(t, NY);
+    }
+    // rows: natural y in, position r (ky = freq_at(r)) out
+    LAGO_HD static void fwd_phase(int ph, int tid, const Block &b, float2 *buf, float2 *tw) {
+        if (ph == 0) {
+            fill_twiddles(tid, tw);
+            load_fill(tid, b, buf);
+        } else if (ph <= G) {
+            run_stage<T, true>(ph - 1, buf, tw, tid);
+        } else if (ph == G + 1) {
+            // column 0 carried A + iB, A = X[0](y), B = X[NZH](y) both real (ZY::fwd_phase, same step): FA stays in column
+            // 0, FB goes to the Nyquist plane
+            if (b.first) for (int i = tid; i < 3 * (NY / 2 + 1); i += NT) {
+                const int c = i / (NY / 2 + 1), ky = i % (NY / 2 + 1);
+                const int rk = pos_of<SY_>(ky), rm = pos_of<SY_>((NY - ky) % NY);
+                float2 *pk = buf + (c * NY + rk) * KCP, *pm = buf + (c * NY + rm) * KCP;
+                const float2 a = pk[0], bb = pm[0];
+                const float2 FA = make_float2(0.5f * (a.x + bb.x), 0.5f * (a.y - bb.y));
+                const float2 D = make_float2(0.5f * (a.x - bb.x), 0.5f * (a.y + bb.y));
+                const float2 FB = make_float2(D.y, -D.x);
+                pk[0] = FA;
+                pm[0] = make_float2(FA.x, -FA.y);
+                b.nyq[(size_t)c * b.ncs + rk] = FB;
+                b.nyq[(size_t)c * b.ncs + rm] = make_float2(FB.x, -FB.y);
+            }
+        } else {
+            store(tid, b, buf);
+        }
+    }
+    // rows: position r in, natural y out (unnormalised)
+    LAGO_HD static void inv_phase(int ph, int tid, const Block &b, float2 *buf, float2 *tw) {
+        if (ph == 0) {
+            fill_twiddles(tid, tw);
+            load_fill(tid, b, buf);
+        } else if (ph == 1) {
+            // FA + i FB into column 0: the inverse transform then returns (X[0](y), X[NZH](y)) (ZY::inv_fill, same step)
+            if (b.first) for (int i = tid; i < 3 * NY; i += NT) {
+                const int c = i / NY, r = i % NY;
+                float2 *p = buf + (c * NY + r) * KCP;
+                const float2 fa = p[0], fb = b.nyq[(size_t)c * b.ncs + r];
+                p[0] = make_float2(fa.x - fb.y, fa.y + fb.x);
+            }
+        } else if (ph <= G + 1) {
+            run_stage<T, false>(ph - 2, buf, tw, tid);
+        } else {
+            store(tid, b, buf);
+        }
+    }
+};
+
 }  // namespace fl
 }  // namespace lago

@@ -48,7 +48,8 @@ static void op_double(const float *c, cd &X, cd &Y, cd &Z) {
     }
 }
 
-template <class SX, class SY, class SZH, bool INV, int NN = 2, int XT = 256>
+// BIG: the zy pass as two launches (ZRows + YPass: planes above the LDS) instead of the one-plane-per-workgroup ZY kernels
+template <class SX, class SY, class SZH, bool INV, int NN = 2, int XT = 256, bool BIG = false>
 static int run_case() {
     constexpr int NX = SX::N, NY = SY::N, NZH = SZH::N, NZ = 2 * NZH, NZC = NZH + 1;
     using Zy = ZY<SY, SZH>;
@@ -89,8 +90,30 @@ static int run_case() {
     const float *tabM = tabMw, *tabN = tabNw;
     const float scale = 1.0f / ((float)NX * NY * NZ);
 
-    std::vector<float2> lds(Zy::SMEM / sizeof(float2) + Xp::SMEM / sizeof(float2));
+    using ZR = ZRows<SZH>;
+    using ZK = typename ZR::K;
+    using Yp = YPass<SY, 256>;
+    std::vector<float2> lds(Zy::SMEM / sizeof(float2) + Xp::SMEM / sizeof(float2) + ZR::SMEM / sizeof(float2) + Yp::SMEM / sizeof(float2));
+    YArgs ya;
+    ya.main_ = mainb; ya.nyq = nyqb; ya.nx = NX; ya.ny = NY; ya.nzh = NZH; ya.ntile = NZH / 16;
+    ya.total = (uint32_t)(NN * NX * ya.ntile); ya.rev = 0;
+    const size_t nblocks = nplanes * NY / ZR::RB;
     // zy forward
+    if (BIG) {
+        for (size_t blk = 0; blk < nblocks; ++blk) {
+            float2 *P = lds.data(), *tw = P + ZR::RB * ZR::PZ;
+            for (int ph = 0; ph <= ZR::GZ + 1; ++ph)
+                for (int tid = 0; tid < ZR::NT; ++tid)
+                    ZK::fwd_phase(ph, tid, m.data() + blk * ZR::RB * NZ, nullptr, nullptr, P, tw);
+            for (int tid = 0; tid < ZR::NT; ++tid) ZR::fwd_store(tid, P, mainb + blk * ZR::RB * NZH);
+        }
+        for (uint32_t blk = 0; blk < ya.total; ++blk) {
+            const auto b = Yp::locate(ya, blk);
+            float2 *buf = lds.data(), *tw = buf + 3 * NY * Yp::KCP;
+            for (int ph = 0; ph < Yp::NPH; ++ph)
+                for (int tid = 0; tid < 256; ++tid) Yp::fwd_phase(ph, tid, b, buf, tw);
+        }
+    } else
     for (size_t p = 0; p < nplanes; ++p) {
         float2 *P = lds.data(), *tw = P + NY * Zy::PZ;
         for (int ph = 0; ph < Zy::NPH; ++ph)
@@ -128,6 +151,22 @@ static int run_case() {
             for (int tid = 0; tid < XT; ++tid) Xp::phase(ph, tid, regs[tid], b, buf, tw, xa.scale);
     }
     // zy inverse
+    if (BIG) {
+        for (uint32_t blk = 0; blk < ya.total; ++blk) {
+            const auto b = Yp::locate(ya, blk);
+            float2 *buf = lds.data(), *tw = buf + 3 * NY * Yp::KCP;
+            for (int ph = 0; ph < Yp::NPH; ++ph)
+                for (int tid = 0; tid < 256; ++tid) Yp::inv_phase(ph, tid, b, buf, tw);
+        }
+        for (size_t blk = 0; blk < nblocks; ++blk) {
+            float2 *P = lds.data(), *tw = P + ZR::RB * ZR::PZ;
+            for (int tid = 0; tid < ZR::NT; ++tid) ZK::fill_twiddles(tid, tw);
+            for (int tid = 0; tid < ZR::NT; ++tid) ZR::inv_fill(tid, mainb + blk * ZR::RB * NZH, P);
+            for (int ph = ZR::GYK + 1; ph <= ZR::GYK + ZR::GZ + 2; ++ph)
+                for (int tid = 0; tid < ZR::NT; ++tid)
+                    ZK::inv_phase(ph, tid, out.data() + blk * ZR::RB * NZ, nullptr, nullptr, P, tw);
+        }
+    } else
     for (size_t p = 0; p < nplanes; ++p) {
         float2 *P = lds.data(), *tw = P + NY * Zy::PZ;
         for (int ph = 0; ph < Zy::NPH_INV; ++ph)
@@ -201,6 +240,10 @@ int main() {
     // half lengths 44 = 11 * 4 and 52 = 13 * 4 (two radix-2 levels), 88-point x lines (5 1/2 operator rows per thread)
     bad += run_case<Sz<11, 3>, Sz<13, 3>, Sz<11, 2>, true, 1>();     // 88 x 104 x 88
     bad += run_case<Sz<13, 3>, Sz<11, 3>, Sz<13, 2>, false, 1>();    // 104 x 88 x 104 (x lengths with NX % 16 = 0 do not take such planes)
+    // planes above the LDS: rows + columns around the x pass (ZRows, YPass) -- on small shapes here, the code is the same
+    bad += run_case<Sz<1, 4>, Sz<1, 6>, Sz<1, 5>, true, 2, 256, true>();     // 16 x 64 x 64
+    bad += run_case<Sz<1, 4>, Sz<3, 6>, Sz<3, 4>, false, 1, 256, true>();    // 16 x 192 x 96
+    bad += run_case<Sz<1, 5>, Sz<7, 4>, Sz<1, 6>, true, 1, 256, true>();     // 32 x 112 x 128
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }
