@@ -461,9 +461,11 @@ __global__ __launch_bounds__((ypass_threads<NY>())) void ypass_kernel(fl::YArgs 
     X(104, 88) X(88, 88) X(88, 104) X(120, 120) X(80, 80)
 #define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256) X(176) X(208) X(112) X(224) X(144) X(240) X(88) X(104) X(120) X(80)
 
-// lengths the rows + columns route (planes above the LDS) is instantiated for: any pair of them that has no one-kernel
-// zy instantiation -- 256 x 256, 224 x 224, 192 x 224, 224 x 192, 256 x 192, ... planes
-#define LAGO_BIG_SIZES(X) X(192) X(224) X(256)
+// lengths the rows + columns route is instantiated for: every (ny, nz) pair of them that has no one-kernel zy
+// instantiation -- the planes above the LDS (256 x 256, 224 x 224, 192 x 224, 208 x 192, 240 x 224 ...) and mixed planes
+// nobody listed (176 x 160, 144 x 128 ...).  Rows: nz / 2 a multiple of 16 (the column pass's bin tiles).
+#define LAGO_BIG_Y_SIZES(X) X(128) X(144) X(160) X(176) X(192) X(208) X(224) X(240) X(256)
+#define LAGO_BIG_Z_SIZES(X) X(128) X(160) X(192) X(224) X(256)
 
 static bool zy_instantiated(int64_t ny, int64_t nz) {
     bool ok = false;
@@ -474,8 +476,11 @@ static bool zy_instantiated(int64_t ny, int64_t nz) {
 }
 static bool big_plane_supported(int64_t ny, int64_t nz) {
     bool oky = false, okz = false;
-#define X(N) oky = oky || ny == N; okz = okz || nz == N;
-    LAGO_BIG_SIZES(X)
+#define X(N) oky = oky || ny == N;
+    LAGO_BIG_Y_SIZES(X)
+#undef X
+#define X(N) okz = okz || nz == N;
+    LAGO_BIG_Z_SIZES(X)
 #undef X
     return oky && okz && !zy_instantiated(ny, nz);
 }
@@ -652,14 +657,14 @@ static hipError_t big_zy_dispatch(int64_t nx, int64_t ny, int64_t nz, int64_t nn
     auto rows = [&]() {
         hipError_t r = hipErrorInvalidValue;
 #define X(N) if (nz == N) r = zrows_launch<N>(za, blocks, inverse, s);
-        LAGO_BIG_SIZES(X)
+        LAGO_BIG_Z_SIZES(X)
 #undef X
         return r;
     };
     auto cols = [&]() {
         hipError_t r = hipErrorInvalidValue;
 #define X(N) if (ny == N) r = ypass_launch<N>(ya, inverse, s);
-        LAGO_BIG_SIZES(X)
+        LAGO_BIG_Y_SIZES(X)
 #undef X
         return r;
     };
