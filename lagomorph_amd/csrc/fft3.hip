@@ -463,9 +463,10 @@ __global__ __launch_bounds__((ypass_threads<NY>())) void ypass_kernel(fl::YArgs 
 
 // lengths the rows + columns route is instantiated for: every (ny, nz) pair of them that has no one-kernel zy
 // instantiation -- the planes above the LDS (256 x 256, 224 x 224, 192 x 224, 208 x 192, 240 x 224 ...) and mixed planes
-// nobody listed (176 x 160, 144 x 128 ...).  Rows: nz / 2 a multiple of 16 (the column pass's bin tiles).
+// nobody listed (176 x 160, 144 x 128, 208 x 208 ...).  (nz / 2 = 72, 88, 104, 120: the column pass masks the half tile at the
+// end of every row.)
 #define LAGO_BIG_Y_SIZES(X) X(128) X(144) X(160) X(176) X(192) X(208) X(224) X(240) X(256)
-#define LAGO_BIG_Z_SIZES(X) X(128) X(160) X(192) X(224) X(256)
+#define LAGO_BIG_Z_SIZES(X) X(128) X(144) X(160) X(176) X(192) X(208) X(224) X(240) X(256)
 
 static bool zy_instantiated(int64_t ny, int64_t nz) {
     bool ok = false;
@@ -650,7 +651,7 @@ static hipError_t ypass_launch(const fl::YArgs &a, bool inverse, hipStream_t s) 
 // the zy transform of planes above the LDS: rows then columns (forward), columns then rows (inverse)
 static hipError_t big_zy_dispatch(int64_t nx, int64_t ny, int64_t nz, int64_t nn, const fl::ZYArgs &za, bool inverse, hipStream_t s) {
     fl::YArgs ya;
-    ya.main_ = za.main_; ya.nyq = za.nyq; ya.nx = (int)nx; ya.ny = (int)ny; ya.nzh = (int)(nz / 2); ya.ntile = (int)(nz / 32);
+    ya.main_ = za.main_; ya.nyq = za.nyq; ya.nx = (int)nx; ya.ny = (int)ny; ya.nzh = (int)(nz / 2); ya.ntile = (int)((nz / 2 + 15) / 16);
     ya.total = (uint32_t)(nn * nx * ya.ntile); ya.rev = za.rev;
     const uint32_t blocks = (uint32_t)((uint64_t)za.total * (uint64_t)ny / 64u);
     hipError_t e = hipErrorInvalidValue;
@@ -717,7 +718,7 @@ int fluid_metric_native(float *out, const float *m, float *work, const float *ta
     hipError_t e = hipSuccess;
     za.rev = next_direction();
     const bool big = !zy_instantiated(ny, nz);   // (fluid_native_supported: then the rows + columns route covers the plane)
-    if (big && (nn * nx * (nz / 32) >= (1ll << 31) || planes * ny / 64 >= (1ll << 31))) return fail_invalid("fluid_metric: batch too large");
+    if (big && (nn * nx * ((nz / 2 + 15) / 16) >= (1ll << 31) || planes * ny / 64 >= (1ll << 31))) return fail_invalid("fluid_metric: batch too large");
     if (stages & 1) e = big ? big_zy_dispatch(nx, ny, nz, nn, za, false, s) : zy_dispatch(ny, nz, za, false, s);
     if (e != hipSuccess) return fail_hip(e, "fluid_metric (zy forward)");
     xa.rev = next_direction();

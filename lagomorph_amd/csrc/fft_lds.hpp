@@ -903,7 +903,7 @@ struct ZRows {
 
 struct YArgs {
     float2 *main_, *nyq;
-    int nx, ny, nzh, ntile;   // ntile = nzh / 16 bin tiles per row
+    int nx, ny, nzh, ntile;   // ntile = ceil(nzh / 16) bin tiles per row (the last one holds 8 bins where nzh % 16 = 8)
     uint32_t total;           // nn * nx * ntile workgroups
     int rev;
 };
@@ -921,6 +921,7 @@ struct YPass {
         float2 *base, *nyq;
         size_t rs, cs, ncs;   // row stride, component stride (complex elements); component stride of the Nyquist plane
         bool first;           // the tile holds column 0 (the packed real columns kz = 0 and kz = nz/2)
+        int nv;               // bins of the tile that exist (16, or nzh % 16 in a row's last tile): the other lanes load zeros, store nothing
     };
     LAGO_HD static Block locate(const YArgs &a, uint32_t blk) {
         const uint32_t qt = blk % (uint32_t)a.ntile, nxi = blk / (uint32_t)a.ntile;
@@ -933,6 +934,7 @@ struct YPass {
         b.base = a.main_ + plane0 * a.ny * a.nzh + (size_t)qt * KL;
         b.nyq = a.nyq + plane0 * a.ny;
         b.first = qt == 0;
+        b.nv = min(KL, a.nzh - (int)qt * KL);
         return b;
     }
     LAGO_HD static float2 *row_ptr(const Block &b, int rr) { return b.base + (size_t)(rr / NY) * b.cs + (size_t)(rr % NY) * b.rs; }
@@ -941,7 +943,8 @@ struct YPass {
         float4 v[KLD];
 #pragma unroll
         for (int k = 0; k < KLD; ++k)
-            if (!RAGGED || rg + k * ROWS_IT < 3 * NY) v[k] = ldg4<0>(reinterpret_cast<const float4 *>(row_ptr(b, rg + k * ROWS_IT) + 2 * l8));
+            if (2 * l8 >= b.nv) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (!RAGGED || rg + k * ROWS_IT < 3 * NY) v[k] = ldg4<0>(reinterpret_cast<const float4 *>(row_ptr(b, rg + k * ROWS_IT) + 2 * l8));
 #pragma unroll
         for (int k = 0; k < KLD; ++k) {
             if (RAGGED && rg + k * ROWS_IT >= 3 * NY) continue;
@@ -954,7 +957,7 @@ struct YPass {
         const int rg = tid >> 3, l8 = tid & 7;
 #pragma unroll
         for (int k = 0; k < KLD; ++k) {
-            if (RAGGED && rg + k * ROWS_IT >= 3 * NY) continue;
+            if ((RAGGED && rg + k * ROWS_IT >= 3 * NY) || 2 * l8 >= b.nv) continue;
             const float2 *s = buf + (rg + k * ROWS_IT) * KCP + 2 * l8;
             const float2 a = s[0], c = s[1];
             stg4<0>(reinterpret_cast<float4 *>(row_ptr(b, rg + k * ROWS_IT) + 2 * l8), make_float4(a.x, a.y, c.x, c.y));

@@ -95,7 +95,7 @@ static int run_case() {
     using Yp = YPass<SY, 256>;
     std::vector<float2> lds(Zy::SMEM / sizeof(float2) + Xp::SMEM / sizeof(float2) + ZR::SMEM / sizeof(float2) + Yp::SMEM / sizeof(float2));
     YArgs ya;
-    ya.main_ = mainb; ya.nyq = nyqb; ya.nx = NX; ya.ny = NY; ya.nzh = NZH; ya.ntile = NZH / 16;
+    ya.main_ = mainb; ya.nyq = nyqb; ya.nx = NX; ya.ny = NY; ya.nzh = NZH; ya.ntile = (NZH + 15) / 16;
     ya.total = (uint32_t)(NN * NX * ya.ntile); ya.rev = 0;
     const size_t nblocks = nplanes * NY / ZR::RB;
     // zy forward
@@ -244,6 +244,7 @@ int main() {
     bad += run_case<Sz<1, 4>, Sz<1, 6>, Sz<1, 5>, true, 2, 256, true>();     // 16 x 64 x 64
     bad += run_case<Sz<1, 4>, Sz<3, 6>, Sz<3, 4>, false, 1, 256, true>();    // 16 x 192 x 96
     bad += run_case<Sz<1, 5>, Sz<7, 4>, Sz<1, 6>, true, 1, 256, true>();     // 32 x 112 x 128
+    bad += run_case<Sz<1, 4>, Sz<1, 6>, Sz<11, 3>, false, 1, 256, true>();   // 16 x 64 x 176 (88 bins per row: the column pass's half tile)
     printf(bad ? "FAILED\n" : "all ok\n");
     return bad;
 }

@@ -20,7 +20,8 @@ SHAPES = [(256, 64, 128), (64, 256, 64), (256, 128, 256), (192, 192, 192), (96, 
           (88, 104, 88), (104, 88, 88), (88, 88, 104), (120, 120, 120), (80, 80, 80), (120, 88, 88), (88, 120, 120), (104, 104, 88),
           # planes above the LDS: rows + columns around the x pass (five launches)
           (256, 256, 256), (64, 256, 256), (160, 192, 224), (192, 224, 192), (224, 224, 224), (96, 256, 192), (128, 224, 256),
-          (64, 176, 160), (112, 144, 128), (176, 208, 192), (240, 240, 224), (80, 128, 224)]
+          (64, 176, 160), (112, 144, 128), (176, 208, 192), (240, 240, 224), (80, 128, 224),
+          (96, 208, 208), (64, 256, 176), (240, 240, 240), (128, 224, 144), (176, 192, 208)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"{a}x{b}x{c}" for a, b, c in SHAPES])

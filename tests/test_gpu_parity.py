@@ -600,7 +600,7 @@ def test_vector_and_scalar_kernels_agree_bitwise(ext, dtype):
                                 # 8 x odd extents: the short last tile of the Nyquist plane
                                 (88, 104, 88), (120, 120, 120), (80, 80, 80), (104, 88, 104), (120, 88, 88),
                                 # planes above the LDS: the rows + columns route
-                                (64, 256, 256), (64, 192, 224), (64, 224, 192), (96, 224, 224), (64, 256, 192)])
+                                (64, 256, 256), (64, 192, 224), (64, 224, 192), (96, 224, 224), (64, 256, 192), (64, 208, 208), (64, 160, 176)])
 @pytest.mark.parametrize("inverse", [True, False])
 def test_fused_fluid_metric_paths(ext, sp, inverse):
     """float32 3D: the three implementations of FluidMetric sharp/flat -- (2) three LDS-tiled FFT
