@@ -11,41 +11,9 @@
 // HBM traffic per call: 6 passes of 4 B/voxel-component (read m, write+read+write+read the
 // spectrum, write out) + the coefficient table, against 14 for rocFFT's 3D plan + operator.
 #include <algorithm>
-#include "common.hpp"
-#include "fft_lds.hpp"
+#include "fft3_sizes.hpp"
 
 namespace lago {
-
-// transform length -> its factorisation R * 2^L2 (fft_lds.hpp)
-template <int N> struct SzOf;
-template <> struct SzOf<32> { using T = fl::Sz<1, 5>; };
-template <> struct SzOf<48> { using T = fl::Sz<3, 4>; };
-template <> struct SzOf<64> { using T = fl::Sz<1, 6>; };
-template <> struct SzOf<80> { using T = fl::Sz<5, 4>; };
-template <> struct SzOf<96> { using T = fl::Sz<3, 5>; };
-template <> struct SzOf<128> { using T = fl::Sz<1, 7>; };
-template <> struct SzOf<160> { using T = fl::Sz<5, 5>; };
-template <> struct SzOf<192> { using T = fl::Sz<3, 6>; };
-template <> struct SzOf<256> { using T = fl::Sz<1, 8>; };
-// 176 = 11 * 16 and 208 = 13 * 16 (half lengths 88, 104): the 176 x 208 x 176 volumes of the OASIS brain images (round 6)
-template <> struct SzOf<88> { using T = fl::Sz<11, 3>; };
-template <> struct SzOf<104> { using T = fl::Sz<13, 3>; };
-template <> struct SzOf<176> { using T = fl::Sz<11, 4>; };
-template <> struct SzOf<208> { using T = fl::Sz<13, 4>; };
-// 7, 9 and 15 times a power of two: 96 x 112 x 96 and 192 x 224 x 160 (cropped MNI grids), 144^3 / 144 x 176 x 144, 240
-template <> struct SzOf<56> { using T = fl::Sz<7, 3>; };
-template <> struct SzOf<112> { using T = fl::Sz<7, 4>; };
-template <> struct SzOf<224> { using T = fl::Sz<7, 5>; };
-template <> struct SzOf<72> { using T = fl::Sz<9, 3>; };
-template <> struct SzOf<144> { using T = fl::Sz<9, 4>; };
-template <> struct SzOf<120> { using T = fl::Sz<15, 3>; };
-template <> struct SzOf<240> { using T = fl::Sz<15, 4>; };
-// 8 times an odd factor (ny % 16 = 8: the Nyquist plane's last tile is half a tile) and the half lengths that go with them:
-// 88 x 104 x 88 (the 176 x 208 x 176 grid at half resolution: multiscale momenta), 120^3, 80^3 (160^3 at half resolution)
-template <> struct SzOf<40> { using T = fl::Sz<5, 3>; };
-template <> struct SzOf<44> { using T = fl::Sz<11, 2>; };
-template <> struct SzOf<52> { using T = fl::Sz<13, 2>; };
-template <> struct SzOf<60> { using T = fl::Sz<15, 2>; };
 
 template <int NY, int NZ>
 using ZYK = fl::ZY<typename SzOf<NY>::T, typename SzOf<NZ / 2>::T>;
@@ -83,16 +51,6 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_kernel(fl::
     }
 }
 
-// Planes whose LDS image leaves room for ONE workgroup per CU only (160 x 160: 104 KB) have nobody to hide their
-// global loads behind: a grid of one persistent workgroup per CU walks the planes and requests plane p + grid into
-// registers (7 float4 per thread) while it transforms plane p.  Two details of that loop, both measured
-// (tools/probes/zy_probe.hip, profiles/r03_zy_passes.md):
-//  * the loads are spread over the transform's phases (one or two per phase) instead of issued together, so that their
-//    issue time hides behind other waves' LDS work;
-//  * the prefetched registers are waited for BEFORE the store phase (`settle`: an empty asm that takes them as
-//    operands).  hipcc counts loads and stores in one counter and waits vmcnt(0) at the next fill, i.e. for this
-//    plane's stores to be acknowledged; with the wait in front of the stores the fill finds nothing pending.
-__device__ __forceinline__ void settle(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
 template <int NY, int NZ>
 __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_forward_persist_kernel(fl::ZYArgs a) {
@@ -167,12 +125,6 @@ __global__ __launch_bounds__((ZYK<NY, NZ>::THREADS)) void zy_inverse_persist_ker
     }
 }
 
-template <typename Kern>
-static hipError_t allow_smem(Kern k, size_t smem) {
-    if (smem <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem);
-}
 
 // ---- 2D fields: the whole FluidMetricOperator.forward (metric.py:11-19) of one batch item in ONE kernel ----------
 // Both component planes of an (H, W) field fit the LDS together up to about 128 x 128 (2 x 66.5 KB): real 2D
@@ -312,84 +264,6 @@ int fluid_metric_2d(float *out, const float *m, int inverse, const float *cosX, 
     return finish_launch(s, "fluid_metric");
 }
 
-// threads per x-pass workgroup: 256, except for the 256-point tile (104 KB: one workgroup per CU, which 512 threads
-// serve 12 % faster).  Measured (tools/ab_fluid.py): wider workgroups LOSE 3-14 % at 128, 160 and 192 points, where
-// two or three 256-thread workgroups share a CU and their 120+ VGPRs per thread would cost the second one.
-template <int NX> constexpr int xpass_wide() { return NX >= 208 ? 512 : 256; }   // (208, 224, 240: 86 - 100 KB, alone on their CU as well)
-
-template <int NX, bool INV, int NT>
-__global__ __launch_bounds__(NT) void fluid_xpass2_kernel(fl::XArgs a) {
-    using K = fl::XPass<typename SzOf<NX>::T, INV, NT>;
-    extern __shared__ __align__(16) unsigned char lago_smem[];
-    float2 *buf = reinterpret_cast<float2 *>(lago_smem), *tw = buf + 3 * K::NX * K::KCP;
-    const uint32_t blk = block_order(blockIdx.x, a.total, a.rev);
-    typename K::Block b = K::locate(a, blk);
-    typename K::Regs r;
-    // consecutive batch items under the same coefficients (held in registers): the 24-byte table
-    // entry of a bin is then read once per `ipw` items instead of once per item
-    const uint32_t n0 = blk / (uint32_t)a.items_per_n * (uint32_t)a.ipw;
-    const int nit = min(a.ipw, a.nn - (int)n0);
-    for (int it = 0; it < nit; ++it) {
-#pragma unroll
-        for (int ph = 0; ph < K::NPH; ++ph) {
-            K::phase(ph, threadIdx.x, r, b, buf, tw, a.scale, it == 0);
-            if (ph + 1 < K::NPH || it + 1 < nit) __syncthreads();
-        }
-        b.base += (size_t)3 * K::NX * b.xs;  // next batch item, same bins
-    }
-}
-
-// The x pass as a persistent grid (two workgroups per CU): each workgroup walks a contiguous run of (bin tile, batch
-// item) pairs -- batch items innermost, so the coefficients stay in registers until the bin tile changes -- and
-// requests the next tile into registers, spread over the phases of the current one; the prefetched registers are
-// settled before the store phase (see zy_forward_persist_kernel).  One-shot workgroups, two per CU, overlap their
-// load / compute / store only by chance: 388 -> ... us at 32 x 3 x 128^3 (tools/ab_fluid.py).
-template <int NX, bool INV, int NT>
-__global__ __launch_bounds__(NT) void fluid_xpass2_persist_kernel(fl::XArgs a) {
-    using K = fl::XPass<typename SzOf<NX>::T, INV, NT>;
-    extern __shared__ __align__(16) unsigned char lago_smem[];
-    float2 *buf = reinterpret_cast<float2 *>(lago_smem), *tw = buf + 3 * K::NX * K::KCP;
-    const uint32_t T = (uint32_t)a.nn * (uint32_t)a.items_per_n;
-    const uint32_t q0 = (uint32_t)((uint64_t)blockIdx.x * T / gridDim.x), q1 = (uint32_t)((uint64_t)(blockIdx.x + 1) * T / gridDim.x);
-    if (q0 >= q1) return;
-    auto at = [&](uint32_t q) {   // pair number q of the launch: bin tile q / nn, batch item q % nn
-        const uint32_t qq = a.rev ? T - 1u - q : q;
-        return K::locate(a, qq % (uint32_t)a.nn, qq / (uint32_t)a.nn);
-    };
-    K::fill_twiddles(threadIdx.x, tw);
-    typename K::Regs r;
-    float4 v[K::KLD];
-    typename K::Block b = at(q0);
-    const float *tb_held = nullptr;
-#pragma unroll
-    for (int k = 0; k < K::KLD; ++k) K::load_one(threadIdx.x, b, v, k);
-    for (uint32_t q = q0; q < q1; ++q) {
-        K::fill(threadIdx.x, v, buf);
-        if (b.tb != tb_held) {   // workgroup-uniform: a new bin tile
-            K::load_coef(threadIdx.x, r, b);
-            tb_held = b.tb;
-        }
-        __syncthreads();
-        const bool more = q + 1 < q1;
-        const typename K::Block bn = more ? at(q + 1) : b;
-#pragma unroll
-        for (int ph = 1; ph < K::NPH; ++ph) {
-            constexpr int NS = K::NPH - 2;   // phases the loads are spread over
-            if (ph <= NS && more) {
-#pragma unroll
-                for (int k = (ph - 1) * K::KLD / NS; k < ph * K::KLD / NS; ++k) K::load_one(threadIdx.x, bn, v, k);
-            }
-            if (ph == K::NPH - 1) {
-#pragma unroll
-                for (int k = 0; k < K::KLD; ++k) settle(v[k]);
-            }
-            K::phase(ph, threadIdx.x, r, b, buf, tw, a.scale, false);
-            __syncthreads();
-        }
-        b = bn;
-    }
-}
-
 // ---- planes above the LDS: rows + columns (fft_lds.hpp: ZRows, YPass) ---------------------------------------------
 template <int NZ>
 using ZRK = fl::ZRows<typename SzOf<NZ / 2>::T>;
@@ -459,7 +333,6 @@ __global__ __launch_bounds__((ypass_threads<NY>())) void ypass_kernel(fl::YArgs 
     X(112, 96) X(96, 112) X(112, 112) X(128, 112) X(112, 128) X(224, 160) X(160, 224) X(224, 128)      \
     X(144, 144) X(176, 144) X(144, 176) X(240, 160) X(160, 240)                                        \
     X(104, 88) X(88, 88) X(88, 104) X(120, 120) X(80, 80)
-#define LAGO_X_SIZES(X) X(64) X(96) X(128) X(160) X(192) X(256) X(176) X(208) X(112) X(224) X(144) X(240) X(88) X(104) X(120) X(80)
 
 // lengths the rows + columns route is instantiated for: every (ny, nz) pair of them that has no one-kernel zy
 // instantiation -- the planes above the LDS (256 x 256, 224 x 224, 192 x 224, 208 x 192, 240 x 224 ...) and mixed planes
@@ -542,68 +415,6 @@ static hipError_t zy_dispatch(int64_t ny, int64_t nz, const fl::ZYArgs &a, bool 
 #define X(NY, NZ) \
     if (ny == NY && nz == NZ) return zy_launch<NY, NZ>(a, inverse, s);
     LAGO_ZY_SHAPES(X)
-#undef X
-    return hipErrorInvalidValue;
-}
-
-std::atomic<int> g_xpass_persist{1};  // 1: persistent x-pass grid (two workgroups per CU) once the launch has enough pairs; 2: always
-
-template <int NX, int NT>
-static hipError_t xpass2_launch_nt(const fl::XArgs &a, bool inverse, hipStream_t s) {
-    using K0 = fl::XPass<typename SzOf<NX>::T, false, NT>;
-    // persistent: tiles that fit a CU twice, and at least eight (bin tile, batch item) pairs per workgroup (below that the
-    // one-shot workgroups are as fast or faster: 142 against 146 us per sharp at 4 x 128^3, tools/ab_fluid.py)
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / K0::SMEM);
-    const uint64_t pairs = (uint64_t)a.nn * (uint64_t)a.items_per_n;
-    const int mode = g_xpass_persist;   // 2 (tests): whatever the size of the launch
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(256u * per_cu, pairs);
-    // (192 points: 263 VGPRs, one 256-thread workgroup per CU -- stays with the one-shot workgroups)
-    // (the persistent kernels exist only for the lengths whose tile fits a CU twice)
-    constexpr bool kCanPersist = K0::SMEM * 2 <= 160 * 1024 && (NX <= 160 || NX == 176);
-    const bool persist = mode && kCanPersist && (mode >= 2 || pairs >= 8ull * grid) && pairs < (1ull << 32);
-    if (inverse) {
-        using K = fl::XPass<typename SzOf<NX>::T, true, NT>;
-        if constexpr (kCanPersist) if (persist) {
-            auto k = fluid_xpass2_persist_kernel<NX, true, NT>;
-            hipError_t e = allow_smem(k, K::SMEM);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(NT), K::SMEM, s, a);
-            return hipSuccess;
-        }
-        auto k = fluid_xpass2_kernel<NX, true, NT>;
-        hipError_t e = allow_smem(k, K::SMEM);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
-    } else {
-        using K = fl::XPass<typename SzOf<NX>::T, false, NT>;
-        if constexpr (kCanPersist) if (persist) {
-            auto k = fluid_xpass2_persist_kernel<NX, false, NT>;
-            hipError_t e = allow_smem(k, K::SMEM);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(NT), K::SMEM, s, a);
-            return hipSuccess;
-        }
-        auto k = fluid_xpass2_kernel<NX, false, NT>;
-        hipError_t e = allow_smem(k, K::SMEM);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(a.total), dim3(NT), K::SMEM, s, a);
-    }
-    return hipSuccess;
-}
-
-std::atomic<int> g_xpass_wide{1};
-
-template <int NX>
-static hipError_t xpass2_launch(const fl::XArgs &a, bool inverse, hipStream_t s) {
-    if constexpr (xpass_wide<NX>() != 256)
-        if (g_xpass_wide) return xpass2_launch_nt<NX, xpass_wide<NX>()>(a, inverse, s);
-    return xpass2_launch_nt<NX, 256>(a, inverse, s);
-}
-
-static hipError_t xpass2_dispatch(int64_t nx, const fl::XArgs &a, bool inverse, hipStream_t s) {
-#define X(N) \
-    if (nx == N) return xpass2_launch<N>(a, inverse, s);
-    LAGO_X_SIZES(X)
 #undef X
     return hipErrorInvalidValue;
 }
