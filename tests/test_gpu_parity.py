@@ -894,7 +894,8 @@ def test_persistent_zy_passes_any_plane_count(ext, batch, plane):
 
 
 @pytest.mark.parametrize("shape,batch", [((64, 64, 64), 1), ((64, 96, 64), 3), ((128, 64, 96), 2), ((160, 64, 64), 5),
-                                         ((96, 32, 128), 7), ((176, 32, 64), 3), ((176, 176, 176), 1)])
+                                         ((96, 32, 128), 7), ((176, 32, 64), 3), ((176, 176, 176), 1),
+                                         ((88, 104, 88), 3), ((120, 120, 120), 2), ((144, 64, 64), 5)])
 @pytest.mark.parametrize("inverse", [True, False])
 def test_persistent_x_pass_any_pair_count(ext, shape, batch, inverse):
     """The x pass as a persistent grid: each workgroup walks a contiguous run of (bin tile, batch item) pairs with its
