@@ -106,7 +106,8 @@ typedef struct lago_tuning {
      * with the planes 112x96, 96x112, 112x112, 128x112, 112x128, 224x160, 160x224, 224x128, 144x144, 176x144, 144x176,
      * 240x160, 160x240 (odd factors 7, 9, 15), and nx in {80,88,104,120} with the planes 80x80, 104x88, 88x88, 88x104, 120x120
      * (a plane with ny % 16 = 8 needs nx % 16 = 8 as well); planes above the LDS or not in these lists, ny in {128,144,...,256}
-     * (multiples of 16 with an odd factor up to 15) and nz from the same set, as rows + columns (five launches:
+     * (multiples of 16 with an odd factor up to 15) and nz from the same set -- since the lists hold every multiple of 16
+     * from 64 to 256, ANY volume with such extents -- as rows + columns (five launches:
      * 256^3, 160 x 192 x 224, 192 x 224 x 192 ...); float32 2D planes up to 128 x 128 in
      * one fused kernel) and the generic hand-written passes of csrc/fftg.hip for every other shape and for float64
      * (any extent up to 4096 (float32) / 2048 (float64) points per axis, lines with a prime factor >= 29 through

@@ -21,7 +21,7 @@ OBJ = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblagomorph_hip.so")
 LIB_PROF = os.path.join(LIBDIR, "liblagomorph_hip_prof.so")
-SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip", "fft3x.hip", "fftg.hip"]
+SOURCES = ["api.hip", "interp.hip", "splat.hip", "diff.hip", "metric.hip", "affine.hip", "fused.hip", "fft.hip", "fftx.hip", "fft3.hip", "fft3x.hip", "fft3b.hip", "fftg.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # extra compiler flags for A/B builds of tools/ (e.g. LAGO_HIPCC_EXTRA="-DLAGO_NT_X_LD=1"; use -f: objects are not keyed on flags)
 EXTRA = os.environ.get("LAGO_HIPCC_EXTRA", "").split()

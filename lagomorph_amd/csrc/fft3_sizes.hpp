@@ -64,4 +64,8 @@ static hipError_t allow_smem(Kern k, size_t smem) {
 hipError_t xpass2_dispatch(int64_t nx, const fl::XArgs &a, bool inverse, hipStream_t s);
 extern std::atomic<int> g_xpass_persist, g_xpass_wide;
 
+// fft3b.hip: the rows + columns route
+bool big_sizes_instantiated(int64_t ny, int64_t nz);
+hipError_t big_zy_dispatch(int64_t nx, int64_t ny, int64_t nz, int64_t nn, const fl::ZYArgs &za, bool inverse, hipStream_t s);
+
 }  // namespace lago

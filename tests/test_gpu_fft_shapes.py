@@ -41,6 +41,31 @@ def test_fft_passes_match_the_float64_path(shape):
         assert err <= 2e-6, (shape, err)
 
 
+def test_every_multiple_of_16_from_64_to_256_runs_the_lds_passes():
+    """The rule the instantiation lists add up to (round 6): any float32 volume whose three extents are multiples of 16 between
+    64 and 256 takes the LDS-tiled passes (three launches where its plane has a one-kernel instantiation, rows + columns
+    otherwise), never the generic passes or rocFFT.  A seeded sample of 40 such shapes against the float64 path."""
+    import random
+
+    import lagomorph_amd as lm
+
+    ext = lm.lagomorph_ext
+    met = lm.FluidMetric([0.1, 0.05, 0.01])
+    rnd = random.Random(16)
+    sizes = list(range(64, 257, 16))
+    g = torch.Generator(device="cuda").manual_seed(16)
+    for _ in range(40):
+        shape = tuple(rnd.choice(sizes) for _ in range(3))
+        m = torch.randn((1, 3) + shape, device="cuda", generator=g)
+        before = ext.path_launches("fluid_lds")
+        out = met.sharp(m)
+        assert ext.path_launches("fluid_lds") == before + 1, shape
+        ref = met.sharp(m.double())
+        err = float((out.double() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-6, (shape, err)
+        del m, out, ref
+
+
 @pytest.mark.parametrize("sp,dtype,mode", [
     ((128, 128, 128), torch.float32, 3), ((160, 160, 160), torch.float32, 3),   # tuned passes (persistent zy at 160)
     ((64, 96, 128), torch.float32, 3), ((32, 32, 64), torch.float32, 3),
